@@ -1,0 +1,101 @@
+"""The oracle (oracle/restatement.py) against outputs of the real reference
+(tests/golden/*.npz, made by tests/golden/make_fixtures.py)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import case_from_golden, load_golden, t
+import ick_amd.synth as synth
+from oracle import restatement as R
+
+FWD = ["fwd_tiny_geo", "fwd_tiny_knowledge", "fwd_tiny_news", "fwd_cfg1_geo", "fwd_mid_geo", "fwd_mid_knowledge"]
+TOL = 2e-5  # fp32, different summation order only
+
+
+@pytest.mark.parametrize("name", FWD)
+def test_forward_scores(name):
+    g = load_golden(name)
+    cfg, P, wm, batch, enc_out = case_from_golden(g)
+    stages = {}
+    with torch.no_grad():
+        scores, caps, dl = R.forward(cfg, P, batch["captions"], enc_out, batch["caption_masks"],
+                                     batch["caption_lengths"], batch["entities"], batch.get("facts"), stages)
+    assert dl == g["decode_lengths"].tolist()
+    assert torch.equal(caps, t(g["captions_sorted"]))
+    ref = t(g["scores"])
+    assert scores.shape == ref.shape
+    assert (scores - ref).abs().max().item() < TOL
+    assert torch.equal(scores.argmax(-1), ref.argmax(-1))
+    if "entities_encoded" in g:
+        # integer-exact stages: gathers and feature slots
+        assert torch.equal(stages["entities_encoded"], t(g["entities_encoded"]))
+        assert torch.equal(stages["embeddings"], t(g["embeddings"]))
+        K = int(g["K"])
+        assert (stages["memory"][:, 196:196 + K] - t(g["entity_context"])).abs().max() < TOL
+        assert (stages["h"] - t(g["h"])).abs().max() < TOL
+        if "facts_encoded" in g:
+            assert torch.equal(stages["facts_encoded"], t(g["facts_encoded"]))
+            assert (stages["memory"][:, 196 + K:] - t(g["fact_context"])).abs().max() < TOL
+
+
+@pytest.mark.parametrize("name", ["fwd_tiny_geo", "fwd_tiny_knowledge", "fwd_tiny_news", "fwd_mid_geo",
+                                  "fwd_mid_knowledge"])
+def test_loss_and_grads(name):
+    g = load_golden(name)
+    cfg, P, wm, batch, enc_out = case_from_golden(g)
+    P = {k: v.clone().requires_grad_(True) for k, v in P.items() if not k.startswith("fact_encoder.")}
+    if cfg.has_facts:
+        P["fact_encoder.predicate_embedding.weight"] = P["predicate_embedding.weight"]
+    scores, caps, dl = R.forward(cfg, P, batch["captions"], enc_out, batch["caption_masks"],
+                                 batch["caption_lengths"], batch["entities"], batch.get("facts"))
+    loss = R.packed_ce_loss(cfg, scores, caps, dl)
+    assert abs(loss.item() - float(g["loss"][0])) < 1e-5
+    loss.backward()
+    norms = dict(zip(g["grad_norm_names"].tolist(), g["grad_norms"].tolist()))
+    for k, n in norms.items():
+        if k.startswith("fact_encoder."):
+            continue
+        assert P[k].grad is not None, k
+        mine = float(P[k].grad.double().norm())
+        assert abs(mine - n) <= 1e-4 * max(n, 1e-3), (k, mine, n)
+    for k in g:
+        if k.startswith("grad::"):
+            ref = t(g[k])
+            assert (P[k[6:]].grad - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item()), k
+
+
+def test_conv1():
+    g = load_golden("conv1_b2")
+    B, seed = int(g["B"]), int(g["seed"])
+    w, b = synth.make_conv1(seed)
+    out = R.feat_proj(synth.make_feats(B, seed), w, b)
+    assert out.shape == (B, 300, 196)
+    assert (out - t(g["out"])).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("name", ["predict_geo", "predict_knowledge", "predict_news"])
+def test_predict_tokens(name):
+    g = load_golden(name)
+    variant = str(g["variant"])
+    K, V, Fn, max_len = int(g["K"]), int(g["V"]), int(g["F"]), int(g["max_len"])
+    wm = synth.make_word_map(V)
+    cfg = R.config_from_word_map(variant, wm)
+    for seed in g["seeds"].tolist():
+        P = synth.make_params(variant, V, seed)
+        ents = synth.make_entities(variant, 1, K, V, seed)
+        facts = synth.make_facts(variant, 1, Fn, K, seed) if variant != "geo" else None
+        with torch.no_grad():
+            seq = R.predict(cfg, P, synth.make_enc_out(1, seed), max_len, ents, facts)
+        assert seq.view(-1).tolist() == g["seq_%d" % seed].reshape(-1).tolist(), (name, seed)
+
+
+def test_loop_cleanup_cases():
+    # hand-checked cases of geo-aware/models.py:421-435
+    out = [5, 5]; R.loop_cleanup(out, [90, 91], 1)
+    assert out == [5, 91]                       # immediate repeat -> runner-up of the last step
+    out = [1, 2, 1, 2]; R.loop_cleanup(out, [90, 91, 92, 93], 3)
+    assert out == [1, 2, 92, 93]                # bigram repeat -> last two rewritten
+    out = [1, 2, 3, 1, 2, 3]; R.loop_cleanup(out, [90, 91, 92, 93, 94, 95], 5)
+    assert out == [1, 2, 92, 93, 94, 95]        # trigram repeat rewrites FOUR positions (as the reference does)
+    out = [1, 2, 3, 4]; R.loop_cleanup(out, [90, 91, 92, 93], 3)
+    assert out == [1, 2, 3, 4]
