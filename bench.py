@@ -1,0 +1,180 @@
+"""bench.py -- decode-steps/s of the caption-decoder hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W] [--mode forward|greedy] [--config cfg2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One *step* = one pass of the hot path over one batch of synthetic input resident in HBM:
+mode forward (default) = Encoder.conv1 feature projection + DecoderTransformer.forward (teacher
+forced, exactly what train.py / validate() call) on cfg2 = B 64 x L 20 decode positions, 14x14x2048
+features, K=20 knowledge rows, vocab 10k => 1280 decode-steps per step and per GPU (weak scaling:
+every rank owns its own 64-sample shard; the forward path has no collective).
+Rank 0 prints ONE JSON line with the whole-job rate plus
+  roofline      the dominant kernel (fp32 MFMA GEMM of the feature projection) timed with HIP events
+                on its launch stream inside the timed region, against the 157.3 TFLOP/s fp32 matrix peak
+  cpu_baseline  the same workload on the host cores through oracle/stock.py (a port of the
+                reference's PyTorch-CPU path), bounded to ~10-20 s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", default="forward", choices=["forward", "greedy"])
+    ap.add_argument("--config", default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, seed, budget_s):
+    """Time the oracle's stock-module port of the reference on the host cores (same seeded workload)."""
+    import ick_amd.synth as synth
+    from oracle.stock import StockDecoder
+    variant, B, L, K, V, Fn = cfg["variant"], cfg["B"], cfg["L"], cfg["K"], cfg["V"], cfg["F"]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = synth.make_params(variant, V, seed)
+    cw, cb = synth.make_conv1(seed)
+    m = StockDecoder(variant, synth.make_word_map(V)).load_reference_params(P, cw, cb).eval()
+    batch = synth.make_batch(variant, B, L, K, V, Fn, seed)
+    feats = synth.make_feats(B, seed)
+
+    def one():
+        with torch.no_grad():
+            enc = m.encode_image(feats)
+            return m(batch["captions"], enc, batch["caption_masks"], batch["caption_lengths"], batch["entities"],
+                     batch.get("facts"))
+
+    one()
+    one()
+    times = []
+    t_end = time.time() + budget_s
+    while time.time() < t_end or len(times) < 3:
+        t0 = time.time()
+        one()
+        times.append(time.time() - t0)
+    best = min(times)
+    return {"value": B * L / best, "unit": "decode-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d full %s passes (conv1 + teacher-forced forward, B=%d L=%d V=%d) in %.1f s; best pass %.1f ms"
+                      % (len(times), variant, B, L, V, sum(times), best * 1e3),
+            "threads": torch.get_num_threads()}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import ick_amd
+    import ick_amd.ops as ops
+    import ick_amd.synth as synth
+
+    cfgname = args.config or ("cfg5" if args.mode == "greedy" else "cfg2")
+    cfg = dict(synth.CONFIGS[cfgname])
+    variant, B, L, K, V, Fn = cfg["variant"], cfg["B"], cfg["L"], cfg["K"], cfg["V"], cfg["F"]
+    seed = 100 + rank  # every rank owns a different shard of the global batch
+    m = ick_amd.load_models(variant)
+    dec = m.DecoderTransformer(synth.make_word_map(V), 300, 512, 512, 10, 3)
+    dec.load_state_dict(synth.make_params(variant, V, 0), strict=False)  # same weights on every rank
+    dec = dec.cuda().eval()
+    enc = m.Encoder(emb_dim=300)
+    cw, cb = synth.make_conv1(0)
+    with torch.no_grad():
+        enc.conv1.weight.copy_(cw)
+        enc.conv1.bias.copy_(cb)
+    enc = enc.cuda().eval()
+    batch = {k: v.cuda() for k, v in synth.make_batch(variant, B, L, K, V, Fn, seed).items()}
+    feats = synth.make_feats(B, seed).cuda()
+    extra = [batch["facts"]] if variant != "geo" else []
+
+    if args.mode == "forward":
+        def step():
+            e = enc(feats)
+            return dec(batch["captions"], e, batch["caption_masks"], batch["caption_lengths"], batch["entities"],
+                       *extra)
+        units_per_step = B * L
+    else:
+        def step():
+            e = enc(feats)
+            return dec.predict(e, L, batch["entities"], *extra)
+        units_per_step = B * L
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    P = 196
+    dom_shape = (B * P, 300, 2048)  # Encoder.conv1 as a GEMM: the largest single kernel of the pass
+    ops.TIMED = {"shape": dom_shape, "events": []}
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    events = ops.TIMED["events"]
+    ops.TIMED = None
+    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+
+    if rank == 0:
+        kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
+        flops = 2.0 * dom_shape[0] * dom_shape[1] * dom_shape[2]
+        achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+        out = {
+            "metric": "decode_steps_per_sec", "value": world * units_per_step * args.steps / dt,
+            "unit": "decode-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %s variant, per-GPU batch %d x %d decode positions, 14x14x2048 features, "
+                                   "K=%d knowledge rows%s, vocab %d" % (cfgname, variant, B, L, K,
+                                                                         (", F=%d facts" % Fn) if Fn else "", V),
+                       "mode": "teacher_forced_forward (Encoder.conv1 + DecoderTransformer.forward)"
+                       if args.mode == "forward" else "greedy_decode (Encoder.conv1 + predict, KV-cached)",
+                       "global_batch": world * B, "parallelism": "dp%d (independent shards)" % world},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "gemm_kernel<4,1,4,4,A k-major> (Encoder.conv1: [%d x %d] x [%d x %d])"
+                                   % (dom_shape[0], dom_shape[2], dom_shape[2], dom_shape[1]),
+                         "kernel_ms": kern_ms, "flops_per_launch": flops, "launches_timed": len(events)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, seed, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -10,3 +10,10 @@ Import as `ick_amd` (see /ick_amd.py).  Sub-modules:
              drop-in replacements for the reference's per-variant `models` module
 """
 __version__ = "0.1.0"
+
+
+def load_models(variant):
+    """Return the drop-in `models` module of a variant ("geo" | "knowledge" | "news")."""
+    import importlib
+    name = {"geo": "geo_aware", "knowledge": "knowledge_aware", "news": "news_knowledge_aware"}[variant]
+    return importlib.import_module("ick_amd.%s.models" % name)

@@ -1,0 +1,64 @@
+// Shared device/host helpers for libick_amd (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ick_amd.h"
+
+namespace ick {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kWave = 64;
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+#define ICK_CHECK_ARG(cond)          \
+    do {                             \
+        if (!(cond)) return ICK_EINVAL; \
+    } while (0)
+
+#define ICK_LAUNCH_RET()                       \
+    do {                                       \
+        hipError_t e__ = hipGetLastError();    \
+        return e__ == hipSuccess ? ICK_OK : (int)e__; \
+    } while (0)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide reductions for blocks of NW waves; scratch must hold NW floats.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) scratch[w] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r += scratch[i];
+    return r;
+}
+template <int NW>
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) scratch[w] = v;
+    __syncthreads();
+    float r = scratch[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) r = fmaxf(r, scratch[i]);
+    return r;
+}
+
+}  // namespace ick

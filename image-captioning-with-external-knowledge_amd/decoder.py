@@ -1,0 +1,397 @@
+"""Encoder / DecoderTransformer engine shared by the three drop-in `models` modules.
+
+Mirrors the reference's operator interface for the hot path:
+    models.Encoder(encoded_image_size=14, emb_dim=300, encoder_dim=2048)         geo-aware/models.py:9-60
+    models.DecoderTransformer(word_map, emb_dim, decoder_dim, encoder_dim, num_heads, num_layers,
+                              dropout_dec=0.5, dropout_enc=0.5, dropout_pos=0.1)  geo-aware/models.py:212-254
+    decoder(captions, encoder_out, caption_masks, caption_lengths, entities[, facts])
+        -> (scores (B,L,V+K[+F]) in length-sorted order, captions_sorted, decode_lengths)   :315-361
+    decoder.predict(encoder_out, max_pred_len, entities[, facts]) -> LongTensor (max_pred_len, B) :363-443
+The module tree (sub-module and parameter names) is the reference's, so its whole-object
+checkpoints (geo-aware/utils.py:32-49) unpickle into these classes and state_dicts interchange.
+torch.nn modules are used ONLY as parameter containers; every forward computation below runs
+in libick_amd.so (HIP, gfx950) through ops.py.  There is no CPU / PyTorch fallback.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+from .lib import IckError
+
+VARIANT_TYPE_OFFSET = {"geo": 4, "knowledge": 6, "news": 5}
+VARIANT_NUM_TYPES = {"geo": 1000, "knowledge": 1000, "news": 20}
+VARIANT_NUM_PREDICATES = {"geo": 0, "knowledge": 3000, "news": 3500}
+
+
+def _sinusoid_table(max_len, d):
+    """PositionEncoder buffer (geo-aware/models.py:199-205), shape (max_len, 1, d)."""
+    pos = torch.arange(max_len, dtype=torch.float32).unsqueeze(1)
+    freq = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * (-math.log(10000.0) / d))
+    table = torch.zeros(max_len, d)
+    table[:, 0::2] = torch.sin(pos * freq)
+    table[:, 1::2] = torch.cos(pos * freq)
+    return table.unsqueeze(1)
+
+
+class PositionEncoder(nn.Module):
+    """Holds the sinusoid buffer `pe` and the dropout rate; applied inside ick_caption_embed."""
+
+    def __init__(self, emb_dim, dropout, max_len=5000):
+        super().__init__()
+        self.dropout = nn.Dropout(p=dropout)
+        self.register_buffer("pe", _sinusoid_table(max_len, emb_dim))
+
+
+class EntityEncoder(nn.Module):
+    """Parameter holder for the entity-type embedding (computation: ick_entity_encode)."""
+
+    def __init__(self, emb_dim, type_embedding):
+        super().__init__()
+        self.emb_dim = emb_dim
+        self.type_embedding = type_embedding
+
+
+class FactEncoder(nn.Module):
+    """Parameter holder for the predicate embedding (computation: ick_fact_encode)."""
+
+    def __init__(self, emb_dim, predicate_embedding):
+        super().__init__()
+        self.emb_dim = emb_dim
+        self.predicate_embedding = predicate_embedding
+
+
+class CaptionEmbedder(nn.Module):
+    def __init__(self, vocab_size):
+        super().__init__()
+        self.vocab_size = vocab_size
+
+
+class Encoder(nn.Module):
+    """Feature projection of the image encoder: conv1 (1x1, 2048 -> emb_dim) + view.
+
+    The hot path starts at the 14x14x2048 feature map (BASELINE configs use precomputed ResNet-101
+    features); the ResNet trunk itself is out of scope, so forward() takes the
+    (B, 2048, 14, 14) map.  Returns (B, emb_dim, 196) like the reference; the storage is token-major
+    (B, 196, emb_dim) -- the layout the decoder's cross-attention K/V projection streams -- exposed
+    through a permuted view, so the decoder consumes it without a copy."""
+
+    def __init__(self, encoded_image_size=14, emb_dim=300, encoder_dim=2048):
+        super().__init__()
+        self.emb_dim = emb_dim
+        self.encoder_dim = encoder_dim
+        self.encoded_image_size = encoded_image_size
+        self.conv1 = nn.Conv2d(encoder_dim, emb_dim, 1)
+        self.fine_tune()
+
+    def forward(self, feats):
+        if feats.dim() != 4 or feats.shape[1] != self.encoder_dim:
+            raise IckError("Encoder.forward expects the (B, %d, H, W) ResNet feature map; the ResNet trunk is "
+                           "outside the accelerated path" % self.encoder_dim)
+        feats = feats.contiguous()
+        B, Cc, Hh, Ww = feats.shape
+        P = Hh * Ww
+        d = self.emb_dim
+        out = torch.empty(B, P, d, device=feats.device, dtype=torch.float32)
+        w = self.conv1.weight.detach().view(d, Cc)
+        ops.gemm_raw(feats, w, out, B * P, d, Cc, 1, P, Cc, 1, d, bias=self.conv1.bias.detach(),
+                     a_grp=P, a_gs=Cc * P)
+        return out.permute(0, 2, 1)
+
+    def fine_tune(self, fine_tune=True):
+        """The reference toggles ResNet blocks 2-4 here (geo-aware/models.py:49-60); there is no trunk
+        in this module, and conv1 is left as it is there (trainable flag untouched)."""
+        return None
+
+
+class DecoderTransformer(nn.Module):
+    variant = "geo"
+
+    def __init__(self, word_map, emb_dim, decoder_dim, encoder_dim, num_heads, num_layers, dropout_dec=0.5,
+                 dropout_enc=0.5, dropout_pos=0.1):
+        super().__init__()
+        v = self.variant
+        self.word_map = word_map
+        self.vocab_size = len(word_map)
+        self.emb_dim = emb_dim
+        self.softmax = nn.Softmax(dim=-1)
+        self.lookahead_mask = None
+        self.pos_encoder = PositionEncoder(emb_dim, dropout_pos)
+        self.transformer_decoder = nn.TransformerDecoder(
+            nn.TransformerDecoderLayer(emb_dim, num_heads, decoder_dim, dropout_dec), num_layers)
+        self.transformer_encoder_entities = nn.TransformerEncoder(
+            nn.TransformerEncoderLayer(emb_dim, num_heads, encoder_dim, dropout_enc), num_layers,
+            enable_nested_tensor=False)
+        if v != "geo":
+            self.transformer_encoder_facts = nn.TransformerEncoder(
+                nn.TransformerEncoderLayer(emb_dim, num_heads, encoder_dim, dropout_enc), num_layers,
+                enable_nested_tensor=False)
+        self.word_embedding = nn.Embedding(self.vocab_size, emb_dim)
+        self.entity_encoder = EntityEncoder(
+            emb_dim, nn.Embedding(VARIANT_NUM_TYPES[v], emb_dim - VARIANT_TYPE_OFFSET[v]))
+        if v != "geo":
+            self.num_predicates = VARIANT_NUM_PREDICATES[v]
+            self.predicate_embedding = nn.Embedding(self.num_predicates, emb_dim)
+            self.fact_encoder = FactEncoder(emb_dim, self.predicate_embedding)
+        self.caption_embedder = CaptionEmbedder(self.vocab_size)
+        self.fc_vocab = nn.Linear(emb_dim, self.vocab_size)
+        self.fc_entity = nn.Linear(emb_dim, 1)
+        if v != "geo":
+            self.fc_fact = nn.Linear(emb_dim, 1)
+            self.fc_predicate = nn.Linear(self.num_predicates, emb_dim)
+        self.init_weights()
+
+    # ------------------------------------------------------------------ reference API surface
+    def init_weights(self):
+        """U(-0.1, 0.1) weights / zero bias on the score-head linears (geo-aware/models.py:264-272)."""
+        heads = [self.fc_vocab, self.fc_entity]
+        if self.variant != "geo":
+            heads += [self.fc_fact, self.fc_predicate]
+        with torch.no_grad():
+            for m in heads:
+                m.bias.zero_()
+                m.weight.uniform_(-0.1, 0.1)
+
+    def load_pretrained_embeddings(self, embeddings):
+        self.word_embedding.weight = nn.Parameter(embeddings)
+
+    def fine_tune_embeddings(self, fine_tune=True):
+        for p in self.word_embedding.parameters():
+            p.requires_grad = fine_tune
+
+    def _generate_square_subsequent_mask(self, sz):
+        """Kept for API parity (geo-aware/models.py:256-262); the HIP attention kernel applies the
+        causal mask from indices and never reads this tensor."""
+        return torch.full((sz, sz), float("-inf")).triu(1)
+
+    # ------------------------------------------------------------------ helpers
+    @property
+    def has_facts(self):
+        return self.variant != "geo"
+
+    @property
+    def num_heads(self):
+        return self.transformer_decoder.layers[0].self_attn.num_heads
+
+    def _check_eval(self):
+        if self.training:
+            drops = [self.pos_encoder.dropout.p, self.transformer_decoder.layers[0].dropout.p,
+                     self.transformer_encoder_entities.layers[0].dropout.p]
+            if any(p > 0 for p in drops) and not getattr(self, "_train_engine", None):
+                raise IckError("training-mode forward goes through ick_amd.training.TrainStep (dropout and the "
+                               "backward kernels live there); call .eval() for inference")
+
+    def _token_major(self, encoder_out):
+        """(B, d, P) -> contiguous (B, P, d) storage.  Our Encoder already stores token-major."""
+        B, d, P = encoder_out.shape
+        if encoder_out.stride() == (P * d, 1, d):
+            return encoder_out.permute(0, 2, 1)
+        return encoder_out.permute(0, 2, 1).contiguous()
+
+    def _packed_cross_kv(self):
+        """[K_0;V_0;K_1;V_1;...] rows of the decoder layers' cross-attention in_proj, so the memory is
+        projected for all layers by one GEMM (cached until a parameter changes)."""
+        layers = self.transformer_decoder.layers
+        key = tuple(l.multihead_attn.in_proj_weight._version for l in layers) + tuple(
+            l.multihead_attn.in_proj_bias._version for l in layers) + tuple(
+            l.multihead_attn.in_proj_weight.data_ptr() for l in layers)
+        cache = self.__dict__.get("_kv_pack")
+        if cache is None or cache[0] != key:
+            d = self.emb_dim
+            w = torch.cat([l.multihead_attn.in_proj_weight.detach()[d:] for l in layers]).contiguous()
+            b = torch.cat([l.multihead_attn.in_proj_bias.detach()[d:] for l in layers]).contiguous()
+            cache = (key, w, b)
+            self.__dict__["_kv_pack"] = cache
+        return cache[1], cache[2]
+
+    def _pred_wt(self):
+        w = self.fc_predicate.weight
+        key = (w._version, w.data_ptr())
+        cache = self.__dict__.get("_pred_wt_cache")
+        if cache is None or cache[0] != key:
+            cache = (key, w.detach().t().contiguous())
+            self.__dict__["_pred_wt_cache"] = cache
+        return cache[1]
+
+    def _context_encoder(self, stack, x):
+        H = self.num_heads
+        d = self.emb_dim
+        B, T, _ = x.shape
+        for layer in stack.layers:
+            qkv = ops.linear(x, layer.self_attn.in_proj_weight.detach(), layer.self_attn.in_proj_bias.detach())
+            sa = torch.empty_like(x)
+            ops.attention_raw(qkv, qkv, qkv, sa, B, H, T, T, d // H, T * 3 * d, 3 * d, T * 3 * d, 3 * d, d // H,
+                              T * 3 * d, 3 * d, d // H, T * d, d, k_off=d, v_off=2 * d)
+            o = ops.linear(sa, layer.self_attn.out_proj.weight.detach(), layer.self_attn.out_proj.bias.detach())
+            x = ops.add_layernorm(o, x, layer.norm1.weight.detach(), layer.norm1.bias.detach(), layer.norm1.eps)
+            f = ops.linear(x, layer.linear1.weight.detach(), layer.linear1.bias.detach(), relu=True)
+            o = ops.linear(f, layer.linear2.weight.detach(), layer.linear2.bias.detach())
+            x = ops.add_layernorm(o, x, layer.norm2.weight.detach(), layer.norm2.bias.detach(), layer.norm2.eps)
+        return x
+
+    def _encode_context(self, enc_tok, entities, facts, gmap):
+        """Entity / fact encoders, context transformers and the all-layer cross K/V projection.
+        Returns (entities_encoded, facts_encoded, kv (B, S, N*2d))."""
+        d = self.emb_dim
+        B, P, _ = enc_tok.shape
+        K = entities.shape[1]
+        ee = ops.entity_encode(self.variant, entities, self.entity_encoder.type_embedding.weight.detach(), d,
+                               facts=facts if self.has_facts else None,
+                               word_emb=self.word_embedding.weight.detach() if self.variant == "news" else None)
+        fe = None
+        Fn = 0
+        if self.has_facts:
+            Fn = facts.shape[1]
+            fe = ops.fact_encode(facts, ee, self.predicate_embedding.weight.detach())
+        ctx_e = self._context_encoder(self.transformer_encoder_entities, ee)
+        ctx_f = self._context_encoder(self.transformer_encoder_facts, fe) if self.has_facts else None
+        wkv, bkv = self._packed_cross_kv()
+        N2 = wkv.shape[0]
+        S = P + K + Fn
+        kv = torch.empty(B, S, N2, device=enc_tok.device, dtype=torch.float32)
+        # image rows (gathered through gmap = sort order), then entity and fact context rows
+        ops.gemm_raw(enc_tok, wkv, kv, B * P, N2, d, d, 1, d, 1, N2, bias=bkv, a_grp=P, a_gs=enc_tok.stride(0),
+                     a_gmap=gmap, c_grp=P, c_gs=S * N2)
+        ops.gemm_raw(ctx_e, wkv, kv[:, P:], B * K, N2, d, d, 1, d, 1, N2, bias=bkv, c_grp=K, c_gs=S * N2)
+        if self.has_facts:
+            ops.gemm_raw(ctx_f, wkv, kv[:, P + K:], B * Fn, N2, d, d, 1, d, 1, N2, bias=bkv, c_grp=Fn, c_gs=S * N2)
+        return ee, fe, kv, (ctx_e, ctx_f)
+
+    def _decoder_layer(self, li, layer, x, kv, S, qkv_buf=None, pos=None, kv_len=None):
+        """One post-LN decoder layer on x (B, T, d).  With qkv_buf (B, max_len, 3d) the layer runs one
+        KV-cached decode step: the new q|k|v row is written at position `pos` and attends to [0, pos]."""
+        H, d = self.num_heads, self.emb_dim
+        dh = d // H
+        B, T, _ = x.shape
+        N2 = kv.shape[2]
+        sa_w, sa_b = layer.self_attn.in_proj_weight.detach(), layer.self_attn.in_proj_bias.detach()
+        sa = torch.empty_like(x)
+        if qkv_buf is None:
+            qkv = ops.linear(x, sa_w, sa_b)
+            ops.attention_raw(qkv, qkv, qkv, sa, B, H, T, T, dh, T * 3 * d, 3 * d, T * 3 * d, 3 * d, dh, T * 3 * d,
+                              3 * d, dh, T * d, d, causal=True, k_off=d, v_off=2 * d)
+        else:
+            ML = qkv_buf.shape[1]
+            row = qkv_buf[:, pos]
+            ops.gemm_raw(x, sa_w, row, B, 3 * d, d, d, 1, d, 1, 3 * d, bias=sa_b, c_grp=1, c_gs=ML * 3 * d)
+            ops.attention_raw(row, qkv_buf, qkv_buf, sa, B, H, 1, pos + 1, dh, ML * 3 * d, 3 * d, ML * 3 * d, 3 * d,
+                              dh, ML * 3 * d, 3 * d, dh, d, d, k_off=d, v_off=2 * d)
+        o = ops.linear(sa, layer.self_attn.out_proj.weight.detach(), layer.self_attn.out_proj.bias.detach())
+        x = ops.add_layernorm(o, x, layer.norm1.weight.detach(), layer.norm1.bias.detach(), layer.norm1.eps)
+        ca_w, ca_b = layer.multihead_attn.in_proj_weight.detach(), layer.multihead_attn.in_proj_bias.detach()
+        q = ops.linear(x, ca_w[:d], ca_b[:d])
+        ca = torch.empty_like(x)
+        ops.attention_raw(q, kv, kv, ca, B, H, T, S, dh, T * d, d, S * N2, N2, dh, S * N2, N2, dh, T * d, d,
+                          k_off=li * 2 * d, v_off=li * 2 * d + d)
+        o = ops.linear(ca, layer.multihead_attn.out_proj.weight.detach(), layer.multihead_attn.out_proj.bias.detach())
+        x = ops.add_layernorm(o, x, layer.norm2.weight.detach(), layer.norm2.bias.detach(), layer.norm2.eps)
+        f = ops.linear(x, layer.linear1.weight.detach(), layer.linear1.bias.detach(), relu=True)
+        o = ops.linear(f, layer.linear2.weight.detach(), layer.linear2.bias.detach())
+        return ops.add_layernorm(o, x, layer.norm3.weight.detach(), layer.norm3.bias.detach(), layer.norm3.eps)
+
+    def _score_head(self, h, ee, fe, eib, gate, out=None):
+        """get_scores: vocabulary logits and pointer scores written into one (B, T, V+K[+F]) buffer."""
+        B, T, d = h.shape
+        V, K = self.vocab_size, ee.shape[1]
+        Fn = fe.shape[1] if fe is not None else 0
+        Vx = V + K + Fn
+        if out is None:
+            out = torch.empty(B, T, Vx, device=h.device, dtype=torch.float32)
+        hv = ops.mul(h, gate) if self.has_facts else h
+        ops.gemm_raw(hv, self.fc_vocab.weight.detach(), out, B * T, V, d, d, 1, d, 1, Vx,
+                     bias=self.fc_vocab.bias.detach())
+        ops.pointer_scores(h, ee, self.fc_entity.weight.detach(), self.fc_entity.bias.detach(), out, V)
+        if self.has_facts:
+            ops.pointer_scores(h, fe, self.fc_fact.weight.detach(), self.fc_fact.bias.detach(), out, V + K, ind=eib)
+        return out
+
+    def _prepare_inputs(self, encoder_out, entities, facts):
+        dev = self.fc_vocab.weight.device
+        if dev.type != "cuda":
+            raise IckError("DecoderTransformer parameters must live on the GPU (decoder.to('cuda'))")
+        entities = entities.to(device=dev, dtype=torch.float32)
+        if self.has_facts:
+            if facts is None:
+                raise IckError("%s variant needs the facts tensor" % self.variant)
+            facts = facts.to(device=dev, dtype=torch.int64)
+        return encoder_out.to(dev), entities, facts
+
+    # ------------------------------------------------------------------ forward (teacher forced)
+    def forward(self, captions, encoder_out, caption_masks, caption_lengths, entities, facts=None, stages=None):
+        self._check_eval()
+        encoder_out, entities, facts = self._prepare_inputs(encoder_out, entities, facts)
+        dev = encoder_out.device
+        # length sort on the host, like the reference's CPU path (the result feeds a Python list anyway)
+        lengths, sort_ind = caption_lengths.detach().squeeze(1).cpu().sort(dim=0, descending=True)
+        decode_lengths = (lengths - 1).tolist()
+        sort_dev = sort_ind.to(dev)
+        captions = captions.to(dev)[sort_dev].contiguous()
+        caption_masks = caption_masks.to(dev)[sort_dev].contiguous()
+        entities = entities[sort_dev].contiguous()
+        if self.has_facts:
+            facts = facts[sort_dev].contiguous()
+        enc_tok = self._token_major(encoder_out)
+        gmap = sort_dev.to(torch.int32)
+        B, L = captions.shape
+        d, V = self.emb_dim, self.vocab_size
+        P, K = enc_tok.shape[1], entities.shape[1]
+
+        ee, fe, kv, ctx = self._encode_context(enc_tok, entities, facts, gmap)
+        pe = self.pos_encoder.pe.view(-1, d)
+        x, emb = ops.caption_embed(captions, caption_masks, self.word_embedding.weight.detach(), ee, fe, pe, V,
+                                   self.word_map["<pad>"], math.sqrt(d), want_emb=True)
+        S = kv.shape[1]
+        for li, layer in enumerate(self.transformer_decoder.layers):
+            x = self._decoder_layer(li, layer, x, kv, S)
+        eib = gate = None
+        if self.has_facts:
+            eib, gate = ops.context_indicators(captions, facts, K, V, self._pred_wt(),
+                                               self.fc_predicate.bias.detach(), mode=0)
+        scores = self._score_head(x, ee, fe, eib, gate)
+        if stages is not None:
+            stages.update(entities_encoded=ee, facts_encoded=fe, embeddings=emb, entity_context=ctx[0],
+                          fact_context=ctx[1], h=x, kv=kv, eib=eib, gate=gate)
+        return scores, captions, decode_lengths
+
+    # ------------------------------------------------------------------ greedy decode (KV cached)
+    @torch.no_grad()
+    def predict(self, encoder_out, max_pred_len, entities, facts=None):
+        """Greedy decode with the reference's semantics per caption (argmax, <end> stop, repeated
+        n-gram clean-up, pointer masks), KV-cached: step i only projects position i.  Works for any
+        batch size (B independent captions); returns LongTensor (max_pred_len, B), <pad> after <end>."""
+        encoder_out, entities, facts = self._prepare_inputs(encoder_out, entities, facts)
+        dev = encoder_out.device
+        entities = entities.contiguous()
+        enc_tok = self._token_major(encoder_out)
+        B = enc_tok.shape[0]
+        d, V, K = self.emb_dim, self.vocab_size, entities.shape[1]
+        ee, fe, kv, _ = self._encode_context(enc_tok, entities, facts, None)
+        S = kv.shape[1]
+        pe = self.pos_encoder.pe.view(-1, d)
+        nl = len(self.transformer_decoder.layers)
+        qkv_cache = [torch.empty(B, max_pred_len, 3 * d, device=dev, dtype=torch.float32) for _ in range(nl)]
+        output = torch.full((B, max_pred_len), self.word_map["<pad>"], dtype=torch.long, device=dev)
+        hist = torch.zeros(B, max_pred_len, dtype=torch.int32, device=dev)
+        finished = torch.zeros(B, dtype=torch.int32, device=dev)
+        tok = torch.full((B, 1), self.word_map["<start>"], dtype=torch.long, device=dev)
+        msk = torch.zeros(B, 1, dtype=torch.long, device=dev)
+        cap_buf = torch.full((B, max_pred_len), self.word_map["<start>"], dtype=torch.long, device=dev)
+        Fn = fe.shape[1] if fe is not None else 0
+        scores = torch.empty(B, 1, V + K + Fn, device=dev, dtype=torch.float32)
+        wemb = self.word_embedding.weight.detach()
+        for i in range(max_pred_len):
+            x = ops.caption_embed(tok, msk, wemb, ee, fe, pe, V, self.word_map["<pad>"], math.sqrt(d), pos0=i)
+            for li, layer in enumerate(self.transformer_decoder.layers):
+                x = self._decoder_layer(li, layer, x, kv, S, qkv_buf=qkv_cache[li], pos=i)
+            eib = gate = None
+            if self.has_facts:
+                eib, gate = ops.context_indicators(cap_buf, facts, K, V, self._pred_wt(),
+                                                   self.fc_predicate.bias.detach(), mode=1)
+            self._score_head(x, ee, fe, eib, gate, out=scores)
+            best, second = ops.top2(scores.view(B, -1))
+            ops.greedy_update(best, second, output, hist, finished, tok.view(-1), msk.view(-1), i, V, K,
+                              self.has_facts, self.word_map["<end>"])
+            if self.has_facts and i + 1 < max_pred_len:
+                cap_buf[:, i + 1] = tok.view(-1)
+        return output.t().contiguous()

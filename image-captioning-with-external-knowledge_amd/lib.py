@@ -1,0 +1,90 @@
+"""ctypes binding of libick_amd.so (C ABI: include/ick_amd.h).
+
+The library is built in-tree by build.py; a missing library is a hard error -- there is no
+CPU or PyTorch fallback anywhere in the product path.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libick_amd.so")
+
+ICK_GEO, ICK_KNOWLEDGE, ICK_NEWS = 0, 1, 2
+VARIANT_ID = {"geo": ICK_GEO, "knowledge": ICK_KNOWLEDGE, "news": ICK_NEWS}
+GEMM_RELU, GEMM_ACCUM, GEMM_ATOMIC = 1, 2, 4
+
+vp = C.c_void_p
+i32 = C.c_int32
+i64 = C.c_int64
+f32 = C.c_float
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", vp), ("B", vp), ("C", vp), ("bias", vp),
+        ("M", i32), ("N", i32), ("K", i32),
+        ("a_rs", i64), ("a_ks", i64), ("a_grp", i32), ("a_gs", i64), ("a_gmap", vp),
+        ("b_rs", i64), ("b_ks", i64),
+        ("c_rs", i64), ("c_grp", i32), ("c_gs", i64), ("c_gmap", vp),
+        ("flags", i32), ("split_k", i32), ("alpha", f32),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("Q", vp), ("K", vp), ("V", vp), ("O", vp), ("lse", vp),
+        ("B", i32), ("H", i32), ("T", i32), ("S", i32), ("dh", i32),
+        ("q_bs", i64), ("q_ts", i64), ("k_bs", i64), ("k_ss", i64), ("k_hs", i64),
+        ("v_bs", i64), ("v_ss", i64), ("v_hs", i64), ("o_bs", i64), ("o_ts", i64),
+        ("scale", f32), ("causal", i32), ("q_pos0", i32), ("kv_len", vp),
+    ]
+
+
+# name -> argtypes; every entry returns int (0 ok, <0 ICK_E*, >0 hipError_t)
+SIGNATURES = {
+    "ick_version": [],
+    "ick_device_info": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int],
+    "ick_gemm": [C.POINTER(GemmArgs), vp],
+    "ick_add_layernorm": [vp, vp, vp, vp, vp, i64, i32, f32, i64, i64, i64, vp, vp, vp],
+    "ick_attention": [C.POINTER(AttnArgs), vp],
+    "ick_entity_encode": [i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp],
+    "ick_fact_encode": [vp, vp, vp, i32, vp, i32, i32, i32, i32, vp],
+    "ick_caption_embed": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp],
+    "ick_context_indicators": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "ick_pointer_scores": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i32, vp, vp],
+    "ick_mul": [vp, vp, vp, i64, vp],
+    "ick_top2": [vp, i64, i32, i32, vp, vp, vp],
+    "ick_greedy_update": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "ick_packed_ce": [vp, i64, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp],
+}
+
+_lib = None
+
+
+class IckError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IckError(
+                "libick_amd.so is missing (%s): build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+                " -- there is no fallback path" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        _lib = lib
+    return _lib
+
+
+_ERRS = {-1: "ICK_EINVAL (bad shape / null pointer / unsupported size)", -2: "ICK_EALIGN", -3: "ICK_EWORKSPACE"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise IckError("%s failed: %s" % (what, _ERRS.get(rc, "hipError_t %d" % rc)))

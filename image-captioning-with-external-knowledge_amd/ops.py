@@ -1,0 +1,206 @@
+"""Per-op Python wrappers over the C ABI.  Tensors are torch CUDA(ROCm) tensors used purely as
+device memory + stream plumbing; all arithmetic happens in libick_amd.so."""
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as L
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise L.IckError("%s must be a float32 device tensor (got %s on %s)" % (name, t.dtype, t.device))
+    return t
+
+
+# bench.py hook: when set to {"shape": (M, N, K), "events": []}, every ick_gemm launch of that shape is
+# bracketed by HIP events recorded on the launch stream (torch's current stream).
+TIMED = None
+
+
+def gemm_raw(A, B, Cout, M, N, K, a_rs, a_ks, b_rs, b_ks, c_rs, bias=None, a_grp=0, a_gs=0, a_gmap=None,
+             c_grp=0, c_gs=0, c_gmap=None, relu=False, accumulate=False, atomic=False, split_k=1, alpha=1.0):
+    """C[m,n] = act(alpha * sum_k A(m,k) B(n,k) + bias[n]) with explicit element strides; A/B/Cout are
+    tensors (only their data pointers are used -- the caller guarantees the strides stay in bounds)."""
+    a = L.GemmArgs()
+    a.A, a.B, a.C, a.bias = _p(A), _p(B), _p(Cout), _p(bias)
+    a.M, a.N, a.K = M, N, K
+    a.a_rs, a.a_ks, a.a_grp, a.a_gs, a.a_gmap = a_rs, a_ks, a_grp, a_gs, _p(a_gmap)
+    a.b_rs, a.b_ks = b_rs, b_ks
+    a.c_rs, a.c_grp, a.c_gs, a.c_gmap = c_rs, c_grp, c_gs, _p(c_gmap)
+    a.flags = (L.GEMM_RELU if relu else 0) | (L.GEMM_ACCUM if accumulate else 0) | (L.GEMM_ATOMIC if atomic else 0)
+    a.split_k = split_k
+    a.alpha = alpha
+    timed = TIMED is not None and TIMED["shape"] == (M, N, K)
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    L.check(L.load().ick_gemm(C.byref(a), _stream()), "ick_gemm")
+    if timed:
+        e1.record()
+        TIMED["events"].append((e0, e1))
+    return Cout
+
+
+def linear(x, w, bias=None, out=None, relu=False):
+    """y = x @ w.T + bias for x (..., K) with contiguous last dim and uniform row stride, w (N, K)."""
+    _f32c(x, "x"); _f32c(w, "w")
+    K = x.shape[-1]
+    N = w.shape[0]
+    x2 = x.reshape(-1, K)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32)
+    o2 = out.view(-1, N) if out.is_contiguous() else out
+    gemm_raw(x2, w, o2, M, N, K, x2.stride(0), 1, w.stride(0), 1, o2.stride(0), bias=bias, relu=relu)
+    return out
+
+
+def add_layernorm(x, res, gamma, beta, eps=1e-5, out=None, save_stats=False):
+    d = x.shape[-1]
+    x2 = x.reshape(-1, d)
+    r2 = None if res is None else res.reshape(-1, d)
+    rows = x2.shape[0]
+    if out is None:
+        out = torch.empty_like(x2)
+    o2 = out.view(-1, d)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    L.check(L.load().ick_add_layernorm(_p(x2), _p(r2), _p(gamma), _p(beta), _p(o2), rows, d, eps, x2.stride(0),
+                                       0 if r2 is None else r2.stride(0), o2.stride(0), _p(mean), _p(rstd),
+                                       _stream()), "ick_add_layernorm")
+    out = out.view(x.shape)
+    return (out, mean, rstd) if save_stats else out
+
+
+def attention_raw(Q, K, V, O, B, H, T, S, dh, q_bs, q_ts, k_bs, k_ss, k_hs, v_bs, v_ss, v_hs, o_bs, o_ts,
+                  causal=False, q_pos0=0, kv_len=None, lse=None, q_off=0, k_off=0, v_off=0):
+    """Element offsets q_off/k_off/v_off select a column block inside a packed projection buffer."""
+    a = L.AttnArgs()
+    a.Q = Q.data_ptr() + 4 * q_off
+    a.K = K.data_ptr() + 4 * k_off
+    a.V = V.data_ptr() + 4 * v_off
+    a.O, a.lse = _p(O), _p(lse)
+    a.B, a.H, a.T, a.S, a.dh = B, H, T, S, dh
+    a.q_bs, a.q_ts, a.k_bs, a.k_ss, a.k_hs = q_bs, q_ts, k_bs, k_ss, k_hs
+    a.v_bs, a.v_ss, a.v_hs, a.o_bs, a.o_ts = v_bs, v_ss, v_hs, o_bs, o_ts
+    a.scale = 1.0 / math.sqrt(dh)
+    a.causal, a.q_pos0, a.kv_len = int(causal), q_pos0, _p(kv_len)
+    L.check(L.load().ick_attention(C.byref(a), _stream()), "ick_attention")
+    return O
+
+
+def attention(q, k, v, H, causal=False):
+    """q (B,T,d), k/v (B,S,d) contiguous -> (B,T,d)."""
+    B, T, d = q.shape
+    S = k.shape[1]
+    dh = d // H
+    out = torch.empty_like(q)
+    attention_raw(q, k, v, out, B, H, T, S, dh, q.stride(0), q.stride(1), k.stride(0), k.stride(1), dh,
+                  v.stride(0), v.stride(1), dh, out.stride(0), out.stride(1), causal=causal)
+    return out
+
+
+def entity_encode(variant, entities, type_emb, d, facts=None, word_emb=None):
+    B, K, cols = entities.shape
+    out = torch.empty(B, K, d, device=entities.device, dtype=torch.float32)
+    F = 0 if facts is None else facts.shape[1]
+    L.check(L.load().ick_entity_encode(L.VARIANT_ID[variant], _p(entities), cols, _p(facts), _p(type_emb),
+                                       type_emb.shape[0], _p(word_emb), 0 if word_emb is None else word_emb.shape[0],
+                                       _p(out), B, K, F, d, _stream()), "ick_entity_encode")
+    return out
+
+
+def fact_encode(facts, entities_encoded, pred_emb):
+    B, F, _ = facts.shape
+    K, d = entities_encoded.shape[1], entities_encoded.shape[2]
+    out = torch.empty(B, F, d, device=facts.device, dtype=torch.float32)
+    L.check(L.load().ick_fact_encode(_p(facts), _p(entities_encoded), _p(pred_emb), pred_emb.shape[0], _p(out), B, K,
+                                     F, d, _stream()), "ick_fact_encode")
+    return out
+
+
+def caption_embed(captions, masks, word_emb, entities_encoded, facts_encoded, pe, V, pad_token, scale, pos0=0,
+                  want_emb=False):
+    B, Lc = captions.shape
+    K, d = entities_encoded.shape[1], entities_encoded.shape[2]
+    F = 0 if facts_encoded is None else facts_encoded.shape[1]
+    out = torch.empty(B, Lc, d, device=captions.device, dtype=torch.float32)
+    emb = torch.empty_like(out) if want_emb else None
+    L.check(L.load().ick_caption_embed(_p(captions), _p(masks), _p(word_emb), _p(entities_encoded),
+                                       _p(facts_encoded), _p(pe), _p(out), _p(emb), B, Lc, K, F, V, d, pad_token,
+                                       scale, pos0, _stream()), "ick_caption_embed")
+    return (out, emb) if want_emb else out
+
+
+def context_indicators(captions, facts, K, V, fc_pred_wt=None, fc_pred_b=None, mode=0):
+    B, Lc = captions.shape
+    F = facts.shape[1]
+    T = Lc if mode == 0 else 1
+    eib = torch.empty(B, T, F, device=captions.device, dtype=torch.float32)
+    gate = None
+    num_pred = d = 0
+    if fc_pred_wt is not None:
+        num_pred, d = fc_pred_wt.shape
+        gate = torch.empty(B, T, d, device=captions.device, dtype=torch.float32)
+    L.check(L.load().ick_context_indicators(_p(captions), _p(facts), _p(fc_pred_wt), _p(fc_pred_b), _p(eib),
+                                            _p(gate), B, Lc, T, K, F, V, num_pred, d, mode, _stream()),
+            "ick_context_indicators")
+    return eib, gate
+
+
+def pointer_scores(h, ctx, w, bias, out, col0, ind=None, out_gmap=None):
+    B, T, d = h.shape
+    Kc = ctx.shape[1]
+    L.check(L.load().ick_pointer_scores(_p(h), _p(ctx), _p(w), _p(bias), _p(ind), _p(out), B, T, Kc, d,
+                                        out.stride(-2), col0, _p(out_gmap), _stream()), "ick_pointer_scores")
+    return out
+
+
+def mul(a, b, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    L.check(L.load().ick_mul(_p(a), _p(b), _p(out), a.numel(), _stream()), "ick_mul")
+    return out
+
+
+def top2(scores):
+    B, Vx = scores.shape
+    best = torch.empty(B, device=scores.device, dtype=torch.int32)
+    second = torch.empty_like(best)
+    L.check(L.load().ick_top2(_p(scores), scores.stride(0), B, Vx, _p(best), _p(second), _stream()), "ick_top2")
+    return best, second
+
+
+def greedy_update(best, second, output, hist, finished, next_token, next_mask, step, V, K, has_facts, end_token):
+    B, max_len = output.shape
+    L.check(L.load().ick_greedy_update(_p(best), _p(second), _p(output), _p(hist), _p(finished), _p(next_token),
+                                       _p(next_mask), B, step, max_len, V, K, int(has_facts), end_token, _stream()),
+            "ick_greedy_update")
+
+
+def packed_ce(scores, captions_sorted, decode_len, pad_token, want_grad=False):
+    """Returns (loss_sum (1,), count (1,), dscores or None): token-mean loss = loss_sum / count."""
+    B, Lc, Vx = scores.shape
+    dev = scores.device
+    row_loss = torch.empty(B * Lc, device=dev, dtype=torch.float32)
+    loss_sum = torch.empty(1, device=dev, dtype=torch.float32)
+    count = torch.empty(1, device=dev, dtype=torch.float32)
+    dscores = torch.empty_like(scores) if want_grad else None
+    L.check(L.load().ick_packed_ce(_p(scores), scores.stride(1), _p(captions_sorted), _p(decode_len), B, Lc, Vx,
+                                   pad_token, _p(row_loss), _p(loss_sum), _p(count), _p(dscores), _stream()),
+            "ick_packed_ce")
+    return loss_sum, count, dscores

@@ -1,0 +1,172 @@
+/*
+ * ick_amd.h -- C ABI of libick_amd.so: the MI355X (gfx950) caption-decoder hot path of
+ * sonniki/image-captioning-with-external-knowledge.
+ *
+ * The reference has no FFI layer: its boundary for this path is the Python API of
+ * <variant>/models.py.  The entry points below are the op boundaries of
+ * SURVEY.md §8(a) rows a1-a14 that the package's Python `models` shim binds through ctypes;
+ * each comment names the reference call site it replaces (paths relative to the reference
+ * root).  Conventions:
+ *   - every pointer is a DEVICE pointer to fp32 / int32 / int64 data owned by the caller
+ *     (PyTorch's caching allocator in the shipped binding); nothing is allocated or freed here;
+ *   - every entry takes the hipStream_t (as void*) to launch on and returns 0 on success,
+ *     a negative ICK_E* code for argument errors, or a positive hipError_t;
+ *   - all activations are batch-major, row-major fp32: (B, T, d) with d contiguous;
+ *   - no entry synchronises the stream or the device.
+ */
+#ifndef ICK_AMD_H
+#define ICK_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICK_OK 0
+#define ICK_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
+#define ICK_EALIGN (-2)   /* pointer or stride violates an alignment requirement */
+#define ICK_EWORKSPACE (-3) /* workspace too small */
+
+#define ICK_MAX_LAYERS 8
+
+/* Library / device probe (no reference counterpart). */
+int ick_version(void);
+int ick_device_info(int* num_cu, int* wave_size, char* arch_name, int arch_name_len);
+
+/* ------------------------------------------------------------------------------------------
+ * Generic fp32 GEMM on the matrix cores:  C[m, n] = act( sum_k A(m,k) * B(n,k) + bias[n] )
+ * Replaces every nn.Linear / 1x1 nn.Conv2d call site on the path:
+ *   Encoder.conv1                         geo-aware/models.py:32,45
+ *   MultiheadAttention in/out projections geo-aware/models.py:241-244 (torch.nn internals)
+ *   linear1 / linear2 of the layers       geo-aware/models.py:241-244
+ *   fc_vocab, fc_predicate                geo-aware/models.py:303; knowledge-aware/models.py:436-438
+ * A element (m,k) lives at A[a_goff(m) + (m % a_grp) * a_rs + k * a_ks] with
+ *   a_goff(m) = (a_gmap ? a_gmap[m / a_grp] : m / a_grp) * a_gs      (a_grp == 0: one group)
+ * B element (n,k) at B[n * b_rs + k * b_ks];  C row m starts at
+ *   C + (c_gmap ? c_gmap[m / c_grp] : m / c_grp) * c_gs + (m % c_grp) * c_rs.
+ * Exactly one of (a_rs, a_ks) and one of (b_rs, b_ks) must be 1.
+ * flags: bit0 = ReLU, bit1 = accumulate into C (C += ...), bit2 = atomic accumulate (split-K).
+ */
+typedef struct {
+    const float* A; const float* B; float* C; const float* bias;
+    int32_t M, N, K;
+    int64_t a_rs, a_ks; int32_t a_grp; int64_t a_gs; const int32_t* a_gmap;
+    int64_t b_rs, b_ks;
+    int64_t c_rs; int32_t c_grp; int64_t c_gs; const int32_t* c_gmap;
+    int32_t flags;
+    int32_t split_k;       /* >1: K is split over blockIdx.z, partial sums added atomically */
+    float   alpha;         /* scales the product before bias (1.0f normally) */
+} ick_gemm_args;
+
+#define ICK_GEMM_RELU 1
+#define ICK_GEMM_ACCUM 2
+#define ICK_GEMM_ATOMIC 4
+
+int ick_gemm(const ick_gemm_args* args, void* stream);
+
+/* y[r,:] = LayerNorm(x[r,:] + res[r,:]) * gamma + beta   (res may be NULL), d <= 1024.
+ * Replaces norm1/norm2/norm3 + the residual adds of Transformer{En,De}coderLayer
+ * (torch/nn/modules/transformer.py post-LN path; built at geo-aware/models.py:241-244).
+ * Optional outputs mean/rstd (rows) are kept for the backward pass. */
+int ick_add_layernorm(const float* x, const float* res, const float* gamma, const float* beta,
+                      float* y, int64_t rows, int32_t d, float eps,
+                      int64_t x_ld, int64_t res_ld, int64_t y_ld,
+                      float* save_mean, float* save_rstd, void* stream);
+
+/* Multi-head attention core: O = softmax(Q K^T * scale [+ causal mask]) V per (batch, head).
+ * Q element (b,t,h,j) at Q[b*q_bs + t*q_ts + h*dh + j]; K/V element (b,s,h,j) at
+ * K[b*k_bs + s*k_ss + h*k_hs + j]; O like Q with o_bs/o_ts.  kv_len (optional, int32[B]) limits
+ * the keys of sample b to s < kv_len[b] (KV-cached greedy decode); q_pos0 is the absolute
+ * position of query row 0 for the causal mask (key s visible iff s <= q_pos0 + t).
+ * Replaces the scaled-dot-product core of nn.MultiheadAttention for
+ *   decoder self-attention (causal), decoder cross-attention over [image ; entity ; fact] memory,
+ *   context-encoder self-attention            geo-aware/models.py:348,358; knowledge-aware:495-496,508
+ * lse (optional, B*H*T) receives log-sum-exp per query row for the backward pass. */
+typedef struct {
+    const float* Q; const float* K; const float* V; float* O; float* lse;
+    int32_t B, H, T, S, dh;
+    int64_t q_bs, q_ts, k_bs, k_ss, k_hs, v_bs, v_ss, v_hs, o_bs, o_ts;
+    float scale; int32_t causal; int32_t q_pos0; const int32_t* kv_len;
+} ick_attn_args;
+int ick_attention(const ick_attn_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Prefill gathers (rows a2-a5, a11).
+ * variant: 0 geo, 1 knowledge, 2 news. */
+#define ICK_GEO 0
+#define ICK_KNOWLEDGE 1
+#define ICK_NEWS 2
+
+/* EntityEncoder.forward: geo-aware/models.py:82-104; knowledge-aware/models.py:82-133;
+ * news-knowledge-aware/models.py:79-134.  entities (B,K,cols) fp32, facts (B,F,3) int64 (may be
+ * NULL for geo), type_emb (ntypes, d-type_off), word_emb (V,d) (news only) -> out (B,K,d). */
+int ick_entity_encode(int32_t variant, const float* entities, int32_t ent_cols, const int64_t* facts,
+                      const float* type_emb, int32_t ntypes, const float* word_emb, int32_t vocab,
+                      float* out, int32_t B, int32_t K, int32_t F, int32_t d, void* stream);
+
+/* FactEncoder.forward: knowledge-aware/models.py:170-188. */
+int ick_fact_encode(const int64_t* facts, const float* entities_encoded, const float* pred_emb,
+                    int32_t num_pred, float* out, int32_t B, int32_t K, int32_t F, int32_t d, void* stream);
+
+/* CaptionEmbedder.forward + `* sqrt(emb_dim)` + PositionEncoder (eval):
+ * geo-aware/models.py:143-181,355-357,199-209; knowledge-aware/models.py:209-259.
+ * captions/masks (B,L) int64; pos0 = absolute position of column 0 (greedy decode steps);
+ * pe (max_len, d) sinusoid table.  out (B,L,d) = emb*scale + pe[pos0+l].  emb_out (optional)
+ * receives the unscaled embedding rows (fixture stage "embeddings"). */
+int ick_caption_embed(const int64_t* captions, const int64_t* masks, const float* word_emb,
+                      const float* entities_encoded, const float* facts_encoded, const float* pe,
+                      float* out, float* emb_out, int32_t B, int32_t L, int32_t K, int32_t F, int32_t V,
+                      int32_t d, int32_t pad_token, float scale, int32_t pos0, void* stream);
+
+/* get_context_indicators: knowledge-aware/models.py:380-418.  Produces, per (b, position p):
+ *   eib (B,T,F) 0/1: subject of fact j was mentioned before p (T==L) / anywhere so far (T==1)
+ *   gate (B,T,d) = fc_predicate(predicate_indicator) = bias + sum over DISTINCT active predicates
+ *   of fc_predicate.weight[:, pred]  (the dense (B,L,3000) indicator and its GEMM,
+ *   knowledge-aware/models.py:436, are never materialised).  fc_pred_wt is the TRANSPOSED weight,
+ *   (num_pred, d) row-major, so one predicate is one contiguous row.  gate may be NULL.
+ * mode 0: teacher-forced (strictly-before semantics), mode 1: predict (whole buffer). */
+int ick_context_indicators(const int64_t* captions, const int64_t* facts, const float* fc_pred_wt,
+                           const float* fc_pred_b, float* eib, float* gate, int32_t B, int32_t L,
+                           int32_t T, int32_t K, int32_t F, int32_t V, int32_t num_pred, int32_t d,
+                           int32_t mode, void* stream);
+
+/* Pointer scores of get_scores (geo-aware/models.py:305-310; knowledge-aware/models.py:439-452):
+ *   out[b,t,col0+k] = sum_d h[b,t,d]*ctx[b,k,d]*w[d] * (ind ? ind[b,t,k] : 1) + bias[0]
+ * written in place into the concatenated score rows (row stride out_ld).  out_gmap (optional,
+ * int32[B]) redirects sample b's rows to batch slot out_gmap[b]. */
+int ick_pointer_scores(const float* h, const float* ctx, const float* w, const float* bias,
+                       const float* ind, float* out, int32_t B, int32_t T, int32_t Kc, int32_t d,
+                       int64_t out_ld, int32_t col0, const int32_t* out_gmap, void* stream);
+
+/* elementwise y = a * b  (vocab_input = h * gate, knowledge-aware/models.py:437) */
+int ick_mul(const float* a, const float* b, float* y, int64_t n, void* stream);
+
+/* Greedy selection of predict(): softmax -> argmax and runner-up per row
+ * (geo-aware/models.py:410-419).  scores (B, Vx) row stride ld -> best/second int32[B]. */
+int ick_top2(const float* scores, int64_t ld, int32_t B, int32_t Vx, int32_t* best, int32_t* second,
+             void* stream);
+
+/* One step of predict()'s token bookkeeping for B independent captions, entirely on device
+ * (geo-aware/models.py:412-442; knowledge-aware/models.py:575-608): writes output[step],
+ * applies the repeated-n-gram clean-up, marks finished captions, and emits the next input
+ * token + mask.  output (B, max_len) int64 pre-filled with <pad>; top2_hist (B, max_len) int32;
+ * finished (B) int32. */
+int ick_greedy_update(const int32_t* best, const int32_t* second, int64_t* output, int32_t* top2_hist,
+                      int32_t* finished, int64_t* next_token, int64_t* next_mask, int32_t B,
+                      int32_t step, int32_t max_len, int32_t V, int32_t K, int32_t has_facts,
+                      int32_t end_token, void* stream);
+
+/* fused token-mean cross entropy over the packed rows of train.py
+ * (pack_padded_sequence + CrossEntropyLoss(ignore_index=<pad>), geo-aware/train.py:275-281):
+ * rows (b,t) with t < decode_len[b] and target != pad contribute.  Writes loss_sum[0] (sum of
+ * token losses), count[0] (number of tokens) and, if dscores != NULL, the UNNORMALISED gradient
+ * (softmax - onehot) for contributing rows and zeros elsewhere. */
+int ick_packed_ce(const float* scores, int64_t ld, const int64_t* captions_sorted, const int32_t* decode_len,
+                  int32_t B, int32_t L, int32_t Vx, int32_t pad_token, float* row_loss /* B*L workspace */,
+                  float* loss_sum, float* count, float* dscores, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICK_AMD_H */

@@ -99,3 +99,17 @@ def test_loop_cleanup_cases():
     assert out == [1, 2, 92, 93, 94, 95]        # trigram repeat rewrites FOUR positions (as the reference does)
     out = [1, 2, 3, 4]; R.loop_cleanup(out, [90, 91, 92, 93], 3)
     assert out == [1, 2, 3, 4]
+
+
+@pytest.mark.parametrize("name", ["fwd_tiny_geo", "fwd_tiny_knowledge", "fwd_tiny_news", "fwd_mid_geo"])
+def test_stock_module_port_matches_reference(name):
+    """oracle/stock.py (the timed CPU baseline of bench.py) against the reference's outputs."""
+    from oracle.stock import StockDecoder
+    g = load_golden(name)
+    cfg, P, wm, batch, enc_out = case_from_golden(g)
+    m = StockDecoder(cfg.variant, wm).load_reference_params(P).eval()
+    with torch.no_grad():
+        scores, caps, dl = m(batch["captions"], enc_out, batch["caption_masks"], batch["caption_lengths"],
+                             batch["entities"], batch.get("facts"))
+    assert dl == g["decode_lengths"].tolist()
+    assert (scores - t(g["scores"])).abs().max().item() < TOL
