@@ -41,12 +41,31 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return int(os.environ.get("ICK_CPU_THREADS", min(n, 16)))
+
+
 def cpu_baseline(cfg, seed, budget_s):
     """Time the oracle's stock-module port of the reference on the host cores (same seeded workload)."""
     import ick_amd.synth as synth
     from oracle.stock import StockDecoder
     variant, B, L, K, V, Fn = cfg["variant"], cfg["B"], cfg["L"], cfg["K"], cfg["V"], cfg["F"]
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     P = synth.make_params(variant, V, seed)
     cw, cb = synth.make_conv1(seed)
