@@ -183,7 +183,7 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d (independent shards)" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "gemm_kernel<4,1,4,4,A k-major> (Encoder.conv1: [%d x %d] x [%d x %d])"
+                         "kernel": "gemm_kernel<2,2,2,2,A k-major,B k-contig,vec> (Encoder.conv1: [%d x %d] x [%d x %d])"
                                    % (dom_shape[0], dom_shape[2], dom_shape[2], dom_shape[1]),
                          "kernel_ms": kern_ms, "flops_per_launch": flops, "launches_timed": len(events)},
         }

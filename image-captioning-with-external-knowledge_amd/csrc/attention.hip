@@ -18,9 +18,13 @@
 namespace ick {
 namespace {
 
-template <int DHP>
+// VEC: operands are in the head-major padded layout (rows of DHP floats, 16-byte aligned) that
+// ick_gemm's head-split epilogue writes: every global access is a coalesced float4; pad columns
+// (dh..DHP) may hold anything and are masked to zero in registers.
+template <int DHP, bool VEC>
 __global__ __launch_bounds__(256) void attn_kernel(ick_attn_args p, int TQ, int SLD) {
     constexpr int VLD = DHP + 4;  // float4 rows; 8 lanes x 16 B cover the 32 banks once
+    constexpr int G = DHP / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int S = p.S, dh = p.dh;
     float* Vs = smem;                 // S * VLD
@@ -33,32 +37,66 @@ __global__ __launch_bounds__(256) void attn_kernel(ick_attn_args p, int TQ, int 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int slen = S;
     if (p.kv_len) slen = min(S, p.kv_len[b]);
+    const float* qb = p.Q + (int64_t)b * p.q_bs + (int64_t)h * p.q_hs + (int64_t)t0 * p.q_ts;
+    const float* kb = p.K + (int64_t)b * p.k_bs + (int64_t)h * p.k_hs;
+    const float* vb = p.V + (int64_t)b * p.v_bs + (int64_t)h * p.v_hs;
+
+    // This lane's first key row is requested before anything else so that its latency overlaps the
+    // Q / V staging (one memory round trip for the whole workgroup instead of two).
+    float kreg[DHP];
+    auto load_key = [&](int s) {
+        if constexpr (VEC) {
+            const float4* kr = reinterpret_cast<const float4*>(kb + (int64_t)min(s, slen - 1) * DHP);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float4 x = kr[g];
+                kreg[4 * g + 0] = x.x; kreg[4 * g + 1] = x.y; kreg[4 * g + 2] = x.z; kreg[4 * g + 3] = x.w;
+            }
+        } else {
+            const float* kr = kb + (int64_t)min(s, slen - 1) * p.k_ss;
+#pragma unroll
+            for (int j = 0; j < DHP; ++j) kreg[j] = kr[j < dh ? j : 0];
+        }
+    };
+    if (slen > 0) load_key(tid);
 
     // stage the Q chunk (zero padded to DHP columns) and V (zero padded to VLD columns)
-    for (int idx = tid; idx < nt * DHP; idx += 256) {
-        const int t = idx / DHP, j = idx % DHP;
-        Qs[idx] = j < dh ? p.Q[(int64_t)b * p.q_bs + (int64_t)(t0 + t) * p.q_ts + h * dh + j] : 0.f;
-    }
-    {
-        const float* vb = p.V + (int64_t)b * p.v_bs + (int64_t)h * p.v_hs;
-        for (int idx = tid; idx < slen * VLD; idx += 256) {
-            const int s = idx / VLD, j = idx - s * VLD;
-            Vs[idx] = j < dh ? vb[(int64_t)s * p.v_ss + j] : 0.f;
+    if constexpr (VEC) {
+        for (int f = tid; f < nt * G; f += 256) {
+            const int t = f / G, g = f % G;
+            float4 x = *reinterpret_cast<const float4*>(qb + (int64_t)t * DHP + 4 * g);
+            x.x = 4 * g + 0 < dh ? x.x : 0.f; x.y = 4 * g + 1 < dh ? x.y : 0.f;
+            x.z = 4 * g + 2 < dh ? x.z : 0.f; x.w = 4 * g + 3 < dh ? x.w : 0.f;
+            *reinterpret_cast<float4*>(Qs + t * DHP + 4 * g) = x;
+        }
+        for (int f = tid; f < slen * G; f += 256) {
+            const int s = f / G, g = f % G;
+            float4 x = *reinterpret_cast<const float4*>(vb + (int64_t)s * DHP + 4 * g);
+            x.x = 4 * g + 0 < dh ? x.x : 0.f; x.y = 4 * g + 1 < dh ? x.y : 0.f;
+            x.z = 4 * g + 2 < dh ? x.z : 0.f; x.w = 4 * g + 3 < dh ? x.w : 0.f;
+            *reinterpret_cast<float4*>(Vs + s * VLD + 4 * g) = x;
+        }
+    } else {
+        for (int idx = tid; idx < nt * DHP; idx += 256) {
+            const int t = idx / DHP, j = idx % DHP;
+            Qs[idx] = j < dh ? qb[(int64_t)t * p.q_ts + j] : 0.f;
+        }
+        for (int idx = tid; idx < slen * DHP; idx += 256) {
+            const int s = idx / DHP, j = idx % DHP;
+            Vs[s * VLD + j] = j < dh ? vb[(int64_t)s * p.v_ss + j] : 0.f;
         }
     }
     __syncthreads();
 
     // phase 1: lane <-> key.  The key row lives in registers, query rows are LDS broadcasts.
-    const float* kb_base = p.K + (int64_t)b * p.k_bs + (int64_t)h * p.k_hs;
     for (int s = tid; s < slen; s += 256) {
-        float kreg[DHP];
-        const float* kr = kb_base + (int64_t)s * p.k_ss;
+        if (s != tid) load_key(s);
 #pragma unroll
-        for (int j = 0; j < DHP; ++j) kreg[j] = j < dh ? kr[j] : 0.f;
+        for (int j = 0; j < DHP; ++j) kreg[j] = j < dh ? kreg[j] : 0.f;  // pad columns may hold anything
         for (int t = 0; t < nt; ++t) {
             float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-            for (int j4 = 0; j4 < DHP / 4; ++j4) {
+            for (int j4 = 0; j4 < G; ++j4) {
                 const float4 q = *reinterpret_cast<const float4*>(Qs + t * DHP + 4 * j4);
                 a0 = fmaf(q.x, kreg[4 * j4 + 0], a0);
                 a1 = fmaf(q.y, kreg[4 * j4 + 1], a1);
@@ -93,9 +131,8 @@ __global__ __launch_bounds__(256) void attn_kernel(ick_attn_args p, int TQ, int 
     __syncthreads();
 
     // phase 3: O[t][4g..4g+3] = sum_s P[t][s] V[s][4g..4g+3]; lane <-> (query, 4 output columns)
-    constexpr int JG = DHP / 4;
-    for (int idx = tid; idx < nt * JG; idx += 256) {
-        const int t = idx / JG, g = idx % JG;
+    for (int idx = tid; idx < nt * G; idx += 256) {
+        const int t = idx / G, g = idx % G;
         const float* pr = Ps + t * SLD;
         const float* vc = Vs + 4 * g;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -129,14 +166,20 @@ int launch_attn(const ick_attn_args& a, hipStream_t s) {
     const size_t fl = fixed + (size_t)TQ * (DHP + SLD + 1);
     if (fl > budget) return ICK_EINVAL;
     const size_t smem = fl * sizeof(float);
-    auto kern = attn_kernel<DHP>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool vec = a.q_ts == DHP && a.k_ss == DHP && a.v_ss == DHP && al16(a.Q) && al16(a.K) && al16(a.V) &&
+                     a.q_bs % 4 == 0 && a.q_hs % 4 == 0 && a.k_bs % 4 == 0 && a.k_hs % 4 == 0 && a.v_bs % 4 == 0 &&
+                     a.v_hs % 4 == 0;
+    static bool attr_set[2] = {false, false};
+    const void* kern = vec ? (const void*)attn_kernel<DHP, true> : (const void*)attn_kernel<DHP, false>;
+    if (!attr_set[vec]) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_set[vec] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.H, a.B, ceil_div(a.T, TQ)), dim3(256), smem, s, a, TQ, SLD);
+    const dim3 grid(a.H, a.B, ceil_div(a.T, TQ));
+    if (vec) hipLaunchKernelGGL((attn_kernel<DHP, true>), grid, dim3(256), smem, s, a, TQ, SLD);
+    else hipLaunchKernelGGL((attn_kernel<DHP, false>), grid, dim3(256), smem, s, a, TQ, SLD);
     ICK_LAUNCH_RET();
 }
 

@@ -18,6 +18,8 @@
 //     ds_read_b32 in that same k order; both strides are bank-conflict free (<=2-way);
 //   * the tile index is remapped so the 8 XCDs (round-robin over blockIdx) each walk a
 //     contiguous run of tiles and the smaller operand panel stays in that XCD's L2.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace ick {
@@ -40,94 +42,122 @@ struct RowMap {  // offset of logical row r:  goff(r / grp) + (r % grp) * rs
     }
 };
 
+// Column offset inside an output row: the column itself, or the head-split scatter
+// [segment][head][position][dhp] (see include/ick_amd.h).
+__device__ __forceinline__ int64_t col_offset(const ick_gemm_args& p, int col) {
+    if (p.hs_dh <= 0) return col;
+    const int hd = p.hs_H * p.hs_dh;
+    const int seg = col / hd, r = col - seg * hd;
+    const int h = r / p.hs_dh, j = r - h * p.hs_dh;
+    return ((int64_t)seg * p.hs_H + h) * ((int64_t)p.hs_S * p.hs_dhp) + j;
+}
+
 // Global -> register -> LDS stager for one operand tile of R rows x BK k.
-template <int R, bool KM>
+// VEC: every row offset / K / base pointer is 16-byte friendly, so the tile is fetched with
+// unconditional global_load_dwordx4 from clamped (always valid) addresses and out-of-range rows
+// or k-slices are zeroed by selects -- no branches, all loads of a slice stay in flight together.
+// !VEC is the generic element-wise fallback for ragged / unaligned operands.
+template <int R, bool KM, bool VEC>
 struct Stager {
     static constexpr int NP = R / 32;                // float4 per thread
     static constexpr int CH = KM ? R / 4 : BK / 4;   // float4 chunks along the contiguous dim
     static constexpr int LD = KM ? R + 4 : LDK;
     static constexpr int FLOATS = KM ? BK * LD : R * LD;
+    static constexpr int KP = 256 / CH;              // k-major: k lines covered per pass
     const float* base;
-    int64_t off[KM ? 1 : NP];  // element offset of this thread's row(s); <0 = out of range
-    int64_t ks;                // k stride (1 for k-contiguous)
-    int c, r0;                 // chunk index / first row (k-contig) or first k line (k-major)
-    bool vec;
-    int rows_total;
-    int row_first;             // k-major: first of this thread's 4 rows (global index)
-    RowMap rm;
+    int64_t off[KM ? 4 : NP];  // k-contig: one clamped row offset per pass; k-major: this thread's 4 rows
+    int64_t ks;
+    int c, r0;
+    uint32_t ok;               // validity bits of the rows behind off[]
     float4 v[NP];
 
-    __device__ __forceinline__ void init(const float* p, const RowMap& m, int64_t kstride, int tile_row0,
-                                         int rows, bool vec_ok) {
-        base = p; ks = kstride; vec = vec_ok; rows_total = rows; rm = m;
+    __device__ __forceinline__ void init(const float* p, const RowMap& m, int64_t kstride, int tile_row0, int rows) {
+        base = p; ks = kstride;
         const int t = threadIdx.x;
         c = t % CH;
         r0 = t / CH;
+        ok = 0;
         if constexpr (KM) {
-            row_first = tile_row0 + 4 * c;
-            off[0] = row_first < rows ? m(row_first) : -1;
+#pragma unroll
+            for (int q = 0; q < (VEC ? 1 : 4); ++q) {
+                const int gr = tile_row0 + 4 * c + q;
+                if (gr < rows) ok |= 1u << q;
+                off[q] = m(min(gr, rows - 1));
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 const int gr = tile_row0 + r0 + 32 * j;
-                off[j] = gr < rows ? m(gr) : -1;
+                if (gr < rows) ok |= 1u << j;
+                off[j] = m(min(gr, rows - 1));
             }
         }
     }
 
+    // Issue the global loads of slice [k0, k0+BK) from clamped addresses; nothing here depends on the
+    // loaded data, so the loads stay in flight behind the MFMAs of the current slice.
     __device__ __forceinline__ void load(int k0, int kend) {
         if constexpr (KM) {
-            constexpr int KP = 256 / CH;
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 const int k = k0 + r0 + KP * j;
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < kend && off[0] >= 0) {
-                    if (vec) {
-                        x = *reinterpret_cast<const float4*>(base + off[0] + (int64_t)k * ks);
-                    } else {
-                        float e[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int gr = row_first + q;
-                            e[q] = gr < rows_total ? base[rm(gr) + (int64_t)k * ks] : 0.f;
-                        }
-                        x = make_float4(e[0], e[1], e[2], e[3]);
-                    }
+                const int64_t ko = (int64_t)(k < kend ? k : 0) * ks;
+                if constexpr (VEC) {
+                    v[j] = *reinterpret_cast<const float4*>(base + off[0] + ko);
+                } else {
+                    v[j].x = base[off[0] + ko]; v[j].y = base[off[1] + ko];
+                    v[j].z = base[off[2] + ko]; v[j].w = base[off[3] + ko];
                 }
-                v[j] = x;
+            }
+        } else {
+            const int k = k0 + 4 * c;
+            if constexpr (VEC) {
+                const int kk = k < kend ? k : 0;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) v[j] = *reinterpret_cast<const float4*>(base + off[j] + kk);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    v[j].x = base[off[j] + (k + 0 < kend ? k + 0 : 0)];
+                    v[j].y = base[off[j] + (k + 1 < kend ? k + 1 : 0)];
+                    v[j].z = base[off[j] + (k + 2 < kend ? k + 2 : 0)];
+                    v[j].w = base[off[j] + (k + 3 < kend ? k + 3 : 0)];
+                }
+            }
+        }
+    }
+
+    // Zero what lies outside the matrix (rows >= rows_total, k >= kend) and write the slice to LDS.
+    __device__ __forceinline__ void store(float* lds, int k0, int kend) const {
+        if constexpr (KM) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const bool kv = k0 + r0 + KP * j < kend;
+                float4 x = v[j];
+                if constexpr (VEC) {
+                    const bool g = kv && (ok & 1u);
+                    x.x = g ? x.x : 0.f; x.y = g ? x.y : 0.f; x.z = g ? x.z : 0.f; x.w = g ? x.w : 0.f;
+                } else {
+                    x.x = (kv && (ok & 1u)) ? x.x : 0.f; x.y = (kv && (ok & 2u)) ? x.y : 0.f;
+                    x.z = (kv && (ok & 4u)) ? x.z : 0.f; x.w = (kv && (ok & 8u)) ? x.w : 0.f;
+                }
+                *reinterpret_cast<float4*>(lds + (r0 + KP * j) * LD + 4 * c) = x;
             }
         } else {
             const int k = k0 + 4 * c;
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (off[j] >= 0 && k < kend) {
-                    const float* p = base + off[j] + k;
-                    if (vec) {
-                        x = *reinterpret_cast<const float4*>(p);
-                    } else {
-                        x.x = p[0];
-                        if (k + 1 < kend) x.y = p[1];
-                        if (k + 2 < kend) x.z = p[2];
-                        if (k + 3 < kend) x.w = p[3];
-                    }
+                const bool rv = (ok >> j) & 1u;
+                float4 x = v[j];
+                if constexpr (VEC) {
+                    const bool g = rv && k < kend;
+                    x.x = g ? x.x : 0.f; x.y = g ? x.y : 0.f; x.z = g ? x.z : 0.f; x.w = g ? x.w : 0.f;
+                } else {
+                    x.x = (rv && k + 0 < kend) ? x.x : 0.f; x.y = (rv && k + 1 < kend) ? x.y : 0.f;
+                    x.z = (rv && k + 2 < kend) ? x.z : 0.f; x.w = (rv && k + 3 < kend) ? x.w : 0.f;
                 }
-                v[j] = x;
+                *reinterpret_cast<float4*>(lds + (r0 + 32 * j) * LD + 4 * c) = x;
             }
-        }
-    }
-
-    __device__ __forceinline__ void store(float* lds) const {
-        if constexpr (KM) {
-            constexpr int KP = 256 / CH;
-#pragma unroll
-            for (int j = 0; j < NP; ++j)
-                *reinterpret_cast<float4*>(lds + (r0 + KP * j) * LD + 4 * c) = v[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < NP; ++j)
-                *reinterpret_cast<float4*>(lds + (r0 + 32 * j) * LD + 4 * c) = v[j];
         }
     }
 };
@@ -145,11 +175,11 @@ __device__ __forceinline__ void read_frag(const float* lds, int row0, int t, int
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool AKM, bool BKM>
+template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m, int tiles_n, int kchunk) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-    using SA = Stager<BM, AKM>;
-    using SB = Stager<BN, BKM>;
+    using SA = Stager<BM, AKM, VEC>;
+    using SB = Stager<BN, BKM, VEC>;
     constexpr int STAGE = SA::FLOATS + SB::FLOATS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -169,10 +199,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m,
 
     const RowMap amap{p.a_grp, p.a_gs, p.a_gmap, p.a_rs};
     const RowMap bmap{0, 0, nullptr, p.b_rs};
-    const bool avec = (p.flags >> 8) & 1, bvec = (p.flags >> 9) & 1;
     SA sa; SB sb;
-    sa.init(p.A, amap, p.a_ks, m0, p.M, avec);
-    sb.init(p.B, bmap, p.b_ks, n0, p.N, bvec);
+    sa.init(p.A, amap, p.a_ks, m0, p.M);
+    sb.init(p.B, bmap, p.b_ks, n0, p.N);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -187,7 +216,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m,
     const int nk = (kend - kbeg + BK - 1) / BK;
     if (nk > 0) {
         sa.load(kbeg, kend); sb.load(kbeg, kend);
-        sa.store(smem); sb.store(smem + SA::FLOATS);
+        sa.store(smem, kbeg, kend); sb.store(smem + SA::FLOATS, kbeg, kend);
     }
     __syncthreads();
     for (int it = 0; it < nk; ++it) {
@@ -213,47 +242,74 @@ __global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m,
         }
         if (more) {
             float* An = smem + ((it + 1) & 1) * STAGE;
-            sa.store(An); sb.store(An + SA::FLOATS);
+            sa.store(An, k0 + BK, kend); sb.store(An + SA::FLOATS, k0 + BK, kend);
         }
         __syncthreads();
     }
 
     // Epilogue.  C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.
-    const RowMap cmap{p.c_grp, p.c_gs, p.c_gmap, p.c_rs};
-    const bool relu = p.flags & ICK_GEMM_RELU, accum = p.flags & ICK_GEMM_ACCUM, atomic = p.flags & ICK_GEMM_ATOMIC;
-    const bool add_bias = p.bias != nullptr && blockIdx.z == 0;
+    const bool hs = p.hs_dh > 0;
+    const RowMap cmap{p.c_grp, p.c_gs, p.c_gmap, hs ? (int64_t)p.hs_dhp : p.c_rs};
+    const int64_t row_bias = hs ? (int64_t)p.hs_s0 * p.hs_dhp : 0;
+    const bool relu = p.flags & ICK_GEMM_RELU;
+    const int mode = (p.flags & ICK_GEMM_ATOMIC) ? 2 : ((p.flags & ICK_GEMM_ACCUM) ? 1 : 0);
+    float bv[TN];
+    int cols[TN];
+    int64_t co[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        cols[b] = n0 + (wn * TN + b) * 16 + fi;
+        co[b] = col_offset(p, cols[b]);
+        bv[b] = (p.bias != nullptr && blockIdx.z == 0 && cols[b] < p.N) ? p.bias[cols[b]] : 0.f;
+    }
+    const float alpha = p.alpha;
+    int64_t coff[TM][4];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + (wm * TM + a) * 16 + fq * 4 + r;
+            coff[a][r] = row < p.M ? cmap(row) + row_bias : -1;
+        }
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = m0 + (wm * TM + a) * 16 + fq * 4 + r;
-            if (row >= p.M) continue;
-            float* crow = p.C + cmap(row);
+            if (coff[a][r] < 0) continue;
+            float* crow = p.C + coff[a][r];
+            float v[TN];
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
-                const int col = n0 + (wn * TN + b) * 16 + fi;
-                if (col >= p.N) continue;
-                float v = acc[a][b][r] * p.alpha;
-                if (add_bias) v += p.bias[col];
-                if (relu) v = fmaxf(v, 0.f);
-                if (atomic) atomicAdd(crow + col, v);
-                else if (accum) crow[col] += v;
-                else crow[col] = v;
+                v[b] = acc[a][b][r] * alpha + bv[b];
+                if (relu) v[b] = fmaxf(v[b], 0.f);
+            }
+            if (mode == 0) {
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    if (cols[b] < p.N) crow[co[b]] = v[b];
+            } else if (mode == 1) {
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    if (cols[b] < p.N) crow[co[b]] += v[b];
+            } else {
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    if (cols[b] < p.N) atomicAdd(crow + co[b], v[b]);
             }
         }
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool AKM, bool BKM>
+template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC>
 int launch(const ick_gemm_args& a, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-    constexpr int STAGE = Stager<BM, AKM>::FLOATS + Stager<BN, BKM>::FLOATS;
+    constexpr int STAGE = Stager<BM, AKM, VEC>::FLOATS + Stager<BN, BKM, VEC>::FLOATS;
     constexpr size_t smem = 2 * STAGE * sizeof(float);
     const int tiles_m = ceil_div(a.M, BM), tiles_n = ceil_div(a.N, BN);
     int split = a.split_k > 1 ? a.split_k : 1;
     int kchunk = ceil_div(ceil_div(a.K, split), BK) * BK;
     split = ceil_div(a.K, kchunk);
-    auto kern = gemm_kernel<WM, WN, TM, TN, AKM, BKM>;
+    auto kern = gemm_kernel<WM, WN, TM, TN, AKM, BKM, VEC>;
     static bool attr_set = false;
     if (!attr_set && smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -261,6 +317,129 @@ int launch(const ick_gemm_args& a, hipStream_t s) {
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, 1, split), dim3(256), smem, s, a, tiles_m, tiles_n, kchunk);
+    ICK_LAUNCH_RET();
+}
+
+// ---------------------------------------------------------------------------------------------
+// K-resident variant for the short, wide chain GEMMs of the transformer layers
+// (M = B*L rows, N in {300, 512, 900}, K in {300, 512}): at 0.2-0.7 GFLOP each they are bound by
+// the global->LDS round trips of a K loop, not by the matrix cores.  Here a workgroup takes a
+// 32 x 32 output tile, pulls BOTH operand panels (32 rows x K each, k-contiguous) into LDS with
+// every load in flight at once, and runs the whole K reduction from LDS: one memory round trip
+// per workgroup.  Each wave owns one 16x16 tile and alternates two accumulators so consecutive
+// MFMAs are independent (40-cycle dependent latency vs 32-cycle issue).
+// ---------------------------------------------------------------------------------------------
+template <int NLOAD>
+__global__ __launch_bounds__(256) void gemm_kres_kernel(ick_gemm_args p, int tiles_m, int tiles_n, int KP,
+                                                        unsigned magic) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LD4 = KP / 4 + 1;  // LDS row stride in float4: KP (K rounded up to 16) + 4 floats of padding,
+    const int LD = LD4 * 4;      // which keeps the ds_read_b128 fragment rows on distinct banks
+    float* As = smem;
+    float* Bs = smem + 32 * LD;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    }
+    const int tm = bid % tiles_m, tn = bid / tiles_m;  // consecutive workgroups share the weight panel
+    const int m0 = tm * 32, n0 = tn * 32;
+    const RowMap amap{p.a_grp, p.a_gs, p.a_gmap, p.a_rs};
+    const bool hs = p.hs_dh > 0;
+    const RowMap cmap{p.c_grp, p.c_gs, p.c_gmap, hs ? (int64_t)p.hs_dhp : p.c_rs};
+    const int64_t row_bias = hs ? (int64_t)p.hs_s0 * p.hs_dhp : 0;
+    const int tid = threadIdx.x;
+    const int CH = KP / 4;           // float4 per LDS row (zero filled beyond K)
+    const int total = 64 * CH;       // rows 0..31 = A tile, 32..63 = B tile
+    // row offsets (may involve a group-map lookup) are resolved once, by one lane per row
+    __shared__ int64_t rowoff[96];   // [0,32) A rows, [32,64) B rows, [64,96) C rows; -1 = out of range
+    if (tid < 32) {
+        const int gr = m0 + tid;
+        rowoff[tid] = gr < p.M ? amap(gr) : -1;
+        rowoff[64 + tid] = gr < p.M ? cmap(gr) + row_bias : -1;
+    } else if (tid < 64) {
+        const int gr = n0 + tid - 32;
+        rowoff[tid] = gr < p.N ? (int64_t)gr * p.b_rs : -1;
+    }
+    __syncthreads();
+    float4 v[NLOAD];
+    // issue every load first (clamped addresses, no data-dependent control flow)
+    // idx / CH by multiply-shift (magic = ceil(2^20 / CH), exact for idx < 64 * CH; checked on the host)
+#pragma unroll
+    for (int j = 0; j < NLOAD; ++j) {
+        const int idx = min(tid + 256 * j, total - 1);
+        const int row = (int)(((unsigned)idx * magic) >> 20), c = idx - row * CH;
+        const int64_t ro = rowoff[row];
+        const float* src = (row < 32 ? p.A : p.B) + (ro < 0 ? 0 : ro) + (4 * c < p.K ? 4 * c : 0);
+        v[j] = *reinterpret_cast<const float4*>(src);
+    }
+#pragma unroll
+    for (int j = 0; j < NLOAD; ++j) {
+        const int idx = tid + 256 * j;
+        const int ci = min(idx, total - 1);
+        const int row = (int)(((unsigned)ci * magic) >> 20), c = ci - row * CH;
+        const bool good = rowoff[row] >= 0 && 4 * c < p.K;
+        float4 x = v[j];
+        x.x = good ? x.x : 0.f; x.y = good ? x.y : 0.f; x.z = good ? x.z : 0.f; x.w = good ? x.w : 0.f;
+        if (idx < total) reinterpret_cast<float4*>(smem)[row * LD4 + c] = x;
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fi = lane & 15, fq = lane >> 4;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const float* ap = As + (wm * 16 + fi) * LD + 4 * fq;
+    const float* bp = Bs + (wn * 16 + fi) * LD + 4 * fq;
+    const int nchunk = KP / 16;
+    for (int t = 0; t < nchunk; ++t) {
+        const float4 a = *reinterpret_cast<const float4*>(ap + 16 * t);
+        const float4 b = *reinterpret_cast<const float4*>(bp + 16 * t);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc1, 0, 0, 0);
+    }
+    const bool relu = p.flags & ICK_GEMM_RELU, accum = p.flags & ICK_GEMM_ACCUM;
+    const int col = n0 + wn * 16 + fi;
+    if (col < p.N) {
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t co = rowoff[64 + wm * 16 + fq * 4 + r];
+            if (co >= 0) {
+                float x = (acc0[r] + acc1[r]) * p.alpha + bv;
+                if (relu) x = fmaxf(x, 0.f);
+                float* dst = p.C + co + col_offset(p, col);
+                if (accum) *dst += x; else *dst = x;
+            }
+        }
+    }
+}
+
+template <int NLOAD>
+int launch_kres(const ick_gemm_args& a, int KP, hipStream_t s) {
+    const size_t smem = (size_t)64 * (KP + 4) * sizeof(float);
+    const int tiles_m = ceil_div(a.M, 32), tiles_n = ceil_div(a.N, 32);
+    auto kern = gemm_kres_kernel<NLOAD>;
+    static bool attr_set = false;
+    if (!attr_set) {  // 768 B of static LDS (rowoff) come on top of the dynamic panel
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int CH = KP / 4;
+    const unsigned magic = ((1u << 20) + CH - 1) / CH;
+    static signed char magic_ok[129] = {0};  // 0 unknown, 1 exact, -1 not exact
+    if (CH > 128) return ICK_EINVAL;
+    if (magic_ok[CH] == 0) {
+        magic_ok[CH] = 1;
+        for (int idx = 0; idx < 64 * CH; ++idx)
+            if ((int)(((unsigned)idx * magic) >> 20) != idx / CH) magic_ok[CH] = -1;
+    }
+    if (magic_ok[CH] < 0) return ICK_EINVAL;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), smem, s, a, tiles_m, tiles_n, KP, magic);
     ICK_LAUNCH_RET();
 }
 
@@ -279,6 +458,13 @@ extern "C" int ick_gemm(const ick_gemm_args* in, void* stream) {
     ICK_CHECK_ARG((a.a_rs == 1) || (a.a_ks == 1));
     ICK_CHECK_ARG((a.b_rs == 1) || (a.b_ks == 1));
     if (a.split_k > 1) ICK_CHECK_ARG(a.flags & ICK_GEMM_ATOMIC);
+    if (a.hs_dh > 0) {
+        ICK_CHECK_ARG(a.hs_dhp >= a.hs_dh && a.hs_H > 0 && a.hs_S > 0 && a.hs_s0 >= 0);
+        ICK_CHECK_ARG(a.N % (a.hs_H * a.hs_dh) == 0);
+        ICK_CHECK_ARG(a.hs_s0 + (a.c_grp > 0 ? a.c_grp : a.M) <= a.hs_S);
+    } else {
+        a.hs_dh = 0;
+    }
     if (a.a_grp <= 0) { a.a_grp = 0; a.a_gmap = nullptr; }
     if (a.c_grp <= 0) { a.c_grp = 0; a.c_gmap = nullptr; }
     // 16-byte vector staging is legal when every float4 the stager forms is aligned and in bounds.
@@ -290,25 +476,52 @@ extern "C" int ick_gemm(const ick_gemm_args* in, void* stream) {
     }
     if (bkm) bvec = aligned16(a.B) && a.b_ks % 4 == 0 && a.N % 4 == 0;
     else bvec = aligned16(a.B) && a.b_rs % 4 == 0 && a.K % 4 == 0;
-    a.flags = (a.flags & 0xff) | (avec ? 0x100 : 0) | (bvec ? 0x200 : 0);
+    const bool vec = avec && bvec;
+    const bool split_one = a.split_k <= 1;
+    a.flags &= 0xff;
     hipStream_t s = (hipStream_t)stream;
 
     // Tile selection: 64x64 per wave on large problems; N<=320 keeps 4 waves stacked along M so a
     // 300-wide output costs 5 x 64 columns instead of 3 x 128; small problems use small tiles so
     // that enough workgroups exist to cover the 256 CUs.
+    // chain GEMMs (short K, k-contiguous operands, not enough work to fill the chip with 64x64 wave
+    // tiles): K-resident 32x32 tiles, one memory round trip per workgroup
+    if (vec && !akm && !bkm && a.K <= 304 && split_one && !(a.flags & ICK_GEMM_ATOMIC) && !getenv("ICK_GEMM_TILE") &&
+        (int64_t)a.M * a.N <= (int64_t)1280 * 320) {
+        const int KP = ceil_div(a.K, 16) * 16;
+        const int nload = ceil_div(64 * (KP / 4), 256);
+        if (nload <= 20) return launch_kres<20>(a, KP, s);
+        return launch_kres<33>(a, KP, s);
+    }
     const int64_t tiles_big = (int64_t)ceil_div(a.M, 128) * ceil_div(a.N, 128);
     const int64_t work = (int64_t)a.M * a.N;
-#define ICK_DISPATCH(WM, WN, TM, TN)                                            \
-    do {                                                                        \
-        if (!akm && !bkm) return launch<WM, WN, TM, TN, false, false>(a, s);    \
-        if (akm && !bkm) return launch<WM, WN, TM, TN, true, false>(a, s);      \
-        if (!akm && bkm) return launch<WM, WN, TM, TN, false, true>(a, s);      \
-        return launch<WM, WN, TM, TN, true, true>(a, s);                        \
+#define ICK_DISPATCH(WM, WN, TM, TN)                                                  \
+    do {                                                                              \
+        if (!akm && !bkm) return launch<WM, WN, TM, TN, false, false, true>(a, s);    \
+        if (akm && !bkm) return launch<WM, WN, TM, TN, true, false, true>(a, s);      \
+        if (!akm && bkm) return launch<WM, WN, TM, TN, false, true, true>(a, s);      \
+        return launch<WM, WN, TM, TN, true, true, true>(a, s);                        \
     } while (0)
-    if (work >= (int64_t)256 * 128 * 128 && a.N > 320) ICK_DISPATCH(2, 2, 4, 4);   // 128 x 128
-    if (work >= (int64_t)200 * 256 * 64) ICK_DISPATCH(4, 1, 4, 4);                  // 256 x 64
-    if (tiles_big >= 96) ICK_DISPATCH(2, 2, 4, 4);
-    if (work >= (int64_t)256 * 64 * 64) ICK_DISPATCH(2, 2, 2, 2);                   // 64 x 64
-    ICK_DISPATCH(2, 2, 1, 1);                                                       // 32 x 32
+    if (!vec) {  // ragged / unaligned operands: element-wise staging, one medium tile shape
+        if (!akm && !bkm) return launch<2, 2, 2, 2, false, false, false>(a, s);
+        if (akm && !bkm) return launch<2, 2, 2, 2, true, false, false>(a, s);
+        if (!akm && bkm) return launch<2, 2, 2, 2, false, true, false>(a, s);
+        return launch<2, 2, 2, 2, true, true, false>(a, s);
+    }
+    {   // experiment hook: ICK_GEMM_TILE=<id> forces a tile shape (0: 256x64, 1: 128x128, 2: 64x64, 3: 32x32, 4: 128x64)
+        static int forced = -2;
+        if (forced == -2) { const char* e = getenv("ICK_GEMM_TILE"); forced = e ? atoi(e) : -1; }
+        if (forced == 0) ICK_DISPATCH(4, 1, 4, 4);
+        if (forced == 1) ICK_DISPATCH(2, 2, 4, 4);
+        if (forced == 2) ICK_DISPATCH(2, 2, 2, 2);
+        if (forced == 3) ICK_DISPATCH(2, 2, 1, 1);
+        if (forced == 4) ICK_DISPATCH(2, 2, 4, 2);
+    }
+    // Measured on MI355X (tools/probes/probe_ops, profiles/r01_*): with exact-fp32 MFMA a 64x64 wave tile
+    // alone needs ~18 us for K = 300, so latency and occupancy favour 64x64 workgroup tiles (32x32 per
+    // wave, 4+ waves per SIMD) on every shape of this path; larger tiles stay available for experiments.
+    (void)tiles_big;
+    if (work >= (int64_t)64 * 64 * 16) ICK_DISPATCH(2, 2, 2, 2);   // 64 x 64 tiles
+    ICK_DISPATCH(2, 2, 1, 1);                                      // 32 x 32 tiles
 #undef ICK_DISPATCH
 }

@@ -21,15 +21,20 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
     if (row >= rows) return;
     const float* xr = x + row * x_ld;
     const float* rr = res ? res + row * res_ld : nullptr;
-    float v[kMaxPerLane];
+    float v[kMaxPerLane], g[kMaxPerLane], bt[kMaxPerLane];
     float sum = 0.f;
+    // every load of the row (x, residual, gamma, beta) is issued up front: one memory round trip
 #pragma unroll
     for (int j = 0; j < kMaxPerLane; ++j) {
         const int c = lane + 64 * j;
         float t = 0.f;
+        g[j] = 0.f;
+        bt[j] = 0.f;
         if (c < d) {
             t = xr[c];
             if (rr) t += rr[c];
+            g[j] = gamma[c];
+            bt[j] = beta[c];
         }
         v[j] = t;
         sum += t;
@@ -47,7 +52,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < kMaxPerLane; ++j) {
         const int c = lane + 64 * j;
-        if (c < d) yr[c] = (v[j] - mean) * rstd * gamma[c] + beta[c];
+        if (c < d) yr[c] = (v[j] - mean) * rstd * g[j] + bt[j];
     }
     if (save_mean && lane == 0) {
         save_mean[row] = mean;

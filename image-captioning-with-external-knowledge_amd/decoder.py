@@ -219,10 +219,10 @@ class DecoderTransformer(nn.Module):
         d = self.emb_dim
         B, T, _ = x.shape
         for layer in stack.layers:
-            qkv = ops.linear(x, layer.self_attn.in_proj_weight.detach(), layer.self_attn.in_proj_bias.detach())
+            qkv = ops.project_heads(x, layer.self_attn.in_proj_weight.detach(), layer.self_attn.in_proj_bias.detach(),
+                                    3, H, T)
             sa = torch.empty_like(x)
-            ops.attention_raw(qkv, qkv, qkv, sa, B, H, T, T, d // H, T * 3 * d, 3 * d, T * 3 * d, 3 * d, d // H,
-                              T * 3 * d, 3 * d, d // H, T * d, d, k_off=d, v_off=2 * d)
+            ops.attention_heads(qkv, qkv, sa, H, d // H, T, T, q_seg=0, k_seg=1, v_seg=2)
             o = ops.linear(sa, layer.self_attn.out_proj.weight.detach(), layer.self_attn.out_proj.bias.detach())
             x = ops.add_layernorm(o, x, layer.norm1.weight.detach(), layer.norm1.bias.detach(), layer.norm1.eps)
             f = ops.linear(x, layer.linear1.weight.detach(), layer.linear1.bias.detach(), relu=True)
@@ -232,8 +232,11 @@ class DecoderTransformer(nn.Module):
 
     def _encode_context(self, enc_tok, entities, facts, gmap):
         """Entity / fact encoders, context transformers and the all-layer cross K/V projection.
-        Returns (entities_encoded, facts_encoded, kv (B, S, N*2d))."""
+        Returns (entities_encoded, facts_encoded, kv, contexts); kv is head-major
+        (B, 2*layers, H, S, 32): segment 2i = keys of decoder layer i, 2i+1 = its values, over the
+        memory rows [196 image positions ; entity rows ; fact rows]."""
         d = self.emb_dim
+        H = self.num_heads
         B, P, _ = enc_tok.shape
         K = entities.shape[1]
         ee = ops.entity_encode(self.variant, entities, self.entity_encoder.type_embedding.weight.detach(), d,
@@ -247,43 +250,37 @@ class DecoderTransformer(nn.Module):
         ctx_e = self._context_encoder(self.transformer_encoder_entities, ee)
         ctx_f = self._context_encoder(self.transformer_encoder_facts, fe) if self.has_facts else None
         wkv, bkv = self._packed_cross_kv()
-        N2 = wkv.shape[0]
+        nseg = wkv.shape[0] // d
         S = P + K + Fn
-        kv = torch.empty(B, S, N2, device=enc_tok.device, dtype=torch.float32)
+        kv = torch.empty(B, nseg, H, S, ops.DHP, device=enc_tok.device, dtype=torch.float32)
         # image rows (gathered through gmap = sort order), then entity and fact context rows
-        ops.gemm_raw(enc_tok, wkv, kv, B * P, N2, d, d, 1, d, 1, N2, bias=bkv, a_grp=P, a_gs=enc_tok.stride(0),
-                     a_gmap=gmap, c_grp=P, c_gs=S * N2)
-        ops.gemm_raw(ctx_e, wkv, kv[:, P:], B * K, N2, d, d, 1, d, 1, N2, bias=bkv, c_grp=K, c_gs=S * N2)
+        ops.project_heads(enc_tok, wkv, bkv, nseg, H, S, out=kv, s0=0, grp=P, a_gmap=gmap, a_gs=enc_tok.stride(0))
+        ops.project_heads(ctx_e, wkv, bkv, nseg, H, S, out=kv, s0=P, grp=K)
         if self.has_facts:
-            ops.gemm_raw(ctx_f, wkv, kv[:, P + K:], B * Fn, N2, d, d, 1, d, 1, N2, bias=bkv, c_grp=Fn, c_gs=S * N2)
+            ops.project_heads(ctx_f, wkv, bkv, nseg, H, S, out=kv, s0=P + K, grp=Fn)
         return ee, fe, kv, (ctx_e, ctx_f)
 
-    def _decoder_layer(self, li, layer, x, kv, S, qkv_buf=None, pos=None, kv_len=None):
-        """One post-LN decoder layer on x (B, T, d).  With qkv_buf (B, max_len, 3d) the layer runs one
-        KV-cached decode step: the new q|k|v row is written at position `pos` and attends to [0, pos]."""
+    def _decoder_layer(self, li, layer, x, kv, S, qkv_buf=None, pos=None):
+        """One post-LN decoder layer on x (B, T, d).  With qkv_buf (B, 3, H, max_len, 32) the layer runs
+        one KV-cached decode step: the new q|k|v row is written at position `pos` and attends to [0, pos]."""
         H, d = self.num_heads, self.emb_dim
         dh = d // H
         B, T, _ = x.shape
-        N2 = kv.shape[2]
         sa_w, sa_b = layer.self_attn.in_proj_weight.detach(), layer.self_attn.in_proj_bias.detach()
         sa = torch.empty_like(x)
         if qkv_buf is None:
-            qkv = ops.linear(x, sa_w, sa_b)
-            ops.attention_raw(qkv, qkv, qkv, sa, B, H, T, T, dh, T * 3 * d, 3 * d, T * 3 * d, 3 * d, dh, T * 3 * d,
-                              3 * d, dh, T * d, d, causal=True, k_off=d, v_off=2 * d)
+            qkv = ops.project_heads(x, sa_w, sa_b, 3, H, T)
+            ops.attention_heads(qkv, qkv, sa, H, dh, T, T, q_seg=0, k_seg=1, v_seg=2, causal=True)
         else:
-            ML = qkv_buf.shape[1]
-            row = qkv_buf[:, pos]
-            ops.gemm_raw(x, sa_w, row, B, 3 * d, d, d, 1, d, 1, 3 * d, bias=sa_b, c_grp=1, c_gs=ML * 3 * d)
-            ops.attention_raw(row, qkv_buf, qkv_buf, sa, B, H, 1, pos + 1, dh, ML * 3 * d, 3 * d, ML * 3 * d, 3 * d,
-                              dh, ML * 3 * d, 3 * d, dh, d, d, k_off=d, v_off=2 * d)
+            ML = qkv_buf.shape[3]
+            ops.project_heads(x, sa_w, sa_b, 3, H, ML, out=qkv_buf, s0=pos, grp=1)
+            ops.attention_heads(qkv_buf, qkv_buf, sa, H, dh, 1, pos + 1, q_seg=0, k_seg=1, v_seg=2, q_t0=pos)
         o = ops.linear(sa, layer.self_attn.out_proj.weight.detach(), layer.self_attn.out_proj.bias.detach())
         x = ops.add_layernorm(o, x, layer.norm1.weight.detach(), layer.norm1.bias.detach(), layer.norm1.eps)
         ca_w, ca_b = layer.multihead_attn.in_proj_weight.detach(), layer.multihead_attn.in_proj_bias.detach()
-        q = ops.linear(x, ca_w[:d], ca_b[:d])
+        q = ops.project_heads(x, ca_w[:d], ca_b[:d], 1, H, T)
         ca = torch.empty_like(x)
-        ops.attention_raw(q, kv, kv, ca, B, H, T, S, dh, T * d, d, S * N2, N2, dh, S * N2, N2, dh, T * d, d,
-                          k_off=li * 2 * d, v_off=li * 2 * d + d)
+        ops.attention_heads(q, kv, ca, H, dh, T, S, q_seg=0, k_seg=2 * li, v_seg=2 * li + 1)
         o = ops.linear(ca, layer.multihead_attn.out_proj.weight.detach(), layer.multihead_attn.out_proj.bias.detach())
         x = ops.add_layernorm(o, x, layer.norm2.weight.detach(), layer.norm2.bias.detach(), layer.norm2.eps)
         f = ops.linear(x, layer.linear1.weight.detach(), layer.linear1.bias.detach(), relu=True)
@@ -341,7 +338,7 @@ class DecoderTransformer(nn.Module):
         pe = self.pos_encoder.pe.view(-1, d)
         x, emb = ops.caption_embed(captions, caption_masks, self.word_embedding.weight.detach(), ee, fe, pe, V,
                                    self.word_map["<pad>"], math.sqrt(d), want_emb=True)
-        S = kv.shape[1]
+        S = kv.shape[3]
         for li, layer in enumerate(self.transformer_decoder.layers):
             x = self._decoder_layer(li, layer, x, kv, S)
         eib = gate = None
@@ -367,10 +364,11 @@ class DecoderTransformer(nn.Module):
         B = enc_tok.shape[0]
         d, V, K = self.emb_dim, self.vocab_size, entities.shape[1]
         ee, fe, kv, _ = self._encode_context(enc_tok, entities, facts, None)
-        S = kv.shape[1]
+        S = kv.shape[3]
         pe = self.pos_encoder.pe.view(-1, d)
         nl = len(self.transformer_decoder.layers)
-        qkv_cache = [torch.empty(B, max_pred_len, 3 * d, device=dev, dtype=torch.float32) for _ in range(nl)]
+        qkv_cache = [torch.empty(B, 3, self.num_heads, max_pred_len, ops.DHP, device=dev, dtype=torch.float32)
+                     for _ in range(nl)]
         output = torch.full((B, max_pred_len), self.word_map["<pad>"], dtype=torch.long, device=dev)
         hist = torch.zeros(B, max_pred_len, dtype=torch.int32, device=dev)
         finished = torch.zeros(B, dtype=torch.int32, device=dev)

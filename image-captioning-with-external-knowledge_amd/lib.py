@@ -27,6 +27,7 @@ class GemmArgs(C.Structure):
         ("b_rs", i64), ("b_ks", i64),
         ("c_rs", i64), ("c_grp", i32), ("c_gs", i64), ("c_gmap", vp),
         ("flags", i32), ("split_k", i32), ("alpha", f32),
+        ("hs_dh", i32), ("hs_dhp", i32), ("hs_H", i32), ("hs_S", i32), ("hs_s0", i32),
     ]
 
 
@@ -34,8 +35,8 @@ class AttnArgs(C.Structure):
     _fields_ = [
         ("Q", vp), ("K", vp), ("V", vp), ("O", vp), ("lse", vp),
         ("B", i32), ("H", i32), ("T", i32), ("S", i32), ("dh", i32),
-        ("q_bs", i64), ("q_ts", i64), ("k_bs", i64), ("k_ss", i64), ("k_hs", i64),
-        ("v_bs", i64), ("v_ss", i64), ("v_hs", i64), ("o_bs", i64), ("o_ts", i64),
+        ("q_bs", i64), ("q_hs", i64), ("q_ts", i64), ("k_bs", i64), ("k_hs", i64), ("k_ss", i64),
+        ("v_bs", i64), ("v_hs", i64), ("v_ss", i64), ("o_bs", i64), ("o_ts", i64),
         ("scale", f32), ("causal", i32), ("q_pos0", i32), ("kv_len", vp),
     ]
 

@@ -86,17 +86,20 @@ def add_layernorm(x, res, gamma, beta, eps=1e-5, out=None, save_stats=False):
     return (out, mean, rstd) if save_stats else out
 
 
-def attention_raw(Q, K, V, O, B, H, T, S, dh, q_bs, q_ts, k_bs, k_ss, k_hs, v_bs, v_ss, v_hs, o_bs, o_ts,
+def attention_raw(Q, K, V, O, B, H, T, S, dh, q_bs, q_hs, q_ts, k_bs, k_hs, k_ss, v_bs, v_hs, v_ss, o_bs, o_ts,
                   causal=False, q_pos0=0, kv_len=None, lse=None, q_off=0, k_off=0, v_off=0):
-    """Element offsets q_off/k_off/v_off select a column block inside a packed projection buffer."""
+    """Strides in elements: batch / head / row for Q, K, V (see include/ick_amd.h); q_off/k_off/v_off are
+    element offsets of the first (segment) inside a packed buffer."""
     a = L.AttnArgs()
     a.Q = Q.data_ptr() + 4 * q_off
     a.K = K.data_ptr() + 4 * k_off
     a.V = V.data_ptr() + 4 * v_off
     a.O, a.lse = _p(O), _p(lse)
     a.B, a.H, a.T, a.S, a.dh = B, H, T, S, dh
-    a.q_bs, a.q_ts, a.k_bs, a.k_ss, a.k_hs = q_bs, q_ts, k_bs, k_ss, k_hs
-    a.v_bs, a.v_ss, a.v_hs, a.o_bs, a.o_ts = v_bs, v_ss, v_hs, o_bs, o_ts
+    a.q_bs, a.q_hs, a.q_ts = q_bs, q_hs, q_ts
+    a.k_bs, a.k_hs, a.k_ss = k_bs, k_hs, k_ss
+    a.v_bs, a.v_hs, a.v_ss = v_bs, v_hs, v_ss
+    a.o_bs, a.o_ts = o_bs, o_ts
     a.scale = 1.0 / math.sqrt(dh)
     a.causal, a.q_pos0, a.kv_len = int(causal), q_pos0, _p(kv_len)
     L.check(L.load().ick_attention(C.byref(a), _stream()), "ick_attention")
@@ -104,14 +107,55 @@ def attention_raw(Q, K, V, O, B, H, T, S, dh, q_bs, q_ts, k_bs, k_ss, k_hs, v_bs
 
 
 def attention(q, k, v, H, causal=False):
-    """q (B,T,d), k/v (B,S,d) contiguous -> (B,T,d)."""
+    """q (B,T,d), k/v (B,S,d) row-major -> (B,T,d)."""
     B, T, d = q.shape
     S = k.shape[1]
     dh = d // H
     out = torch.empty_like(q)
-    attention_raw(q, k, v, out, B, H, T, S, dh, q.stride(0), q.stride(1), k.stride(0), k.stride(1), dh,
-                  v.stride(0), v.stride(1), dh, out.stride(0), out.stride(1), causal=causal)
+    attention_raw(q, k, v, out, B, H, T, S, dh, q.stride(0), dh, q.stride(1), k.stride(0), dh, k.stride(1),
+                  v.stride(0), dh, v.stride(1), out.stride(0), out.stride(1), causal=causal)
     return out
+
+
+DHP = 32  # padded head width of the head-major projection buffers
+
+
+def project_heads(x, w, bias, nseg, H, S, out=None, s0=0, grp=None, a_gmap=None, a_gs=None):
+    """Packed projection x (B*grp rows, K) @ w.T (nseg*d, K) scattered into the head-major layout
+    out (B, nseg, H, S, DHP) at positions s0 .. s0+grp-1 (ick_gemm head-split epilogue)."""
+    d = w.shape[0] // nseg
+    K = w.shape[1]
+    x2 = x.reshape(-1, K)
+    M = x2.shape[0]
+    grp = grp if grp is not None else (x.shape[1] if x.dim() == 3 else M)
+    Bn = M // grp
+    if out is None:
+        out = torch.empty(Bn, nseg, H, S, DHP, device=x.device, dtype=torch.float32)
+    a = L.GemmArgs()
+    a.A, a.B, a.C, a.bias = _p(x2), _p(w), _p(out), _p(bias)
+    a.M, a.N, a.K = M, w.shape[0], K
+    a.a_rs, a.a_ks = x2.stride(0), 1
+    if a_gmap is not None:
+        a.a_grp, a.a_gs, a.a_gmap = grp, a_gs, _p(a_gmap)
+    a.b_rs, a.b_ks = w.stride(0), 1
+    a.c_rs, a.c_grp, a.c_gs = 0, grp, out.stride(0)
+    a.split_k, a.alpha = 1, 1.0
+    a.hs_dh, a.hs_dhp, a.hs_H, a.hs_S, a.hs_s0 = d // H, DHP, H, S, s0
+    L.check(L.load().ick_gemm(C.byref(a), _stream()), "ick_gemm(head-split)")
+    return out
+
+
+def attention_heads(q, kv, O, H, dh, T, S, q_seg=0, k_seg=0, v_seg=1, causal=False, kv_len=None, q_pos0=0, q_t0=0,
+                    lse=None):
+    """Attention over head-major buffers: q (B, nq, H, Tq_alloc, DHP), kv (B, nkv, H, S_alloc, DHP);
+    the first T query rows starting at q_t0 attend to the first S key rows."""
+    B = q.shape[0]
+    Tq, Sa = q.shape[3], kv.shape[3]
+    attention_raw(q, kv, kv, O, B, H, T, S, dh,
+                  q.stride(0), Tq * DHP, DHP, kv.stride(0), Sa * DHP, DHP, kv.stride(0), Sa * DHP, DHP,
+                  O.stride(0), O.stride(1), causal=causal, q_pos0=q_pos0, kv_len=kv_len, lse=lse,
+                  q_off=q_seg * H * Tq * DHP + q_t0 * DHP, k_off=k_seg * H * Sa * DHP, v_off=v_seg * H * Sa * DHP)
+    return O
 
 
 def entity_encode(variant, entities, type_emb, d, facts=None, word_emb=None):

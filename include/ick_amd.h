@@ -47,6 +47,11 @@ int ick_device_info(int* num_cu, int* wave_size, char* arch_name, int arch_name_
  *   C + (c_gmap ? c_gmap[m / c_grp] : m / c_grp) * c_gs + (m % c_grp) * c_rs.
  * Exactly one of (a_rs, a_ks) and one of (b_rs, b_ks) must be 1.
  * flags: bit0 = ReLU, bit1 = accumulate into C (C += ...), bit2 = atomic accumulate (split-K).
+ * Head-split epilogue (hs_dh > 0): the N columns are [segment][head][hs_dh] (packed q|k|v or
+ * k|v-per-layer projections) and are scattered into the attention kernel's head-major layout
+ *   C[ goff(m) + seg*(hs_H*hs_S*hs_dhp) + head*(hs_S*hs_dhp) + (hs_s0 + m % c_grp)*hs_dhp + j ]
+ * i.e. per sample [segment][head][position][hs_dhp] with rows padded to hs_dhp floats (pad columns
+ * are not written).  c_rs is ignored in this mode.
  */
 typedef struct {
     const float* A; const float* B; float* C; const float* bias;
@@ -57,6 +62,7 @@ typedef struct {
     int32_t flags;
     int32_t split_k;       /* >1: K is split over blockIdx.z, partial sums added atomically */
     float   alpha;         /* scales the product before bias (1.0f normally) */
+    int32_t hs_dh, hs_dhp, hs_H, hs_S, hs_s0;   /* head-split epilogue, see above (hs_dh == 0: off) */
 } ick_gemm_args;
 
 #define ICK_GEMM_RELU 1
@@ -75,8 +81,10 @@ int ick_add_layernorm(const float* x, const float* res, const float* gamma, cons
                       float* save_mean, float* save_rstd, void* stream);
 
 /* Multi-head attention core: O = softmax(Q K^T * scale [+ causal mask]) V per (batch, head).
- * Q element (b,t,h,j) at Q[b*q_bs + t*q_ts + h*dh + j]; K/V element (b,s,h,j) at
- * K[b*k_bs + s*k_ss + h*k_hs + j]; O like Q with o_bs/o_ts.  kv_len (optional, int32[B]) limits
+ * Q element (b,t,h,j) at Q[b*q_bs + h*q_hs + t*q_ts + j]; K/V element (b,s,h,j) at
+ * K[b*k_bs + h*k_hs + s*k_ss + j]; O element at O[b*o_bs + t*o_ts + h*dh + j] (row-major rows for the
+ * output projection).  The head-major padded layout written by ick_gemm's head-split epilogue
+ * (q_ts == k_ss == v_ss == 32, 16-byte aligned) takes the vectorised path.  kv_len (optional, int32[B]) limits
  * the keys of sample b to s < kv_len[b] (KV-cached greedy decode); q_pos0 is the absolute
  * position of query row 0 for the causal mask (key s visible iff s <= q_pos0 + t).
  * Replaces the scaled-dot-product core of nn.MultiheadAttention for
@@ -86,7 +94,7 @@ int ick_add_layernorm(const float* x, const float* res, const float* gamma, cons
 typedef struct {
     const float* Q; const float* K; const float* V; float* O; float* lse;
     int32_t B, H, T, S, dh;
-    int64_t q_bs, q_ts, k_bs, k_ss, k_hs, v_bs, v_ss, v_hs, o_bs, o_ts;
+    int64_t q_bs, q_hs, q_ts, k_bs, k_hs, k_ss, v_bs, v_hs, v_ss, o_bs, o_ts;
     float scale; int32_t causal; int32_t q_pos0; const int32_t* kv_len;
 } ick_attn_args;
 int ick_attention(const ick_attn_args* args, void* stream);

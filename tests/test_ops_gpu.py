@@ -173,7 +173,7 @@ def test_attention_packed_kv_len_and_lse(ops):
     out = torch.empty(B, T, d, device="cuda")
     lse = torch.empty(B * H * T, device="cuda")
     dq, dc = dev(qkv), dev(cache)
-    ops.attention_raw(dq, dc, dc, out, B, H, T, S, dh, 3 * d, 3 * d, S * 2 * d, 2 * d, dh, S * 2 * d, 2 * d, dh,
+    ops.attention_raw(dq, dc, dc, out, B, H, T, S, dh, 3 * d, dh, 3 * d, S * 2 * d, dh, 2 * d, S * 2 * d, dh, 2 * d,
                       d, d, causal=False, kv_len=dev(kv_len), lse=lse, v_off=d)
     ref = ref_attention(qkv[:, :, :d], cache[:, :, :d], cache[:, :, d:], H, False, kv_len.long())
     close(out, ref, 3e-6, "attention kv_len")
@@ -182,6 +182,43 @@ def test_attention_packed_kv_len_and_lse(ops):
     att = qq @ kk.transpose(-1, -2) / math.sqrt(dh)
     att = att.masked_fill(torch.arange(S).view(1, 1, 1, S) >= kv_len.long().view(B, 1, 1, 1), float("-inf"))
     close(lse.view(B, H, T), att.logsumexp(-1), 3e-6, "lse")
+
+
+def test_head_split_projection_and_head_major_attention(ops):
+    """ick_gemm's head-split epilogue + the vectorised attention path == row-major math, including the
+    KV-cache form (rows appended at a position, queries read at an offset)."""
+    B, T, S, H, d = 3, 20, 216, 10, 300
+    dh = d // H
+    x, mem = rnd(B, T, d, seed=1), rnd(B, S, d, seed=2)
+    wq, bq = rnd(d, d, seed=3, scale=0.1), rnd(d, seed=4)
+    wkv, bkv = rnd(4 * d, d, seed=5, scale=0.1), rnd(4 * d, seed=6)   # two layers' [K;V]
+    q = ops.project_heads(dev(x), dev(wq), dev(bq), 1, H, T)
+    kv = torch.full((B, 4, H, S, ops.DHP), float("nan"), device="cuda")     # pads stay NaN: must be masked
+    ops.project_heads(dev(mem[:, :200].contiguous()), dev(wkv), dev(bkv), 4, H, S, out=kv, s0=0, grp=200)
+    ops.project_heads(dev(mem[:, 200:].contiguous()), dev(wkv), dev(bkv), 4, H, S, out=kv, s0=200, grp=S - 200)
+    qr = x.double() @ wq.double().t() + bq.double()
+    kvr = mem.double() @ wkv.double().t() + bkv.double()
+    got = kv[:, :, :, :, :dh].permute(0, 3, 1, 2, 4).reshape(B, S, 4 * d)
+    close(got, kvr, 2e-5, "head-split kv")
+    for layer in (0, 1):
+        out = torch.empty(B, T, d, device="cuda")
+        ops.attention_heads(q, kv, out, H, dh, T, S, q_seg=0, k_seg=2 * layer, v_seg=2 * layer + 1)
+        ref = ref_attention(qr.float(), kvr[:, :, 2 * layer * d:(2 * layer + 1) * d].float(),
+                            kvr[:, :, (2 * layer + 1) * d:(2 * layer + 2) * d].float(), H, False)
+        close(out, ref, 5e-6, "head-major attention layer %d" % layer)
+    # KV-cache form: position 7 of a (B, 3, H, 12, 32) cache, attends to keys 0..7
+    ML, pos = 12, 7
+    w3, b3 = rnd(3 * d, d, seed=7, scale=0.1), rnd(3 * d, seed=8)
+    xs = rnd(B, ML, d, seed=9)
+    cache = torch.full((B, 3, H, ML, ops.DHP), float("nan"), device="cuda")
+    for i in range(pos + 1):
+        ops.project_heads(dev(xs[:, i:i + 1].contiguous()), dev(w3), dev(b3), 3, H, ML, out=cache, s0=i, grp=1)
+    out = torch.empty(B, 1, d, device="cuda")
+    ops.attention_heads(cache, cache, out, H, dh, 1, pos + 1, q_seg=0, k_seg=1, v_seg=2, q_t0=pos)
+    pr = xs.double() @ w3.double().t() + b3.double()
+    ref = ref_attention(pr[:, pos:pos + 1, :d].float(), pr[:, :pos + 1, d:2 * d].float(),
+                        pr[:, :pos + 1, 2 * d:].float(), H, False)
+    close(out, ref, 5e-6, "cached step")
 
 
 # -------------------------------------------------------------------------------------- prefill

@@ -1,0 +1,79 @@
+// Back-to-back timing of libick_amd.so entry points from C++ (no Python launch overhead).
+// Usage: probe_ops [iters]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "ick_amd.h"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+static hipStream_t st;
+template <typename F> float timeit(F f, int iters) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 10; ++i) f();
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) f();
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1000.f / iters;
+}
+
+int main(int argc, char** argv) {
+    int iters = argc > 1 ? atoi(argv[1]) : 200;
+    CK(hipStreamCreate(&st));
+    float *A, *B, *C, *bias;
+    size_t na = (size_t)64 * 2048 * 196, nb = (size_t)64 * 6 * 10 * 256 * 32 /* >= KV of 64 samples */, nc = (size_t)13824 * 2048;
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    CK(hipMalloc(&A, na * 4)); CK(hipMalloc(&B, nb * 4)); CK(hipMalloc(&C, nc * 4)); CK(hipMalloc(&bias, 65536));
+    std::vector<float> h(na);
+    for (size_t i = 0; i < na; ++i) h[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
+    CK(hipMemcpy(A, h.data(), na * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(B, h.data(), std::min(na, nb) * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(bias, 0, 65536));
+    auto gemm = [&](const char* name, int M, int N, int K, bool feat, int hs) {
+        ick_gemm_args a; memset(&a, 0, sizeof(a));
+        a.A = A; a.B = B; a.C = C; a.bias = bias; a.M = M; a.N = N; a.K = K; a.alpha = 1.f; a.split_k = 1;
+        if (feat) { a.a_rs = 1; a.a_ks = 196; a.a_grp = 196; a.a_gs = (int64_t)K * 196; }
+        else { a.a_rs = K; a.a_ks = 1; }
+        a.b_rs = K; a.b_ks = 1; a.c_rs = N;
+        if (hs) { a.hs_dh = 30; a.hs_dhp = 32; a.hs_H = 10; a.hs_S = hs; a.hs_s0 = 0; a.c_grp = hs; a.c_gs = (int64_t)(N / 300) * 10 * hs * 32; }
+        int rc = ick_gemm(&a, st);
+        if (rc) { printf("%s rc=%d\n", name, rc); return; }
+        float us = timeit([&] { ick_gemm(&a, st); }, iters);
+        printf("%-28s M=%5d N=%5d K=%4d : %8.2f us  %6.1f TFLOP/s\n", name, M, N, K, us, 2.0 * M * N * K / us * 1e-6);
+    };
+    gemm("feat_proj (k-major A)", 12544, 300, 2048, true, 0);
+    gemm("cross KV image rows", 12544, 1800, 300, false, 196);
+    gemm("cross KV entity rows", 1280, 1800, 300, false, 20);
+    gemm("vocab", 1280, 10000, 300, false, 0);
+    gemm("qkv (head split)", 1280, 900, 300, false, 20);
+    gemm("q-proj (head split)", 1280, 300, 300, false, 20);
+    gemm("out-proj", 1280, 300, 300, false, 0);
+    gemm("ffn1", 1280, 512, 300, false, 0);
+    gemm("ffn2", 1280, 300, 512, false, 0);
+    gemm("decode-step qkv B=64", 64, 900, 300, false, 0);
+    gemm("decode-step vocab B=64", 64, 10000, 300, false, 0);
+    gemm("square 4096", 4096, 4096, 2048, false, 0);
+    // attention
+    float* Q = A; float* KV = B; float* O = C;
+    auto attn = [&](const char* name, int Bn, int T, int S, int causal) {
+        ick_attn_args a; memset(&a, 0, sizeof(a));
+        a.Q = Q; a.K = KV; a.V = KV + (size_t)10 * S * 32; a.O = O; a.B = Bn; a.H = 10; a.T = T; a.S = S; a.dh = 30;
+        a.q_bs = (int64_t)10 * T * 32; a.q_hs = T * 32; a.q_ts = 32;
+        a.k_bs = (int64_t)6 * 10 * S * 32; a.k_hs = S * 32; a.k_ss = 32; a.v_bs = a.k_bs; a.v_hs = a.k_hs; a.v_ss = 32;
+        a.o_bs = T * 300; a.o_ts = 300; a.scale = 0.18f; a.causal = causal;
+        int rc = ick_attention(&a, st);
+        if (rc) { printf("%s rc=%d\n", name, rc); return; }
+        float us = timeit([&] { ick_attention(&a, st); }, iters);
+        printf("%-28s B=%3d T=%3d S=%3d       : %8.2f us\n", name, Bn, T, S, us);
+    };
+    attn("cross attention", 64, 20, 216, 0);
+    attn("self attention", 64, 20, 20, 1);
+    attn("decode cross", 64, 1, 216, 0);
+    float us = timeit([&] { ick_add_layernorm(A, B, bias, bias, C, 1280, 300, 1e-5f, 300, 300, 300, nullptr, nullptr, st); }, iters);
+    printf("%-28s rows=1280               : %8.2f us\n", "add_layernorm", us);
+    return 0;
+}
