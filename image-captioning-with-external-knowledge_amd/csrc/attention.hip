@@ -183,6 +183,155 @@ int launch_attn(const ick_attn_args& a, hipStream_t s) {
     ICK_LAUNCH_RET();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward of the attention core (training step).  Inputs are the forward's head-major Q/K/V, its
+// row-major output O, the upstream gradient dO (row-major) and the saved log-sum-exp; outputs are
+// row-major gradients (the layout the weight/data-gradient GEMMs consume):
+//   P = exp(QK^T*scale - lse);  dV = P^T dO;  dP = dO V^T;  D = rowsum(dO*O)
+//   dS = P*(dP - D);  dQ = scale * dS K;  dK = scale * dS^T Q
+// One workgroup per (sample, head, query chunk).  Phase 1: lane <-> key keeps its K and V rows and
+// its dK / dV accumulators in registers while the queries stream from LDS; the scaled dS tile is
+// parked in LDS.  Phase 2: lane <-> (query, 4 columns) forms dQ from dS and the K tile in LDS.
+// ---------------------------------------------------------------------------------------------
+template <int DHP>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(ick_attn_bwd_args p, int TQ, int SLD) {
+    constexpr int VLD = DHP + 4;
+    constexpr int G = DHP / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int S = p.S, dh = p.dh;
+    float* Ks = smem;                  // S * VLD
+    float* Qs = Ks + S * VLD;          // TQ * DHP
+    float* Gs = Qs + TQ * DHP;         // TQ * DHP   (dO rows)
+    float* dS = Gs + TQ * DHP;         // TQ * SLD
+    float* Dl = dS + TQ * SLD;         // TQ  rowsum(dO * O)
+    float* Ls = Dl + TQ;               // TQ  lse
+
+    const int h = blockIdx.x, b = blockIdx.y, t0 = blockIdx.z * TQ;
+    const int nt = min(TQ, p.T - t0);
+    const int tid = threadIdx.x;
+    const bool multi = gridDim.z > 1;
+    const float* qb = p.Q + (int64_t)b * p.q_bs + (int64_t)h * p.q_hs + (int64_t)t0 * DHP;
+    const float* kb = p.K + (int64_t)b * p.k_bs + (int64_t)h * p.k_hs;
+    const float* vb = p.V + (int64_t)b * p.v_bs + (int64_t)h * p.v_hs;
+    const float* ob = p.O + (int64_t)b * p.o_bs + (int64_t)t0 * p.o_ts + h * dh;
+    const float* gb = p.dO + (int64_t)b * p.o_bs + (int64_t)t0 * p.o_ts + h * dh;
+
+    for (int f = tid; f < nt * G; f += 256) {
+        const int t = f / G, g = f % G;
+        float4 x = *reinterpret_cast<const float4*>(qb + (int64_t)t * DHP + 4 * g);
+        x.x = 4 * g + 0 < dh ? x.x : 0.f; x.y = 4 * g + 1 < dh ? x.y : 0.f;
+        x.z = 4 * g + 2 < dh ? x.z : 0.f; x.w = 4 * g + 3 < dh ? x.w : 0.f;
+        *reinterpret_cast<float4*>(Qs + t * DHP + 4 * g) = x;
+    }
+    for (int idx = tid; idx < nt * DHP; idx += 256) {
+        const int t = idx / DHP, j = idx % DHP;
+        Gs[idx] = j < dh ? gb[(int64_t)t * p.o_ts + j] : 0.f;
+    }
+    for (int f = tid; f < S * G; f += 256) {
+        const int s = f / G, g = f % G;
+        float4 x = *reinterpret_cast<const float4*>(kb + (int64_t)s * DHP + 4 * g);
+        x.x = 4 * g + 0 < dh ? x.x : 0.f; x.y = 4 * g + 1 < dh ? x.y : 0.f;
+        x.z = 4 * g + 2 < dh ? x.z : 0.f; x.w = 4 * g + 3 < dh ? x.w : 0.f;
+        *reinterpret_cast<float4*>(Ks + s * VLD + 4 * g) = x;
+    }
+    if (tid < nt) {
+        float dsum = 0.f;
+        for (int j = 0; j < dh; ++j) dsum = fmaf(gb[(int64_t)tid * p.o_ts + j], ob[(int64_t)tid * p.o_ts + j], dsum);
+        Dl[tid] = dsum;
+        Ls[tid] = p.lse[((int64_t)b * p.H + h) * p.T + t0 + tid];
+    }
+    __syncthreads();
+
+    for (int s = tid; s < S; s += 256) {
+        float kreg[DHP], vreg[DHP], dk[DHP], dv[DHP];
+        const float4* vr = reinterpret_cast<const float4*>(vb + (int64_t)s * DHP);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float4 kx = *reinterpret_cast<const float4*>(Ks + s * VLD + 4 * g);
+            const float4 vx = vr[g];
+            kreg[4 * g + 0] = kx.x; kreg[4 * g + 1] = kx.y; kreg[4 * g + 2] = kx.z; kreg[4 * g + 3] = kx.w;
+            vreg[4 * g + 0] = 4 * g + 0 < dh ? vx.x : 0.f; vreg[4 * g + 1] = 4 * g + 1 < dh ? vx.y : 0.f;
+            vreg[4 * g + 2] = 4 * g + 2 < dh ? vx.z : 0.f; vreg[4 * g + 3] = 4 * g + 3 < dh ? vx.w : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < DHP; ++j) { dk[j] = 0.f; dv[j] = 0.f; }
+        for (int t = 0; t < nt; ++t) {
+            float sc = 0.f, dp = 0.f;
+            float q[DHP], g[DHP];
+#pragma unroll
+            for (int j4 = 0; j4 < G; ++j4) {
+                const float4 qx = *reinterpret_cast<const float4*>(Qs + t * DHP + 4 * j4);
+                const float4 gx = *reinterpret_cast<const float4*>(Gs + t * DHP + 4 * j4);
+                q[4 * j4 + 0] = qx.x; q[4 * j4 + 1] = qx.y; q[4 * j4 + 2] = qx.z; q[4 * j4 + 3] = qx.w;
+                g[4 * j4 + 0] = gx.x; g[4 * j4 + 1] = gx.y; g[4 * j4 + 2] = gx.z; g[4 * j4 + 3] = gx.w;
+            }
+#pragma unroll
+            for (int j = 0; j < DHP; ++j) {
+                sc = fmaf(q[j], kreg[j], sc);
+                dp = fmaf(g[j], vreg[j], dp);
+            }
+            float pr = __expf(sc * p.scale - Ls[t]);
+            if (p.causal && s > p.q_pos0 + t0 + t) pr = 0.f;
+            const float ds = pr * (dp - Dl[t]) * p.scale;
+#pragma unroll
+            for (int j = 0; j < DHP; ++j) {
+                dv[j] = fmaf(pr, g[j], dv[j]);
+                dk[j] = fmaf(ds, q[j], dk[j]);
+            }
+            dS[t * SLD + s] = ds;
+        }
+        float* dkr = p.dK + (int64_t)b * p.dk_bs + (int64_t)s * p.dk_ss + h * dh;
+        float* dvr = p.dV + (int64_t)b * p.dv_bs + (int64_t)s * p.dv_ss + h * dh;
+        if (multi) {
+            for (int j = 0; j < dh; ++j) { atomicAdd(dkr + j, dk[j]); atomicAdd(dvr + j, dv[j]); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < DHP; ++j)
+                if (j < dh) { dkr[j] = dk[j]; dvr[j] = dv[j]; }
+        }
+    }
+    __syncthreads();
+
+    for (int idx = tid; idx < nt * G; idx += 256) {
+        const int t = idx / G, g = idx % G;
+        const float* dr = dS + t * SLD;
+        const float* kc = Ks + 4 * g;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int s = 0; s < S; ++s) {
+            const float d = dr[s];
+            const float4 kx = *reinterpret_cast<const float4*>(kc + s * VLD);
+            o.x = fmaf(d, kx.x, o.x); o.y = fmaf(d, kx.y, o.y); o.z = fmaf(d, kx.z, o.z); o.w = fmaf(d, kx.w, o.w);
+        }
+        float* dq = p.dQ + (int64_t)b * p.dq_bs + (int64_t)(t0 + t) * p.dq_ts + h * dh;
+        const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (4 * g + q < dh) dq[4 * g + q] = ov[q];
+    }
+}
+
+template <int DHP>
+int launch_attn_bwd(const ick_attn_bwd_args& a, hipStream_t s) {
+    constexpr int VLD = DHP + 4;
+    const int SLD = a.S | 1;
+    const size_t fixed = (size_t)a.S * VLD;
+    int TQ = a.T;
+    const size_t budget = 150 * 1024 / sizeof(float);
+    while (TQ > 1 && fixed + (size_t)TQ * (2 * DHP + SLD + 2) > budget) TQ = (TQ + 1) / 2;
+    const size_t fl = fixed + (size_t)TQ * (2 * DHP + SLD + 2);
+    if (fl > budget) return ICK_EINVAL;
+    auto kern = attn_bwd_kernel<DHP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.H, a.B, ceil_div(a.T, TQ)), dim3(256), fl * sizeof(float), s, a, TQ, SLD);
+    ICK_LAUNCH_RET();
+}
+
 }  // namespace
 }  // namespace ick
 
@@ -196,4 +345,22 @@ extern "C" int ick_attention(const ick_attn_args* in, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (a.dh <= 32) return launch_attn<32>(a, s);
     return launch_attn<64>(a, s);
+}
+
+
+extern "C" int ick_attention_bwd(const ick_attn_bwd_args* in, void* stream) {
+    using namespace ick;
+    if (!in) return ICK_EINVAL;
+    const ick_attn_bwd_args& a = *in;
+    ICK_CHECK_ARG(a.Q && a.K && a.V && a.O && a.dO && a.lse && a.dQ && a.dK && a.dV);
+    ICK_CHECK_ARG(a.B > 0 && a.B <= 65535 && a.H > 0 && a.T > 0 && a.S > 0 && a.dh > 0 && a.dh <= 64);
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const int DHP = a.dh <= 32 ? 32 : 64;
+    // head-major padded operands only (what the training forward produces)
+    ICK_CHECK_ARG(a.q_ts == DHP && a.k_ss == DHP && a.v_ss == DHP && al16(a.Q) && al16(a.K) && al16(a.V));
+    ICK_CHECK_ARG(a.q_bs % 4 == 0 && a.q_hs % 4 == 0 && a.k_bs % 4 == 0 && a.k_hs % 4 == 0 && a.v_bs % 4 == 0 &&
+                  a.v_hs % 4 == 0);
+    hipStream_t s = (hipStream_t)stream;
+    if (DHP == 32) return launch_attn_bwd<32>(a, s);
+    return launch_attn_bwd<64>(a, s);
 }

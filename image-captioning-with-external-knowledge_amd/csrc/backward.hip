@@ -1,0 +1,435 @@
+// Backward kernels of the training step (loss.backward() through the
+// decoder of geo-aware/train.py:282-292, then clip_gradient + Adam.step).  The GEMM-shaped
+// gradients (data / weight gradients of every Linear) reuse ick_gemm with k-major operands; this
+// file holds the rest: LayerNorm, ReLU mask, bias column sums, the gather/scatter backward of the
+// embedding and encoder stages, the pointer-score head, the predicate gate, and the fused
+// clamp + Adam update.
+#include "common.h"
+
+namespace ick {
+namespace {
+
+constexpr int kMaxPerLane = 16;
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm backward for y = LN(z) * gamma + beta with z = x + res (recomputed here):
+//   zh = (z - mean) * rstd;  g = dy * gamma
+//   dz = rstd * (g - mean_d(g) - zh * mean_d(g * zh));   dgamma += sum_rows dy * zh;  dbeta += sum_rows dy
+// One wave per row; per-workgroup partial dgamma/dbeta go through LDS, then one float atomic per
+// column per workgroup.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ res,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ dz,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int64_t rows, int d, int rows_per_block) {
+    extern __shared__ float sm[];  // 2 * d partial sums
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 2 * d; i += 256) sm[i] = 0.f;
+    __syncthreads();
+    float ag[kMaxPerLane], ab[kMaxPerLane], gm[kMaxPerLane];
+#pragma unroll
+    for (int j = 0; j < kMaxPerLane; ++j) {
+        const int c = lane + 64 * j;
+        ag[j] = 0.f; ab[j] = 0.f;
+        gm[j] = c < d ? gamma[c] : 0.f;
+    }
+    const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+    for (int r = wave; r < rows_per_block; r += 4) {
+        const int64_t row = row0 + r;
+        if (row >= rows) break;
+        const float mu = mean[row], rs = rstd[row];
+        float zh[kMaxPerLane], g[kMaxPerLane];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < kMaxPerLane; ++j) {
+            const int c = lane + 64 * j;
+            float z = 0.f, dyv = 0.f;
+            if (c < d) {
+                z = x[row * d + c];
+                if (res) z += res[row * d + c];
+                dyv = dy[row * d + c];
+            }
+            zh[j] = c < d ? (z - mu) * rs : 0.f;
+            g[j] = dyv * gm[j];
+            s1 += g[j];
+            s2 += g[j] * zh[j];
+            ag[j] += dyv * zh[j];
+            ab[j] += dyv;
+        }
+        s1 = wave_sum(s1) / (float)d;
+        s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+        for (int j = 0; j < kMaxPerLane; ++j) {
+            const int c = lane + 64 * j;
+            if (c < d) dz[row * d + c] = rs * (g[j] - s1 - zh[j] * s2);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kMaxPerLane; ++j) {
+        const int c = lane + 64 * j;
+        if (c < d) {
+            atomicAdd(&sm[c], ag[j]);
+            atomicAdd(&sm[d + c], ab[j]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < d; i += 256) {
+        atomicAdd(dgamma + i, sm[i]);
+        atomicAdd(dbeta + i, sm[d + i]);
+    }
+}
+
+// dpre = dpost where the forward activation was positive (ReLU), in place or out of place
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ act,
+                                                       float* __restrict__ dx, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dx[i] = act[i] > 0.f ? dy[i] : 0.f;
+}
+
+// out[n] += sum_m a[m, n]   (bias gradients).  grid (column blocks of 64, row slabs); each wave owns
+// 64 columns x a run of rows, waves of a workgroup are combined in LDS, slabs by float atomics.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, int64_t M, int N, int64_t ld,
+                                                     float* __restrict__ out, int rows_per_block) {
+    __shared__ float sm[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    if (c < N)
+        for (int64_t r = r0 + wave; r < r1; r += 4) s += a[r * ld + c];
+    sm[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < N) atomicAdd(out + c, sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// CaptionEmbedder backward: dx (B,L,d) * scale is added to the row each token was read from
+// (word embedding / encoded entity / encoded fact) -- mirrors ick_caption_embed's selection.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void caption_embed_bwd_kernel(const float* __restrict__ dx,
+                                                                const int64_t* __restrict__ captions,
+                                                                const int64_t* __restrict__ masks,
+                                                                float* __restrict__ dword, float* __restrict__ dee,
+                                                                float* __restrict__ dfe, int B, int L, int K, int F,
+                                                                int V, int d, int pad_token, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * L) return;
+    const int b = row / L;
+    const int64_t tok = captions[row];
+    const int64_t m = masks[row];
+    float* dst;
+    if (m == 1) {
+        int64_t ei = tok - V;
+        if (ei < 0 || ei >= K) ei = K - 1;
+        dst = dee + ((int64_t)b * K + ei) * d;
+    } else if (m == 2 && dfe != nullptr) {
+        int64_t fi = tok - V - K;
+        if (fi < 0 || fi >= F) fi = F - 1;
+        dst = dfe + ((int64_t)b * F + fi) * d;
+    } else {
+        if (dword == nullptr) return;
+        int64_t w = tok >= V ? (int64_t)pad_token : tok;
+        if (w < 0) w = pad_token;
+        dst = dword + w * d;
+    }
+    const float* src = dx + (int64_t)row * d;
+    for (int c = lane; c < d; c += 64) atomicAdd(dst + c, src[c] * scale);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pointer-score backward.  s[b,t,k] = ind * sum_d h*ctx*w + bias
+//   dh[b,t,:]   += sum_k ds*ind * ctx[b,k,:] * w        (one workgroup per (b,t))
+//   dctx[b,k,:] += sum_t ds*ind * h[b,t,:] * w          (one workgroup per (b,k))
+//   dw          += sum ds*ind * h * ctx ;  dbias += sum ds
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pointer_bwd_dh_kernel(const float* __restrict__ ds, int64_t ds_ld, int col0,
+                                                             const float* __restrict__ ctx, const float* __restrict__ w,
+                                                             const float* __restrict__ ind, float* __restrict__ dh,
+                                                             int T, int Kc, int d) {
+    const int b = blockIdx.y, t = blockIdx.x;
+    const float* dsr = ds + ((int64_t)b * T + t) * ds_ld + col0;
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float acc = 0.f;
+        for (int k = 0; k < Kc; ++k) {
+            float g = dsr[k];
+            if (ind) g *= ind[((int64_t)b * T + t) * Kc + k];
+            acc = fmaf(g, ctx[((int64_t)b * Kc + k) * d + c], acc);
+        }
+        dh[((int64_t)b * T + t) * d + c] += acc * w[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void pointer_bwd_dctx_kernel(const float* __restrict__ ds, int64_t ds_ld, int col0,
+                                                               const float* __restrict__ h, const float* __restrict__ ctx,
+                                                               const float* __restrict__ w, const float* __restrict__ ind,
+                                                               float* __restrict__ dctx, float* __restrict__ dw,
+                                                               float* __restrict__ dbias, int T, int Kc, int d) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, k = blockIdx.x;
+    float bsum = 0.f;
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t) {
+            float g = ds[((int64_t)b * T + t) * ds_ld + col0 + k];
+            if (ind) g *= ind[((int64_t)b * T + t) * Kc + k];
+            acc = fmaf(g, h[((int64_t)b * T + t) * d + c], acc);
+        }
+        dctx[((int64_t)b * Kc + k) * d + c] += acc * w[c];
+        atomicAdd(dw + c, acc * ctx[((int64_t)b * Kc + k) * d + c]);
+    }
+    if (threadIdx.x < T) bsum = ds[((int64_t)b * T + threadIdx.x) * ds_ld + col0 + k];
+    for (int t = threadIdx.x + 256; t < T; t += 256) bsum += ds[((int64_t)b * T + t) * ds_ld + col0 + k];
+    bsum = block_sum<4>(bsum, red);
+    if (threadIdx.x == 0) atomicAdd(dbias, bsum);
+}
+
+// EntityEncoder backward: only the type embedding is trainable (feature slots are inputs).  News:
+// e = enc * avg(name words)  =>  d enc = de * avg ; d word_emb[name_w] += de * enc / 5.
+__global__ __launch_bounds__(256) void entity_encode_bwd_kernel(int variant, const float* __restrict__ dee,
+                                                                const float* __restrict__ ent, int cols,
+                                                                const float* __restrict__ ee,
+                                                                const float* __restrict__ word_emb, int vocab,
+                                                                float* __restrict__ dtype_emb, int ntypes,
+                                                                float* __restrict__ dword, int B, int K, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * K) return;
+    const float* e = ent + (int64_t)row * cols;
+    const int type_off = variant == ICK_GEO ? 4 : (variant == ICK_KNOWLEDGE ? 6 : 5);
+    int ty = (int)e[4];
+    ty = ty < 0 ? 0 : (ty >= ntypes ? ntypes - 1 : ty);
+    int name[5] = {0, 0, 0, 0, 0};
+    if (variant == ICK_NEWS) {
+#pragma unroll
+        for (int w = 0; w < 5; ++w) {
+            int n = (int)e[5 + w];
+            name[w] = n < 0 ? 0 : (n >= vocab ? vocab - 1 : n);
+        }
+    }
+    for (int c = lane; c < d; c += 64) {
+        float g = dee[(int64_t)row * d + c];
+        if (variant == ICK_NEWS) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 5; ++w) s += word_emb[(int64_t)name[w] * d + c];
+            const float avg = s / 5.0f;
+            // enc = ee / avg is not recoverable when avg == 0; recompute enc's trainable part instead
+            const float enc_g = g * avg;                       // gradient wrt the un-scaled encoding
+            if (dword) {
+                // d avg = g * enc ; enc = ee / avg when avg != 0, and the product ee is what we stored
+                const float enc = avg != 0.f ? ee[(int64_t)row * d + c] / avg : 0.f;
+                const float gw = g * enc / 5.0f;
+#pragma unroll
+                for (int w = 0; w < 5; ++w) atomicAdd(dword + (int64_t)name[w] * d + c, gw);
+            }
+            g = enc_g;
+        }
+        if (c >= type_off) atomicAdd(dtype_emb + (int64_t)ty * (d - type_off) + (c - type_off), g);
+    }
+}
+
+// FactEncoder backward: f = ee[subject] + pred_emb[predicate]
+__global__ __launch_bounds__(256) void fact_encode_bwd_kernel(const float* __restrict__ dfe,
+                                                              const int64_t* __restrict__ facts, float* __restrict__ dee,
+                                                              float* __restrict__ dpred, int num_pred, int B, int K,
+                                                              int F, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * F) return;
+    const int b = row / F;
+    int subj = (int)facts[(int64_t)row * 3 + 1];
+    int pred = (int)facts[(int64_t)row * 3 + 2];
+    subj = subj < 0 ? 0 : (subj >= K ? K - 1 : subj);
+    pred = pred < 0 ? 0 : (pred >= num_pred ? num_pred - 1 : pred);
+    for (int c = lane; c < d; c += 64) {
+        const float g = dfe[(int64_t)row * d + c];
+        atomicAdd(dee + ((int64_t)b * K + subj) * d + c, g);
+        atomicAdd(dpred + (int64_t)pred * d + c, g);
+    }
+}
+
+// Predicate-gate backward (knowledge variants): gate[b,p,:] = bias + sum_{distinct active preds} W[:, pred]
+// => dW[:, pred] += sum over positions where pred is active of dgate[b,p,:];  dbias += sum dgate.
+// Same activation / representative logic as context_indicators_kernel (prefill.hip).
+constexpr int kInf = 0x3fffffff;
+__global__ __launch_bounds__(256) void context_gate_bwd_kernel(const int64_t* __restrict__ captions,
+                                                               const int64_t* __restrict__ facts,
+                                                               const float* __restrict__ dgate, float* __restrict__ dw,
+                                                               float* __restrict__ dbias, int L, int T, int K, int F,
+                                                               int V, int num_pred, int d, int mode) {
+    extern __shared__ int smi[];
+    int* first = smi;
+    int* act = first + K;
+    int* pred = act + F;
+    int* rep = pred + F;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int k = tid; k < K; k += 256) first[k] = kInf;
+    __syncthreads();
+    for (int t = tid; t < L; t += 256) {
+        const int64_t n = captions[(int64_t)b * L + t] - V;
+        if (n >= 0 && n < K) atomicMin(&first[(int)n], t);
+    }
+    __syncthreads();
+    for (int j = tid; j < F; j += 256) {
+        const int64_t subj = facts[((int64_t)b * F + j) * 3 + 1];
+        const int64_t q = facts[((int64_t)b * F + j) * 3 + 2];
+        int a = kInf;
+        if (subj >= 0 && subj < K && first[(int)subj] < kInf) a = mode == 0 ? first[(int)subj] + 1 : 0;
+        act[j] = a;
+        pred[j] = (q >= 0 && q < num_pred) ? (int)q : -1;
+    }
+    __syncthreads();
+    for (int j = tid; j < F; j += 256) {
+        int r = act[j] < kInf && pred[j] >= 0;
+        if (r)
+            for (int i = 0; i < F; ++i)
+                if (i != j && pred[i] == pred[j] && (act[i] < act[j] || (act[i] == act[j] && i < j))) { r = 0; break; }
+        rep[j] = r;
+    }
+    __syncthreads();
+    for (int c = tid; c < d; c += 256) {
+        // suffix sums of dgate over positions: a predicate active from position a gets sum_{p >= a}
+        float tot = 0.f;
+        for (int p = 0; p < T; ++p) tot += dgate[((int64_t)b * T + p) * d + c];
+        atomicAdd(dbias + c, tot);
+        for (int j = 0; j < F; ++j) {
+            if (!rep[j] || act[j] >= T) continue;
+            float s = 0.f;
+            for (int p = act[j]; p < T; ++p) s += dgate[((int64_t)b * T + p) * d + c];
+            atomicAdd(dw + (int64_t)c * num_pred + pred[j], s);  // fc_predicate.weight is (d, num_pred)
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// clip_gradient (geo-aware/utils.py:75-85) + torch.optim.Adam.step (default betas/eps, no weight
+// decay, no amsgrad) over one flat fp32 parameter bucket:
+//   g = clamp(g * gscale, -clip, clip);  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2
+//   p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_clamp_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                         float gscale, float clip, float lr, float b1, float b2,
+                                                         float eps, float bc1, float bc2_sqrt) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const float step = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float gi = g[i] * gscale;
+        if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+        g[i] = gi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, int64_t n, const float* __restrict__ num,
+                                                    const float* __restrict__ den) {
+    const float s = num[0] / den[0];
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) x[i] *= s;
+}
+
+}  // namespace
+}  // namespace ick
+
+using namespace ick;
+
+extern "C" int ick_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma,
+                                 const float* mean, const float* rstd, float* dz, float* dgamma, float* dbeta,
+                                 int64_t rows, int32_t d, void* stream) {
+    ICK_CHECK_ARG(dy && x && gamma && mean && rstd && dz && dgamma && dbeta && rows > 0 && d > 0 && d <= 1024);
+    const int rpb = 16;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(ceil_div(rows, rpb)), dim3(256), 2 * d * sizeof(float),
+                       (hipStream_t)stream, dy, x, res, gamma, mean, rstd, dz, dgamma, dbeta, rows, d, rpb);
+    ICK_LAUNCH_RET();
+}
+
+extern "C" int ick_relu_bwd(const float* dy, const float* act, float* dx, int64_t n, void* stream) {
+    ICK_CHECK_ARG(dy && act && dx && n > 0);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((int)std::min<int64_t>(ceil_div(n, 256), 2048)), dim3(256), 0,
+                       (hipStream_t)stream, dy, act, dx, n);
+    ICK_LAUNCH_RET();
+}
+
+extern "C" int ick_colsum(const float* a, int64_t M, int32_t N, int64_t ld, float* out, void* stream) {
+    ICK_CHECK_ARG(a && out && M > 0 && N > 0 && ld >= N);
+    const int rpb = 64;
+    ICK_CHECK_ARG(ceil_div(M, rpb) <= 65535);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64), ceil_div(M, rpb)), dim3(256), 0, (hipStream_t)stream, a, M,
+                       N, ld, out, rpb);
+    ICK_LAUNCH_RET();
+}
+
+extern "C" int ick_caption_embed_bwd(const float* dx, const int64_t* captions, const int64_t* masks, float* dword,
+                                     float* dee, float* dfe, int32_t B, int32_t L, int32_t K, int32_t F, int32_t V,
+                                     int32_t d, int32_t pad_token, float scale, void* stream) {
+    ICK_CHECK_ARG(dx && captions && masks && dee && B > 0 && L > 0 && K > 0 && d > 0);
+    hipLaunchKernelGGL(caption_embed_bwd_kernel, dim3(ceil_div((int64_t)B * L, 4)), dim3(256), 0, (hipStream_t)stream,
+                       dx, captions, masks, dword, dee, dfe, B, L, K, F, V, d, pad_token, scale);
+    ICK_LAUNCH_RET();
+}
+
+extern "C" int ick_pointer_scores_bwd(const float* ds, int64_t ds_ld, int32_t col0, const float* h, const float* ctx,
+                                      const float* w, const float* ind, float* dh, float* dctx, float* dw,
+                                      float* dbias, int32_t B, int32_t T, int32_t Kc, int32_t d, void* stream) {
+    ICK_CHECK_ARG(ds && h && ctx && w && dh && dctx && dw && dbias && B > 0 && B <= 65535 && T > 0 && Kc > 0 && d > 0);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pointer_bwd_dh_kernel, dim3(T, B), dim3(256), 0, s, ds, ds_ld, col0, ctx, w, ind, dh, T, Kc, d);
+    hipLaunchKernelGGL(pointer_bwd_dctx_kernel, dim3(Kc, B), dim3(256), 0, s, ds, ds_ld, col0, h, ctx, w, ind, dctx, dw,
+                       dbias, T, Kc, d);
+    ICK_LAUNCH_RET();
+}
+
+extern "C" int ick_entity_encode_bwd(int32_t variant, const float* dee, const float* entities, int32_t ent_cols,
+                                     const float* ee, const float* word_emb, int32_t vocab, float* dtype_emb,
+                                     int32_t ntypes, float* dword, int32_t B, int32_t K, int32_t d, void* stream) {
+    ICK_CHECK_ARG(dee && entities && dtype_emb && B > 0 && K > 0 && d > 6);
+    if (variant == ICK_NEWS) ICK_CHECK_ARG(ee && word_emb && vocab > 0);
+    hipLaunchKernelGGL(entity_encode_bwd_kernel, dim3(ceil_div((int64_t)B * K, 4)), dim3(256), 0, (hipStream_t)stream,
+                       variant, dee, entities, ent_cols, ee, word_emb, vocab, dtype_emb, ntypes, dword, B, K, d);
+    ICK_LAUNCH_RET();
+}
+
+extern "C" int ick_fact_encode_bwd(const float* dfe, const int64_t* facts, float* dee, float* dpred, int32_t num_pred,
+                                   int32_t B, int32_t K, int32_t F, int32_t d, void* stream) {
+    ICK_CHECK_ARG(dfe && facts && dee && dpred && B > 0 && K > 0 && F > 0 && d > 0);
+    hipLaunchKernelGGL(fact_encode_bwd_kernel, dim3(ceil_div((int64_t)B * F, 4)), dim3(256), 0, (hipStream_t)stream,
+                       dfe, facts, dee, dpred, num_pred, B, K, F, d);
+    ICK_LAUNCH_RET();
+}
+
+extern "C" int ick_context_gate_bwd(const int64_t* captions, const int64_t* facts, const float* dgate, float* dw,
+                                    float* dbias, int32_t B, int32_t L, int32_t T, int32_t K, int32_t F, int32_t V,
+                                    int32_t num_pred, int32_t d, int32_t mode, void* stream) {
+    ICK_CHECK_ARG(captions && facts && dgate && dw && dbias && B > 0 && L > 0 && K > 0 && F > 0);
+    ICK_CHECK_ARG((mode == 0 && T == L) || (mode == 1 && T == 1));
+    const size_t smem = (size_t)(K + 3 * F) * sizeof(int);
+    hipLaunchKernelGGL(context_gate_bwd_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, captions, facts, dgate,
+                       dw, dbias, L, T, K, F, V, num_pred, d, mode);
+    ICK_LAUNCH_RET();
+}
+
+extern "C" int ick_adam_clamp(float* p, float* g, float* m, float* v, int64_t n, float gscale, float clip, float lr,
+                              float beta1, float beta2, float eps, int32_t step, void* stream) {
+    ICK_CHECK_ARG(p && g && m && v && n > 0 && step >= 1);
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_clamp_kernel, dim3((int)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0,
+                       (hipStream_t)stream, p, g, m, v, n, gscale, clip, lr, beta1, beta2, eps, bc1, sqrtf(bc2));
+    ICK_LAUNCH_RET();
+}
+
+extern "C" int ick_scale_by_ratio(float* x, int64_t n, const float* num, const float* den, void* stream) {
+    ICK_CHECK_ARG(x && num && den && n > 0);
+    hipLaunchKernelGGL(scale_kernel, dim3((int)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0,
+                       (hipStream_t)stream, x, n, num, den);
+    ICK_LAUNCH_RET();
+}

@@ -174,13 +174,12 @@ class DecoderTransformer(nn.Module):
     def num_heads(self):
         return self.transformer_decoder.layers[0].self_attn.num_heads
 
-    def _check_eval(self):
-        if self.training:
-            drops = [self.pos_encoder.dropout.p, self.transformer_decoder.layers[0].dropout.p,
-                     self.transformer_encoder_entities.layers[0].dropout.p]
-            if any(p > 0 for p in drops) and not getattr(self, "_train_engine", None):
-                raise IckError("training-mode forward goes through ick_amd.training.TrainStep (dropout and the "
-                               "backward kernels live there); call .eval() for inference")
+    def _dropout_rates(self):
+        return (self.pos_encoder.dropout.p, self.transformer_decoder.layers[0].dropout.p,
+                self.transformer_encoder_entities.layers[0].dropout.p)
+
+    def _wants_grad(self):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 
     def _token_major(self, encoder_out):
         """(B, d, P) -> contiguous (B, P, d) storage.  Our Encoder already stores token-major."""
@@ -316,7 +315,9 @@ class DecoderTransformer(nn.Module):
 
     # ------------------------------------------------------------------ forward (teacher forced)
     def forward(self, captions, encoder_out, caption_masks, caption_lengths, entities, facts=None, stages=None):
-        self._check_eval()
+        if self.training and any(p > 0 for p in self._dropout_rates()):
+            raise IckError("training-mode dropout is not implemented in the HIP path yet: construct the decoder "
+                           "with dropout_dec=dropout_enc=dropout_pos=0 (or call .eval())")
         encoder_out, entities, facts = self._prepare_inputs(encoder_out, entities, facts)
         dev = encoder_out.device
         # length sort on the host, like the reference's CPU path (the result feeds a Python list anyway)
@@ -333,6 +334,12 @@ class DecoderTransformer(nn.Module):
         B, L = captions.shape
         d, V = self.emb_dim, self.vocab_size
         P, K = enc_tok.shape[1], entities.shape[1]
+        if self._wants_grad() and stages is None:
+            # autograd bridge: the HIP backward pass runs when the caller's loss.backward() reaches us
+            from . import training
+            scores = training.DecoderGraphFn.apply(self, captions, caption_masks, entities, facts, enc_tok.detach(),
+                                                   gmap, *training.unique_parameters(self))
+            return scores, captions, decode_lengths
 
         ee, fe, kv, ctx = self._encode_context(enc_tok, entities, facts, gmap)
         pe = self.pos_encoder.pe.view(-1, d)

@@ -1,0 +1,46 @@
+"""Data-parallel glue: one process per GPU, each rank owns a contiguous shard of
+the global minibatch, and the ONLY exchange per step is one all-reduce(sum) of a flat fp32 bucket
+[gradient of the SUM of token losses ..., sum of token losses, token count].  Dividing the reduced
+gradient by the reduced token count reproduces the reference's single-process token-mean loss over
+the global batch (geo-aware/train.py:281,297) -- a per-rank mean followed by an average would not,
+because ranks hold different numbers of non-pad tokens.  Backend "nccl" is RCCL over xGMI on ROCm;
+the same code runs on "gloo" for the CPU tests."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun's environment (no-op for a single process)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or dist.is_initialized():
+        return world
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kw = {}
+    if backend == "nccl":
+        kw["device_id"] = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend=backend, **kw)
+    return world
+
+
+def shard(batch_size, rank, world):
+    """Contiguous shard [lo, hi) of the global batch owned by `rank`."""
+    per = (batch_size + world - 1) // world
+    lo = min(batch_size, rank * per)
+    return lo, min(batch_size, lo + per)
+
+
+def allreduce_bucket(flat, group=None):
+    """Sum the flat gradient bucket (with its trailing [loss_sum, count]) over all ranks, in place."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat
+
+
+def normalise_bucket(flat, n):
+    """Global token-mean: divide the n gradient entries by the reduced token count (CPU/any device)."""
+    flat[:n] /= flat[n + 1]
+    return flat

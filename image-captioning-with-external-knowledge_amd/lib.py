@@ -41,6 +41,17 @@ class AttnArgs(C.Structure):
     ]
 
 
+class AttnBwdArgs(C.Structure):
+    _fields_ = [
+        ("Q", vp), ("K", vp), ("V", vp), ("O", vp), ("dO", vp), ("lse", vp), ("dQ", vp), ("dK", vp), ("dV", vp),
+        ("B", i32), ("H", i32), ("T", i32), ("S", i32), ("dh", i32),
+        ("q_bs", i64), ("q_hs", i64), ("q_ts", i64), ("k_bs", i64), ("k_hs", i64), ("k_ss", i64),
+        ("v_bs", i64), ("v_hs", i64), ("v_ss", i64), ("o_bs", i64), ("o_ts", i64),
+        ("dq_bs", i64), ("dq_ts", i64), ("dk_bs", i64), ("dk_ss", i64), ("dv_bs", i64), ("dv_ss", i64),
+        ("scale", f32), ("causal", i32), ("q_pos0", i32),
+    ]
+
+
 # name -> argtypes; every entry returns int (0 ok, <0 ICK_E*, >0 hipError_t)
 SIGNATURES = {
     "ick_version": [],
@@ -57,6 +68,17 @@ SIGNATURES = {
     "ick_top2": [vp, i64, i32, i32, vp, vp, vp],
     "ick_greedy_update": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "ick_packed_ce": [vp, i64, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp],
+    "ick_attention_bwd": [C.POINTER(AttnBwdArgs), vp],
+    "ick_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp],
+    "ick_relu_bwd": [vp, vp, vp, i64, vp],
+    "ick_colsum": [vp, i64, i32, i64, vp, vp],
+    "ick_caption_embed_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
+    "ick_pointer_scores_bwd": [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "ick_entity_encode_bwd": [i32, vp, vp, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, vp],
+    "ick_fact_encode_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "ick_context_gate_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "ick_adam_clamp": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, i32, vp],
+    "ick_scale_by_ratio": [vp, i64, vp, vp, vp],
 }
 
 _lib = None

@@ -248,3 +248,120 @@ def packed_ce(scores, captions_sorted, decode_len, pad_token, want_grad=False):
                                    pad_token, _p(row_loss), _p(loss_sum), _p(count), _p(dscores), _stream()),
             "ick_packed_ce")
     return loss_sum, count, dscores
+
+
+# ------------------------------------------------------------------------------------------------
+# Backward / training-step wrappers
+# ------------------------------------------------------------------------------------------------
+def attention_heads_bwd(q, kv, O, dO, lse, dQ, dK, dV, H, dh, T, S, q_seg=0, k_seg=0, v_seg=1, causal=False):
+    """Backward of attention_heads.  q (B,nq,H,Tq,DHP), kv (B,nkv,H,Sa,DHP); O/dO (B,T,d) row-major;
+    dQ (B,T,*) / dK, dV (B,S,*) row-major views (last-dim stride 1; their column offset selects the
+    segment), written as [h*dh + j]."""
+    B = q.shape[0]
+    Tq, Sa = q.shape[3], kv.shape[3]
+    a = L.AttnBwdArgs()
+    a.Q = q.data_ptr() + 4 * (q_seg * H * Tq * DHP)
+    a.K = kv.data_ptr() + 4 * (k_seg * H * Sa * DHP)
+    a.V = kv.data_ptr() + 4 * (v_seg * H * Sa * DHP)
+    a.O, a.dO, a.lse = _p(O), _p(dO), _p(lse)
+    a.dQ, a.dK, a.dV = _p(dQ), _p(dK), _p(dV)
+    a.B, a.H, a.T, a.S, a.dh = B, H, T, S, dh
+    a.q_bs, a.q_hs, a.q_ts = q.stride(0), Tq * DHP, DHP
+    a.k_bs, a.k_hs, a.k_ss = kv.stride(0), Sa * DHP, DHP
+    a.v_bs, a.v_hs, a.v_ss = kv.stride(0), Sa * DHP, DHP
+    a.o_bs, a.o_ts = O.stride(0), O.stride(1)
+    a.dq_bs, a.dq_ts = dQ.stride(0), dQ.stride(1)
+    a.dk_bs, a.dk_ss = dK.stride(0), dK.stride(1)
+    a.dv_bs, a.dv_ss = dV.stride(0), dV.stride(1)
+    a.scale = 1.0 / math.sqrt(dh)
+    a.causal, a.q_pos0 = int(causal), 0
+    L.check(L.load().ick_attention_bwd(C.byref(a), _stream()), "ick_attention_bwd")
+
+
+def layernorm_bwd(dy, x, res, gamma, mean, rstd, dgamma, dbeta):
+    d = x.shape[-1]
+    rows = x.numel() // d
+    dz = torch.empty_like(x)
+    L.check(L.load().ick_layernorm_bwd(_p(dy), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(dgamma),
+                                       _p(dbeta), rows, d, _stream()), "ick_layernorm_bwd")
+    return dz
+
+
+def relu_bwd(dy, act, out=None):
+    if out is None:
+        out = torch.empty_like(dy)
+    L.check(L.load().ick_relu_bwd(_p(dy), _p(act), _p(out), dy.numel(), _stream()), "ick_relu_bwd")
+    return out
+
+
+def colsum(a2d, out):
+    """out[n] += sum_m a2d[m, n] for a row-major 2-D view."""
+    M, N = a2d.shape
+    L.check(L.load().ick_colsum(_p(a2d), M, N, a2d.stride(0), _p(out), _stream()), "ick_colsum")
+    return out
+
+
+def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False):
+    """Backward of y = x @ w.T + b for row-major 2-D views dy (M,N), x (M,K), w (N,K):
+    dw += dy.T @ x (split-K over M, float atomics), db += colsum(dy), dx = dy @ w."""
+    M, N = dy.shape
+    K = x.shape[1]
+    if dw is not None:
+        gemm_raw(dy, x, dw, N, K, M, 1, dy.stride(0), 1, x.stride(0), dw.stride(0), atomic=True,
+                 split_k=max(1, min(16, M // 256)))
+    if db is not None:
+        colsum(dy, db)
+    if need_dx:
+        if dx is None:
+            dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+        gemm_raw(dy, w, dx, M, K, N, dy.stride(0), 1, 1, w.stride(0), dx.stride(0), accumulate=accumulate_dx)
+    return dx
+
+
+def caption_embed_bwd(dx, captions, masks, dword, dee, dfe, V, pad_token, scale):
+    B, Lc = captions.shape
+    K, d = dee.shape[1], dee.shape[2]
+    F = 0 if dfe is None else dfe.shape[1]
+    L.check(L.load().ick_caption_embed_bwd(_p(dx), _p(captions), _p(masks), _p(dword), _p(dee), _p(dfe), B, Lc, K, F,
+                                           V, d, pad_token, scale, _stream()), "ick_caption_embed_bwd")
+
+
+def pointer_scores_bwd(dscores, col0, h, ctx, w, ind, dh, dctx, dw, dbias):
+    B, T, d = h.shape
+    Kc = ctx.shape[1]
+    L.check(L.load().ick_pointer_scores_bwd(_p(dscores), dscores.stride(-2), col0, _p(h), _p(ctx), _p(w), _p(ind),
+                                            _p(dh), _p(dctx), _p(dw), _p(dbias), B, T, Kc, d, _stream()),
+            "ick_pointer_scores_bwd")
+
+
+def entity_encode_bwd(variant, dee, entities, ee, dtype_emb, word_emb=None, dword=None):
+    B, K, cols = entities.shape
+    d = dee.shape[2]
+    L.check(L.load().ick_entity_encode_bwd(L.VARIANT_ID[variant], _p(dee), _p(entities), cols, _p(ee), _p(word_emb),
+                                           0 if word_emb is None else word_emb.shape[0], _p(dtype_emb),
+                                           dtype_emb.shape[0], _p(dword), B, K, d, _stream()),
+            "ick_entity_encode_bwd")
+
+
+def fact_encode_bwd(dfe, facts, dee, dpred):
+    B, F, d = dfe.shape
+    K = dee.shape[1]
+    L.check(L.load().ick_fact_encode_bwd(_p(dfe), _p(facts), _p(dee), _p(dpred), dpred.shape[0], B, K, F, d,
+                                         _stream()), "ick_fact_encode_bwd")
+
+
+def context_gate_bwd(captions, facts, dgate, dw, dbias, K, V, mode=0):
+    B, Lc = captions.shape
+    F = facts.shape[1]
+    T, d = dgate.shape[1], dgate.shape[2]
+    L.check(L.load().ick_context_gate_bwd(_p(captions), _p(facts), _p(dgate), _p(dw), _p(dbias), B, Lc, T, K, F, V,
+                                          dw.shape[1], d, mode, _stream()), "ick_context_gate_bwd")
+
+
+def adam_clamp(p, g, m, v, step, lr, clip=5.0, gscale=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
+    L.check(L.load().ick_adam_clamp(_p(p), _p(g), _p(m), _p(v), p.numel(), gscale, clip, lr, beta1, beta2, eps, step,
+                                    _stream()), "ick_adam_clamp")
+
+
+def scale_by_ratio(x, num, den):
+    L.check(L.load().ick_scale_by_ratio(_p(x), x.numel(), _p(num), _p(den), _stream()), "ick_scale_by_ratio")

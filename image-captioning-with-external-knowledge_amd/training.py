@@ -1,0 +1,382 @@
+"""Training step of the caption decoder on MI355X.
+
+Reference call surface (geo-aware/train.py:269-292):
+    scores, caps_sorted, decode_lengths = decoder(captions, imgs, masks, lengths, entities[, facts])
+    loss = CrossEntropyLoss(ignore_index=<pad>)(pack_padded(scores), pack_padded(caps_sorted[:, 1:]))
+    decoder_optimizer.zero_grad(); loss.backward(); clip_gradient(optimizer, 5.0); optimizer.step()
+
+Two ways in:
+  * drop-in: in train() mode DecoderTransformer.forward routes through DecoderGraphFn, a
+    torch.autograd.Function whose backward runs the hand-written HIP backward pass, so the
+    reference's train.py works unchanged (its loss / optimizer stay torch objects);
+  * fused: TrainStep owns one flat fp32 bucket for parameters, gradients and Adam moments, runs
+    forward -> packed cross entropy -> backward -> (RCCL all-reduce of the bucket) -> clamp + Adam,
+    all in HIP kernels, one collective per step (data parallel over the GPUs of a node).
+Dropout: the reference constructs the decoder with dropout 0.5/0.5/0.1; the masks come from a
+counter-based generator (see ick_dropout) and cannot be bit-identical to torch's CPU stream, so
+parity of the training math is pinned with dropout disabled (p = 0 / eval-mode fixtures).
+"""
+import math
+
+import torch
+
+from . import dp, ops
+from .lib import IckError
+
+
+class Tape:
+    """Activations kept from the forward pass for the backward pass."""
+
+    def __init__(self):
+        self.enc_layers = {}   # stack name -> list of per-layer dicts
+        self.dec_layers = []
+        self.misc = {}
+
+
+def _p(x):
+    return x.detach()
+
+
+# ----------------------------------------------------------------------------------------------
+# forward with saved activations
+# ----------------------------------------------------------------------------------------------
+def _context_encoder_fwd(dec, stack, x, tape_list):
+    H, d = dec.num_heads, dec.emb_dim
+    B, T, _ = x.shape
+    for layer in stack.layers:
+        t = {"x": x}
+        t["qkv"] = ops.project_heads(x, _p(layer.self_attn.in_proj_weight), _p(layer.self_attn.in_proj_bias), 3, H, T)
+        t["sa"] = torch.empty_like(x)
+        t["lse"] = torch.empty(B * H * T, device=x.device, dtype=torch.float32)
+        ops.attention_heads(t["qkv"], t["qkv"], t["sa"], H, d // H, T, T, 0, 1, 2, lse=t["lse"])
+        t["o1"] = ops.linear(t["sa"], _p(layer.self_attn.out_proj.weight), _p(layer.self_attn.out_proj.bias))
+        t["x1"], t["m1"], t["r1"] = ops.add_layernorm(t["o1"], x, _p(layer.norm1.weight), _p(layer.norm1.bias),
+                                                      layer.norm1.eps, save_stats=True)
+        t["f"] = ops.linear(t["x1"], _p(layer.linear1.weight), _p(layer.linear1.bias), relu=True)
+        t["o2"] = ops.linear(t["f"], _p(layer.linear2.weight), _p(layer.linear2.bias))
+        x, t["m2"], t["r2"] = ops.add_layernorm(t["o2"], t["x1"], _p(layer.norm2.weight), _p(layer.norm2.bias),
+                                                layer.norm2.eps, save_stats=True)
+        tape_list.append(t)
+    return x
+
+
+def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list):
+    H, d = dec.num_heads, dec.emb_dim
+    dh = d // H
+    B, T, _ = x.shape
+    t = {"x": x}
+    t["qkv"] = ops.project_heads(x, _p(layer.self_attn.in_proj_weight), _p(layer.self_attn.in_proj_bias), 3, H, T)
+    t["sa"] = torch.empty_like(x)
+    t["lse_s"] = torch.empty(B * H * T, device=x.device, dtype=torch.float32)
+    ops.attention_heads(t["qkv"], t["qkv"], t["sa"], H, dh, T, T, 0, 1, 2, causal=True, lse=t["lse_s"])
+    t["o1"] = ops.linear(t["sa"], _p(layer.self_attn.out_proj.weight), _p(layer.self_attn.out_proj.bias))
+    t["x1"], t["m1"], t["r1"] = ops.add_layernorm(t["o1"], x, _p(layer.norm1.weight), _p(layer.norm1.bias),
+                                                  layer.norm1.eps, save_stats=True)
+    ca_w, ca_b = _p(layer.multihead_attn.in_proj_weight), _p(layer.multihead_attn.in_proj_bias)
+    t["qc"] = ops.project_heads(t["x1"], ca_w[:d], ca_b[:d], 1, H, T)
+    t["ca"] = torch.empty_like(x)
+    t["lse_c"] = torch.empty(B * H * T, device=x.device, dtype=torch.float32)
+    ops.attention_heads(t["qc"], kv, t["ca"], H, dh, T, S, 0, 2 * li, 2 * li + 1, lse=t["lse_c"])
+    t["o2"] = ops.linear(t["ca"], _p(layer.multihead_attn.out_proj.weight), _p(layer.multihead_attn.out_proj.bias))
+    t["x2"], t["m2"], t["r2"] = ops.add_layernorm(t["o2"], t["x1"], _p(layer.norm2.weight), _p(layer.norm2.bias),
+                                                  layer.norm2.eps, save_stats=True)
+    t["f"] = ops.linear(t["x2"], _p(layer.linear1.weight), _p(layer.linear1.bias), relu=True)
+    t["o3"] = ops.linear(t["f"], _p(layer.linear2.weight), _p(layer.linear2.bias))
+    x, t["m3"], t["r3"] = ops.add_layernorm(t["o3"], t["x2"], _p(layer.norm3.weight), _p(layer.norm3.bias),
+                                            layer.norm3.eps, save_stats=True)
+    tape_list.append(t)
+    return x
+
+
+def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gmap):
+    """Teacher-forced forward on already length-sorted inputs; returns (scores, tape)."""
+    tape = Tape()
+    m = tape.misc
+    d, V, H = dec.emb_dim, dec.vocab_size, dec.num_heads
+    B, L = captions.shape
+    P, K = enc_tok.shape[1], entities.shape[1]
+    ee = ops.entity_encode(dec.variant, entities, _p(dec.entity_encoder.type_embedding.weight), d,
+                           facts=facts if dec.has_facts else None,
+                           word_emb=_p(dec.word_embedding.weight) if dec.variant == "news" else None)
+    fe, Fn = None, 0
+    if dec.has_facts:
+        Fn = facts.shape[1]
+        fe = ops.fact_encode(facts, ee, _p(dec.predicate_embedding.weight))
+    tape.enc_layers["entities"] = []
+    ctx_e = _context_encoder_fwd(dec, dec.transformer_encoder_entities, ee, tape.enc_layers["entities"])
+    ctx_f = None
+    if dec.has_facts:
+        tape.enc_layers["facts"] = []
+        ctx_f = _context_encoder_fwd(dec, dec.transformer_encoder_facts, fe, tape.enc_layers["facts"])
+    # contiguous memory (B, S, d): the K/V projection and its weight gradient are then plain GEMMs
+    img = enc_tok.index_select(0, gmap.long()) if gmap is not None else enc_tok
+    mem = torch.cat([img, ctx_e] + ([ctx_f] if dec.has_facts else []), dim=1)
+    S = mem.shape[1]
+    wkv, bkv = dec._packed_cross_kv()
+    nseg = wkv.shape[0] // d
+    kv = ops.project_heads(mem, wkv, bkv, nseg, H, S)
+    pe = dec.pos_encoder.pe.view(-1, d)
+    x = ops.caption_embed(captions, caption_masks, _p(dec.word_embedding.weight), ee, fe, pe, V,
+                          dec.word_map["<pad>"], math.sqrt(d))
+    for li, layer in enumerate(dec.transformer_decoder.layers):
+        x = _decoder_layer_fwd(dec, li, layer, x, kv, S, tape.dec_layers)
+    eib = gate = hv = None
+    if dec.has_facts:
+        eib, gate = ops.context_indicators(captions, facts, K, V, dec._pred_wt(), _p(dec.fc_predicate.bias), mode=0)
+        hv = ops.mul(x, gate)
+    Vx = V + K + Fn
+    scores = torch.empty(B, L, Vx, device=x.device, dtype=torch.float32)
+    ops.gemm_raw(hv if dec.has_facts else x, _p(dec.fc_vocab.weight), scores, B * L, V, d, d, 1, d, 1, Vx,
+                 bias=_p(dec.fc_vocab.bias))
+    ops.pointer_scores(x, ee, _p(dec.fc_entity.weight), _p(dec.fc_entity.bias), scores, V)
+    if dec.has_facts:
+        ops.pointer_scores(x, fe, _p(dec.fc_fact.weight), _p(dec.fc_fact.bias), scores, V + K, ind=eib)
+    m.update(ee=ee, fe=fe, mem=mem, kv=kv, h=x, hv=hv, eib=eib, gate=gate, captions=captions, masks=caption_masks,
+             entities=entities, facts=facts, P=P, K=K, Fn=Fn, S=S, wkv=wkv)
+    return scores, tape
+
+
+# ----------------------------------------------------------------------------------------------
+# backward
+# ----------------------------------------------------------------------------------------------
+def _g(grads, param):
+    """Gradient buffer of a parameter (None when it is frozen)."""
+    return grads.get(id(param))
+
+
+def _lin_bwd(grads, dy2, x2, lin_w, lin_b, w_rows=None, need_dx=True, dx=None, acc=False):
+    """Backward of a Linear whose weight is `lin_w` (optionally the row slice w_rows of it)."""
+    gw, gb = _g(grads, lin_w), _g(grads, lin_b)
+    w = _p(lin_w)
+    if w_rows is not None:
+        w = w[w_rows]
+        gw = gw[w_rows] if gw is not None else None
+        gb = gb[w_rows] if gb is not None else None
+    return ops.linear_bwd(dy2, x2, w, gw, gb, need_dx=need_dx, dx=dx, accumulate_dx=acc)
+
+
+def _context_encoder_bwd(dec, stack, tapes, dx, grads):
+    H, d = dec.num_heads, dec.emb_dim
+    for layer, t in zip(reversed(list(stack.layers)), reversed(tapes)):
+        B, T, _ = t["x"].shape
+        M = B * T
+        dz = ops.layernorm_bwd(dx, t["o2"], t["x1"], _p(layer.norm2.weight), t["m2"], t["r2"],
+                               _g(grads, layer.norm2.weight), _g(grads, layer.norm2.bias))
+        df = _lin_bwd(grads, dz.view(M, d), t["f"].view(M, -1), layer.linear2.weight, layer.linear2.bias)
+        dpre = ops.relu_bwd(df, t["f"].view(M, -1))
+        dx1 = _lin_bwd(grads, dpre, t["x1"].view(M, d), layer.linear1.weight, layer.linear1.bias, dx=dz.view(M, d),
+                       acc=True)
+        dz = ops.layernorm_bwd(dx1.view(B, T, d), t["o1"], t["x"], _p(layer.norm1.weight), t["m1"], t["r1"],
+                               _g(grads, layer.norm1.weight), _g(grads, layer.norm1.bias))
+        dsa = _lin_bwd(grads, dz.view(M, d), t["sa"].view(M, d), layer.self_attn.out_proj.weight,
+                       layer.self_attn.out_proj.bias)
+        dqkv = torch.zeros(B, T, 3 * d, device=dx.device, dtype=torch.float32)
+        ops.attention_heads_bwd(t["qkv"], t["qkv"], t["sa"], dsa.view(B, T, d), t["lse"], dqkv[:, :, :d],
+                                dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:], H, d // H, T, T, 0, 1, 2)
+        dx = _lin_bwd(grads, dqkv.view(M, 3 * d), t["x"].view(M, d), layer.self_attn.in_proj_weight,
+                      layer.self_attn.in_proj_bias, dx=dz.view(M, d), acc=True).view(B, T, d)
+    return dx
+
+
+def _decoder_layer_bwd(dec, li, layer, t, dx, dkv_rows, kv, S, grads):
+    H, d = dec.num_heads, dec.emb_dim
+    dh = d // H
+    B, T, _ = t["x"].shape
+    M = B * T
+    dz = ops.layernorm_bwd(dx, t["o3"], t["x2"], _p(layer.norm3.weight), t["m3"], t["r3"],
+                           _g(grads, layer.norm3.weight), _g(grads, layer.norm3.bias))
+    df = _lin_bwd(grads, dz.view(M, d), t["f"].view(M, -1), layer.linear2.weight, layer.linear2.bias)
+    dpre = ops.relu_bwd(df, t["f"].view(M, -1))
+    dx2 = _lin_bwd(grads, dpre, t["x2"].view(M, d), layer.linear1.weight, layer.linear1.bias, dx=dz.view(M, d),
+                   acc=True)
+    dz = ops.layernorm_bwd(dx2.view(B, T, d), t["o2"], t["x1"], _p(layer.norm2.weight), t["m2"], t["r2"],
+                           _g(grads, layer.norm2.weight), _g(grads, layer.norm2.bias))
+    dca = _lin_bwd(grads, dz.view(M, d), t["ca"].view(M, d), layer.multihead_attn.out_proj.weight,
+                   layer.multihead_attn.out_proj.bias)
+    dq = torch.empty(B, T, d, device=dx.device, dtype=torch.float32)
+    c0 = 2 * li * d
+    ops.attention_heads_bwd(t["qc"], kv, t["ca"], dca.view(B, T, d), t["lse_c"], dq, dkv_rows[:, :, c0:c0 + d],
+                            dkv_rows[:, :, c0 + d:c0 + 2 * d], H, dh, T, S, 0, 2 * li, 2 * li + 1)
+    dx1 = _lin_bwd(grads, dq.view(M, d), t["x1"].view(M, d), layer.multihead_attn.in_proj_weight,
+                   layer.multihead_attn.in_proj_bias, w_rows=slice(0, d), dx=dz.view(M, d), acc=True)
+    dz = ops.layernorm_bwd(dx1.view(B, T, d), t["o1"], t["x"], _p(layer.norm1.weight), t["m1"], t["r1"],
+                           _g(grads, layer.norm1.weight), _g(grads, layer.norm1.bias))
+    dsa = _lin_bwd(grads, dz.view(M, d), t["sa"].view(M, d), layer.self_attn.out_proj.weight,
+                   layer.self_attn.out_proj.bias)
+    dqkv = torch.zeros(B, T, 3 * d, device=dx.device, dtype=torch.float32)
+    ops.attention_heads_bwd(t["qkv"], t["qkv"], t["sa"], dsa.view(B, T, d), t["lse_s"], dqkv[:, :, :d],
+                            dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:], H, dh, T, T, 0, 1, 2, causal=True)
+    return _lin_bwd(grads, dqkv.view(M, 3 * d), t["x"].view(M, d), layer.self_attn.in_proj_weight,
+                    layer.self_attn.in_proj_bias, dx=dz.view(M, d), acc=True).view(B, T, d)
+
+
+def backward_from_tape(dec, tape, dscores, grads):
+    """Accumulate parameter gradients of `dec` into `grads` (dict id(param) -> zero-initialised
+    tensor shaped like the parameter; frozen parameters are simply absent)."""
+    m = tape.misc
+    d, V, H = dec.emb_dim, dec.vocab_size, dec.num_heads
+    h, ee, fe = m["h"], m["ee"], m["fe"]
+    # frozen parameters (other than the word embedding, whose scatter is simply skipped) get a scratch
+    # buffer so every kernel has somewhere to accumulate; the scratch is dropped afterwards
+    grads = dict(grads)
+    for prm in unique_parameters(dec):
+        if id(prm) not in grads and prm is not dec.word_embedding.weight:
+            grads[id(prm)] = torch.zeros_like(prm)
+    B, L, _ = h.shape
+    P, K, Fn, S = m["P"], m["K"], m["Fn"], m["S"]
+    M = B * L
+    Vx = dscores.shape[2]
+    dsc2 = dscores.view(M, Vx)
+    dev = h.device
+    dee = torch.zeros_like(ee)
+    dfe = torch.zeros_like(fe) if fe is not None else None
+    # ---- score head
+    hv = m["hv"] if dec.has_facts else h
+    dhv = _lin_bwd(grads, dsc2[:, :V], hv.view(M, d), dec.fc_vocab.weight, dec.fc_vocab.bias).view(B, L, d)
+    if dec.has_facts:
+        dh = ops.mul(dhv, m["gate"])
+        dgate = ops.mul(dhv, h)
+        gw, gb = _g(grads, dec.fc_predicate.weight), _g(grads, dec.fc_predicate.bias)
+        if gw is not None:
+            ops.context_gate_bwd(m["captions"], m["facts"], dgate, gw, gb, K, V, mode=0)
+    else:
+        dh = dhv
+
+    def gbuf(param):
+        return _g(grads, param)
+
+    ops.pointer_scores_bwd(dscores, V, h, ee, _p(dec.fc_entity.weight), None, dh, dee, gbuf(dec.fc_entity.weight),
+                           gbuf(dec.fc_entity.bias))
+    if dec.has_facts:
+        ops.pointer_scores_bwd(dscores, V + K, h, fe, _p(dec.fc_fact.weight), m["eib"], dh, dfe,
+                               gbuf(dec.fc_fact.weight), gbuf(dec.fc_fact.bias))
+    # ---- decoder stack
+    layers = list(dec.transformer_decoder.layers)
+    nseg = 2 * len(layers)
+    dkv_rows = torch.zeros(B, S, nseg * d, device=dev, dtype=torch.float32)
+    dx = dh
+    for li in reversed(range(len(layers))):
+        dx = _decoder_layer_bwd(dec, li, layers[li], tape.dec_layers[li], dx, dkv_rows, m["kv"], S, grads)
+    # ---- cross K/V projection: weight gradient over all memory rows, data gradient for context rows only
+    mem2 = m["mem"].view(B * S, d)
+    dkv2 = dkv_rows.view(B * S, nseg * d)
+    for li, layer in enumerate(layers):
+        gw, gb = _g(grads, layer.multihead_attn.in_proj_weight), _g(grads, layer.multihead_attn.in_proj_bias)
+        sl = dkv2[:, 2 * li * d:(2 * li + 2) * d]
+        if gw is not None:
+            ops.gemm_raw(sl, mem2, gw[d:], 2 * d, d, B * S, 1, sl.stride(0), 1, d, d, atomic=True, split_k=16)
+        if gb is not None:
+            ops.colsum(sl, gb[d:])
+    nctx = K + Fn
+    dctx = torch.empty(B, nctx, d, device=dev, dtype=torch.float32)
+    ops.gemm_raw(dkv_rows[:, P:], m["wkv"], dctx, B * nctx, d, nseg * d, nseg * d, 1, 1, d, d, a_grp=nctx,
+                 a_gs=S * nseg * d)
+    # ---- context encoders
+    dee_enc = _context_encoder_bwd(dec, dec.transformer_encoder_entities, tape.enc_layers["entities"],
+                                   dctx[:, :K].contiguous(), grads)
+    dee += dee_enc
+    if dec.has_facts:
+        dfe_enc = _context_encoder_bwd(dec, dec.transformer_encoder_facts, tape.enc_layers["facts"],
+                                       dctx[:, K:].contiguous(), grads)
+        dfe += dfe_enc
+    # ---- caption embedding, fact encoder, entity encoder
+    gword = _g(grads, dec.word_embedding.weight)
+    ops.caption_embed_bwd(dx, m["captions"], m["masks"], gword, dee, dfe, V, dec.word_map["<pad>"], math.sqrt(d))
+    if dec.has_facts:
+        ops.fact_encode_bwd(dfe, m["facts"], dee, gbuf(dec.predicate_embedding.weight))
+    ops.entity_encode_bwd(dec.variant, dee, m["entities"], ee, gbuf(dec.entity_encoder.type_embedding.weight),
+                          word_emb=_p(dec.word_embedding.weight) if dec.variant == "news" else None,
+                          dword=gword if dec.variant == "news" else None)
+
+
+# ----------------------------------------------------------------------------------------------
+# autograd bridge (drop-in for the reference's train.py)
+# ----------------------------------------------------------------------------------------------
+class DecoderGraphFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dec, captions, masks, entities, facts, enc_tok, gmap, *params):
+        scores, tape = forward_with_tape(dec, captions, masks, entities, facts, enc_tok, gmap)
+        ctx.dec, ctx.tape, ctx.params = dec, tape, params
+        return scores
+
+    @staticmethod
+    def backward(ctx, dscores):
+        dec, params = ctx.dec, ctx.params
+        grads = {id(p): torch.zeros_like(p) for p in params if p.requires_grad}
+        backward_from_tape(dec, ctx.tape, dscores.contiguous(), grads)
+        return (None,) * 7 + tuple(grads.get(id(p)) for p in params)
+
+
+def unique_parameters(dec):
+    seen, out = set(), []
+    for p in dec.parameters():
+        if id(p) not in seen:
+            seen.add(id(p))
+            out.append(p)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# fused data-parallel training step
+# ----------------------------------------------------------------------------------------------
+class TrainStep:
+    """forward -> packed CE -> backward -> all-reduce -> clamp + Adam over one flat fp32 bucket.
+
+    Gradient semantics equal the single-process full-batch step of the reference: every rank
+    contributes the SUM of its token losses' gradients plus its token count; after the
+    all-reduce(sum) the bucket is divided by the global token count, clamped to +-grad_clip
+    (geo-aware/train.py:287-288 clamps the full-batch gradient) and fed to Adam (lr 4e-4)."""
+
+    def __init__(self, decoder, lr=4e-4, grad_clip=5.0, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+        self.dec = decoder
+        self.lr, self.clip, self.betas, self.eps = lr, grad_clip, betas, eps
+        self.pg = process_group
+        self.step_count = 0
+        params = [p for p in unique_parameters(decoder) if p.requires_grad]
+        dev = params[0].device
+        n = sum(p.numel() for p in params)
+        self.n = n
+        # +2 trailing floats travel with the gradient bucket: [sum of token losses, token count]
+        self.flat_p = torch.empty(n, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(n + 2, device=dev, dtype=torch.float32)
+        self.flat_m = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.flat_v = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.grads = {}
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                self.flat_p[off:off + k].copy_(p.reshape(-1))
+                p.data = self.flat_p[off:off + k].view(p.shape)      # parameters become views of the bucket
+                self.grads[id(p)] = self.flat_g[off:off + k].view(p.shape)
+                off += k
+        self.params = params
+
+    def __call__(self, captions, encoder_out, caption_masks, caption_lengths, entities, facts=None):
+        dec = self.dec
+        encoder_out, entities, facts = dec._prepare_inputs(encoder_out, entities, facts)
+        dev = encoder_out.device
+        lengths, sort_ind = caption_lengths.detach().squeeze(1).cpu().sort(dim=0, descending=True)
+        sort_dev = sort_ind.to(dev)
+        captions = captions.to(dev)[sort_dev].contiguous()
+        caption_masks = caption_masks.to(dev)[sort_dev].contiguous()
+        entities = entities[sort_dev].contiguous()
+        if dec.has_facts:
+            facts = facts[sort_dev].contiguous()
+        enc_tok = dec._token_major(encoder_out)
+        decode_len = (lengths - 1).to(torch.int32).to(dev)
+        self.flat_g.zero_()
+        scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok,
+                                         sort_dev.to(torch.int32))
+        loss_sum, count, dscores = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True)
+        backward_from_tape(dec, tape, dscores, self.grads)
+        self.flat_g[self.n:self.n + 1].copy_(loss_sum)
+        self.flat_g[self.n + 1:].copy_(count)
+        dp.allreduce_bucket(self.flat_g, self.pg)
+        # divide by the global token count (device-resident), clamp, Adam
+        ops.scale_by_ratio(self.flat_g[:self.n], torch.ones_like(count), self.flat_g[self.n + 1:])
+        self.step_count += 1
+        ops.adam_clamp(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count, self.lr, self.clip, 1.0,
+                       self.betas[0], self.betas[1], self.eps)
+        # token-mean loss of the global batch, still on the device
+        return self.flat_g[self.n:self.n + 1] / self.flat_g[self.n + 1:]

@@ -174,6 +174,63 @@ int ick_packed_ce(const float* scores, int64_t ld, const int64_t* captions_sorte
                   int32_t B, int32_t L, int32_t Vx, int32_t pad_token, float* row_loss /* B*L workspace */,
                   float* loss_sum, float* count, float* dscores, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Training step (row a14): backward kernels behind loss.backward() of geo-aware/train.py:282-292,
+ * and clip_gradient + Adam.step (geo-aware/utils.py:75-85, train.py:287-292).  Weight and data
+ * gradients of the Linear layers are ick_gemm calls with k-major operands.
+ */
+/* Backward of ick_attention.  Q/K/V: the forward's head-major padded buffers (row stride 32 or 64
+ * floats); O, dO row-major with (o_bs, o_ts); lse from the forward.  Outputs are row-major:
+ * dQ element (b,t,h,j) at dQ[b*dq_bs + t*dq_ts + h*dh + j], dK/dV element (b,s,h,j) at
+ * dK[b*dk_bs + s*dk_ss + h*dh + j].  When the queries do not fit one workgroup's LDS the key/value
+ * gradients are accumulated with float atomics and dK/dV must be zero on entry. */
+typedef struct {
+    const float* Q; const float* K; const float* V; const float* O; const float* dO; const float* lse;
+    float* dQ; float* dK; float* dV;
+    int32_t B, H, T, S, dh;
+    int64_t q_bs, q_hs, q_ts, k_bs, k_hs, k_ss, v_bs, v_hs, v_ss, o_bs, o_ts;
+    int64_t dq_bs, dq_ts, dk_bs, dk_ss, dv_bs, dv_ss;
+    float scale; int32_t causal; int32_t q_pos0;
+} ick_attn_bwd_args;
+int ick_attention_bwd(const ick_attn_bwd_args* args, void* stream);
+
+/* dz = dLN/d(x+res) ; dgamma += ..., dbeta += ... (accumulated with float atomics). */
+int ick_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma, const float* mean,
+                      const float* rstd, float* dz, float* dgamma, float* dbeta, int64_t rows, int32_t d,
+                      void* stream);
+/* dx = dy where the forward ReLU output `act` was positive, else 0. */
+int ick_relu_bwd(const float* dy, const float* act, float* dx, int64_t n, void* stream);
+/* out[n] += sum_m a[m*ld + n]  (bias gradients). */
+int ick_colsum(const float* a, int64_t M, int32_t N, int64_t ld, float* out, void* stream);
+/* Backward of ick_caption_embed: dx*scale is scatter-added to word_emb / entity / fact gradient rows. */
+int ick_caption_embed_bwd(const float* dx, const int64_t* captions, const int64_t* masks, float* dword,
+                          float* dee, float* dfe, int32_t B, int32_t L, int32_t K, int32_t F, int32_t V,
+                          int32_t d, int32_t pad_token, float scale, void* stream);
+/* Backward of ick_pointer_scores: ds = dscores[..., col0:col0+Kc] (row stride ds_ld);
+ * dh += ..., dctx += ..., dw += ..., dbias += ... */
+int ick_pointer_scores_bwd(const float* ds, int64_t ds_ld, int32_t col0, const float* h, const float* ctx,
+                           const float* w, const float* ind, float* dh, float* dctx, float* dw, float* dbias,
+                           int32_t B, int32_t T, int32_t Kc, int32_t d, void* stream);
+/* Backward of ick_entity_encode (type embedding; news: also the name-word embeddings). */
+int ick_entity_encode_bwd(int32_t variant, const float* dee, const float* entities, int32_t ent_cols,
+                          const float* ee, const float* word_emb, int32_t vocab, float* dtype_emb,
+                          int32_t ntypes, float* dword, int32_t B, int32_t K, int32_t d, void* stream);
+/* Backward of ick_fact_encode: dee[b, subject] += dfe, dpred_emb[predicate] += dfe. */
+int ick_fact_encode_bwd(const float* dfe, const int64_t* facts, float* dee, float* dpred, int32_t num_pred,
+                        int32_t B, int32_t K, int32_t F, int32_t d, void* stream);
+/* Backward of the predicate gate of ick_context_indicators: dgate (B,T,d) ->
+ * fc_predicate.weight.grad (d, num_pred) and bias.grad (d), accumulated. */
+int ick_context_gate_bwd(const int64_t* captions, const int64_t* facts, const float* dgate, float* dw,
+                         float* dbias, int32_t B, int32_t L, int32_t T, int32_t K, int32_t F, int32_t V,
+                         int32_t num_pred, int32_t d, int32_t mode, void* stream);
+/* g = clamp(g*gscale, +-clip) (clip <= 0: no clamp) followed by torch.optim.Adam's update, one flat
+ * fp32 bucket; `step` is the 1-based step count. */
+int ick_adam_clamp(float* p, float* g, float* m, float* v, int64_t n, float gscale, float clip, float lr,
+                   float beta1, float beta2, float eps, int32_t step, void* stream);
+/* x *= num[0] / den[0] with device-resident scalars (token-mean normalisation without a host sync). */
+int ick_scale_by_ratio(float* x, int64_t n, const float* num, const float* den, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,262 @@
+"""Training-step parity on the MI355X (row a14): backward kernels vs torch autograd in fp64, whole-model
+gradients vs the reference's own gradients (golden fixtures), the fused TrainStep vs the reference
+sequence (CE -> backward -> clamp -> Adam), and data-parallel equivalence."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+from torch.nn.utils.rnn import pack_padded_sequence
+
+import ick_amd
+import ick_amd.synth as synth
+from helpers import case_from_golden, load_golden, t
+from oracle import restatement as R
+from test_forward_gpu import build_decoder
+from test_ops_gpu import close, dev, ref_attention, rnd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import ick_amd.ops as ops
+    return ops
+
+
+# ------------------------------------------------------------------------------- kernel level
+def test_layernorm_bwd(ops):
+    rows, d = 130, 300
+    x, r, g, b, dy = rnd(rows, d, seed=1), rnd(rows, d, seed=2), 1 + rnd(d, seed=3, scale=0.1), rnd(d, seed=4), \
+        rnd(rows, d, seed=5)
+    xr, rr, gr, br = (v.double().requires_grad_(True) for v in (x, r, g, b))
+    F.layer_norm(xr + rr, (d,), gr, br, 1e-5).backward(dy.double())
+    y, mean, rstd = ops.add_layernorm(dev(x), dev(r), dev(g), dev(b), save_stats=True)
+    dg, db = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+    dz = ops.layernorm_bwd(dev(dy), dev(x), dev(r), dev(g), mean, rstd, dg, db)
+    close(dz, xr.grad, 5e-6, "ln dz")
+    close(dg, gr.grad, 2e-5, "ln dgamma")
+    close(db, br.grad, 2e-5, "ln dbeta")
+
+
+@pytest.mark.parametrize("B,T,S,causal", [(3, 20, 216, False), (3, 20, 20, True), (2, 7, 6, False), (2, 40, 300, False)])
+def test_attention_bwd(ops, B, T, S, causal):
+    H, d = 10, 300
+    dh = d // H
+    x, mem, do = rnd(B, T, d, seed=1), rnd(B, S, d, seed=2), rnd(B, T, d, seed=3)
+    wq, wkv = rnd(d, d, seed=4, scale=0.1), rnd(2 * d, d, seed=5, scale=0.1)
+    q = ops.project_heads(dev(x), dev(wq), None, 1, H, T)
+    kv = ops.project_heads(dev(mem), dev(wkv), None, 2, H, S)
+    out = torch.empty(B, T, d, device="cuda")
+    lse = torch.empty(B * H * T, device="cuda")
+    ops.attention_heads(q, kv, out, H, dh, T, S, 0, 0, 1, causal=causal, lse=lse)
+    qr = (x.double() @ wq.double().t()).requires_grad_(True)
+    kvr = (mem.double() @ wkv.double().t())
+    kr, vr = kvr[..., :d].clone().requires_grad_(True), kvr[..., d:].clone().requires_grad_(True)
+    ref = ref_attention_f64(qr, kr, vr, H, causal)
+    ref.backward(do.double())
+    dq = torch.zeros(B, T, d, device="cuda")
+    dkv = torch.zeros(B, S, 2 * d, device="cuda")
+    ops.attention_heads_bwd(q, kv, out, dev(do), lse, dq, dkv[:, :, :d], dkv[:, :, d:], H, dh, T, S, 0, 0, 1,
+                            causal=causal)
+    close(out, ref.detach(), 5e-6, "fwd")
+    close(dq, qr.grad, 1e-5, "dq")
+    close(dkv[:, :, :d], kr.grad, 1e-5, "dk")
+    close(dkv[:, :, d:], vr.grad, 1e-5, "dv")
+
+
+def ref_attention_f64(q, k, v, H, causal):
+    B, T, d = q.shape
+    S = k.shape[1]
+    dh = d // H
+    qq = q.view(B, T, H, dh).transpose(1, 2)
+    kk = k.view(B, S, H, dh).transpose(1, 2)
+    vv = v.view(B, S, H, dh).transpose(1, 2)
+    att = qq @ kk.transpose(-1, -2) / math.sqrt(dh)
+    if causal:
+        att = att + torch.full((T, S), float("-inf"), dtype=att.dtype).triu(1)
+    return (att.softmax(-1) @ vv).transpose(1, 2).reshape(B, T, d)
+
+
+def test_linear_bwd_relu_colsum(ops):
+    M, N, K = 1280, 512, 300
+    x, w, b, dy = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3), rnd(M, N, seed=4)
+    xr, wr, br = (v.double().requires_grad_(True) for v in (x, w, b))
+    yr = F.relu(F.linear(xr, wr, br))
+    yr.backward(dy.double())
+    y = ops.linear(dev(x), dev(w), dev(b), relu=True)
+    dpre = ops.relu_bwd(dev(dy), y)
+    dw, db = torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda")
+    dx = ops.linear_bwd(dpre, dev(x), dev(w), dw, db)
+    close(dx, xr.grad, 2e-5, "dx")
+    close(dw, wr.grad, 5e-5, "dw")
+    close(db, br.grad, 5e-5, "db")
+
+
+def test_pointer_and_embedding_bwd(ops):
+    B, T, Kc, d, V = 4, 6, 7, 300, 50
+    h, ctx, w, b = rnd(B, T, d, seed=1), rnd(B, Kc, d, seed=2), rnd(1, d, seed=3, scale=0.1), rnd(1, seed=4)
+    ind = (rnd(B, T, Kc, seed=5) > 0).float()
+    ds = rnd(B, T, V + Kc, seed=6)
+    hr, cr, wr, br = (v.double().requires_grad_(True) for v in (h, ctx, w, b))
+    s = ((hr.unsqueeze(2) * cr.unsqueeze(1) * ind.double().unsqueeze(3)) * wr.view(1, 1, 1, d)).sum(-1) + br
+    s.backward(ds[:, :, V:].double())
+    dh, dctx = torch.zeros(B, T, d, device="cuda"), torch.zeros(B, Kc, d, device="cuda")
+    dw, db = torch.zeros(1, d, device="cuda"), torch.zeros(1, device="cuda")
+    ops.pointer_scores_bwd(dev(ds), V, dev(h), dev(ctx), dev(w), dev(ind), dh, dctx, dw, db)
+    close(dh, hr.grad, 1e-5, "dh")
+    close(dctx, cr.grad, 1e-5, "dctx")
+    close(dw, wr.grad, 2e-5, "dw")
+    close(db, br.grad, 2e-5, "db")
+    # caption embedding scatter
+    variant, Lc, K, Fn = "knowledge", 9, 7, 6
+    P = synth.make_params(variant, V, 3)
+    cfg = R.config_from_word_map(variant, synth.make_word_map(V))
+    batch = synth.make_batch(variant, B, Lc, K, V, Fn, 3)
+    ee, fe = rnd(B, K, d, seed=7), rnd(B, Fn, d, seed=8)
+    we = P["word_embedding.weight"]
+    wer, eer, fer = (v.double().requires_grad_(True) for v in (we, ee, fe))
+    emb = R.caption_embed(cfg, {"word_embedding.weight": wer}, batch["captions"], batch["caption_masks"], eer, fer)
+    dx = rnd(B, Lc, d, seed=9)
+    (emb * math.sqrt(d)).backward(dx.double())
+    dword, dee, dfe = torch.zeros(V, d, device="cuda"), torch.zeros(B, K, d, device="cuda"), \
+        torch.zeros(B, Fn, d, device="cuda")
+    ops.caption_embed_bwd(dev(dx), dev(batch["captions"]), dev(batch["caption_masks"]), dword, dee, dfe, V, cfg.pad,
+                          math.sqrt(d))
+    close(dword, wer.grad, 1e-5, "dword")
+    close(dee, eer.grad, 1e-5, "dee")
+    close(dfe, fer.grad, 1e-5, "dfe")
+
+
+def test_adam_clamp_matches_torch(ops):
+    n = 10007
+    p0, g0 = rnd(n, seed=1), rnd(n, seed=2, scale=20.0)
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=4e-4)
+    p, m, v = dev(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        g = g0 * step
+        pt.grad = g.clone().clamp_(-5, 5)
+        opt.step()
+        ops.adam_clamp(p, dev(g), m, v, step, 4e-4, clip=5.0)
+        close(p, pt.detach(), 2e-6, "adam step %d" % step)
+
+
+# ------------------------------------------------------------------------------- whole model
+def reference_loss(scores, caps_sorted, dl, pad):
+    targets = caps_sorted[:, 1:]
+    sp = pack_padded_sequence(scores, dl, batch_first=True).data
+    tp = pack_padded_sequence(targets, dl, batch_first=True).data
+    return F.cross_entropy(sp, tp, ignore_index=pad)
+
+
+@pytest.mark.parametrize("name", ["fwd_tiny_geo", "fwd_tiny_knowledge", "fwd_tiny_news", "fwd_mid_geo",
+                                  "fwd_mid_knowledge"])
+def test_gradients_vs_reference_golden(name):
+    """loss.backward() through the drop-in module == the reference's gradients (train.py's loss)."""
+    g = load_golden(name)
+    cfg, P, wm, batch, enc_out = case_from_golden(g)
+    dec = build_decoder(cfg.variant, cfg.vocab_size, P)
+    args = [batch["captions"].cuda(), enc_out.cuda(), batch["caption_masks"].cuda(), batch["caption_lengths"].cuda(),
+            batch["entities"]]
+    if "facts" in batch:
+        args.append(batch["facts"].cuda())
+    scores, caps, dl = dec(*args)
+    assert scores.requires_grad
+    loss = reference_loss(scores, caps, dl, wm["<pad>"])
+    assert abs(loss.item() - float(g["loss"][0])) < 2e-5
+    loss.backward()
+    named = dict(dec.named_parameters())
+    norms = dict(zip(g["grad_norm_names"].tolist(), g["grad_norms"].tolist()))
+    for k, n in norms.items():
+        if k.startswith("fact_encoder."):
+            continue
+        assert named[k].grad is not None, k
+        mine = float(named[k].grad.double().norm())
+        assert abs(mine - n) <= 2e-4 * max(n, 1e-3), (k, mine, n)
+    for k in g:
+        if k.startswith("grad::"):
+            ref = t(g[k])
+            err = (named[k[6:]].grad.cpu() - ref).abs().max().item()
+            assert err < 2e-5 * max(1.0, ref.abs().max().item()), (k, err)
+
+
+def test_train_step_matches_reference_sequence_and_dp_split():
+    """TrainStep (fused CE + backward + clamp + Adam) vs the reference sequence on the CPU oracle; then
+    the same update from two half-batch 'ranks' whose buckets are summed (what the all-reduce does)."""
+    from ick_amd.training import TrainStep, backward_from_tape, forward_with_tape
+    import ick_amd.ops as ops
+    variant, B, L, K, V, Fn, seed = "knowledge", 6, 9, 5, 120, 4, 5
+    P = synth.make_params(variant, V, seed)
+    wm = synth.make_word_map(V)
+    cfg = R.config_from_word_map(variant, wm)
+    batch = synth.make_batch(variant, B, L, K, V, Fn, seed)
+    enc_out = synth.make_enc_out(B, seed)
+    # reference sequence on the oracle (CPU autograd, torch Adam)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items() if not k.startswith("fact_encoder.")}
+    Pr["fact_encoder.predicate_embedding.weight"] = Pr["predicate_embedding.weight"]
+    uniq = [v for k, v in Pr.items() if not k.startswith("fact_encoder.")]
+    opt = torch.optim.Adam(uniq, lr=4e-4)
+    scores, caps, dl = R.forward(cfg, Pr, batch["captions"], enc_out, batch["caption_masks"],
+                                 batch["caption_lengths"], batch["entities"], batch["facts"])
+    loss_ref = R.packed_ce_loss(cfg, scores, caps, dl)
+    loss_ref.backward()
+    for p in uniq:
+        p.grad.clamp_(-5.0, 5.0)
+    opt.step()
+    # fused step
+    dec = build_decoder(variant, V, P).train()
+    for mod in dec.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    for layer in list(dec.transformer_decoder.layers) + list(dec.transformer_encoder_entities.layers) + \
+            list(dec.transformer_encoder_facts.layers):
+        for att in (getattr(layer, "self_attn", None), getattr(layer, "multihead_attn", None)):
+            if att is not None:
+                att.dropout = 0.0
+    ts = TrainStep(dec, lr=4e-4, grad_clip=5.0)
+    loss = ts(batch["captions"].cuda(), enc_out.cuda(), batch["caption_masks"].cuda(),
+              batch["caption_lengths"].cuda(), batch["entities"], batch["facts"].cuda())
+    assert abs(loss.item() - loss_ref.item()) < 2e-5
+    named = dict(dec.named_parameters())
+    for k, pr in Pr.items():
+        if k.startswith("fact_encoder."):
+            continue
+        err = (named[k].detach().cpu() - pr.detach()).abs().max().item()
+        assert err < 5e-5, (k, err)   # Adam's first step moves every weight by ~lr=4e-4: a wrong gradient shows
+    # ---- DP: two ranks, half the batch each; sum of the unnormalised buckets == full-batch bucket
+    dec2 = build_decoder(variant, V, P).train()
+    for mod in dec2.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    full = TrainStep(dec2, lr=4e-4)
+    buckets = []
+    for lo in (0, 3):
+        sub = {k: v[lo:lo + 3] for k, v in batch.items()}
+        lengths, sort_ind = sub["caption_lengths"].squeeze(1).sort(descending=True)
+        sd = sort_ind.cuda()
+        caps_s = sub["captions"].cuda()[sd].contiguous()
+        masks_s = sub["caption_masks"].cuda()[sd].contiguous()
+        ents_s = sub["entities"].cuda()[sd].contiguous()
+        facts_s = sub["facts"].cuda()[sd].contiguous()
+        enc_tok = enc_out[lo:lo + 3].cuda().permute(0, 2, 1).contiguous()
+        full.flat_g.zero_()
+        sc, tape = forward_with_tape(dec2, caps_s, masks_s, ents_s, facts_s, enc_tok, sd.to(torch.int32))
+        ls, cnt, dsc = ops.packed_ce(sc, caps_s, (lengths - 1).to(torch.int32).cuda(), wm["<pad>"], want_grad=True)
+        backward_from_tape(dec2, tape, dsc, full.grads)
+        full.flat_g[full.n:full.n + 1].copy_(ls)
+        full.flat_g[full.n + 1:].copy_(cnt)
+        buckets.append(full.flat_g.clone())
+    summed = buckets[0] + buckets[1]           # == all_reduce(SUM)
+    full.flat_g.zero_()
+    sd = batch["caption_lengths"].squeeze(1).sort(descending=True)
+    caps_s = batch["captions"].cuda()[sd.indices.cuda()].contiguous()
+    sc, tape = forward_with_tape(dec2, caps_s, batch["caption_masks"].cuda()[sd.indices.cuda()].contiguous(),
+                                 batch["entities"].cuda()[sd.indices.cuda()].contiguous(),
+                                 batch["facts"].cuda()[sd.indices.cuda()].contiguous(),
+                                 enc_out.cuda().permute(0, 2, 1).contiguous(), sd.indices.cuda().to(torch.int32))
+    ls, cnt, dsc = ops.packed_ce(sc, caps_s, (sd.values - 1).to(torch.int32).cuda(), wm["<pad>"], want_grad=True)
+    backward_from_tape(dec2, tape, dsc, full.grads)
+    assert cnt.item() == summed[full.n + 1].item()
+    err = (summed[:full.n] - full.flat_g[:full.n]).abs().max().item()
+    assert err < 1e-4 * max(1.0, full.flat_g[:full.n].abs().max().item()), err
