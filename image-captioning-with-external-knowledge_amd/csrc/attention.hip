@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void attn_kernel(ick_attn_args p, int TQ, int 
     const int h = blockIdx.x, b = blockIdx.y, t0 = blockIdx.z * TQ;
     const int nt = min(TQ, p.T - t0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Dropout drop = make_dropout(p.drop_p, p.drop_seed, p.drop_site);
     int slen = S;
     if (p.kv_len) slen = min(S, p.kv_len[b]);
     const float* qb = p.Q + (int64_t)b * p.q_bs + (int64_t)h * p.q_hs + (int64_t)t0 * p.q_ts;
@@ -117,9 +118,11 @@ __global__ __launch_bounds__(256) void attn_kernel(ick_attn_args p, int TQ, int 
         for (int s = lane; s < slen; s += 64) m = fmaxf(m, pr[s]);
         m = wave_max(m);
         float sum = 0.f;
+        const uint32_t rowbase = (uint32_t)((b * p.H + h) * p.T + t0 + t) * (uint32_t)S;
         for (int s = lane; s < slen; s += 64) {
             const float e = (m == -INFINITY) ? 0.f : __expf(pr[s] - m);
-            pr[s] = e;
+            // attention-weight dropout of nn.MultiheadAttention (training): the normaliser keeps every key
+            pr[s] = drop.on() ? e * drop.mask(rowbase + (uint32_t)s) : e;
             sum += e;
         }
         sum = wave_sum(sum);
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(ick_attn_bwd_args p, int 
     const int nt = min(TQ, p.T - t0);
     const int tid = threadIdx.x;
     const bool multi = gridDim.z > 1;
+    const Dropout drop = make_dropout(p.drop_p, p.drop_seed, p.drop_site);
     const float* qb = p.Q + (int64_t)b * p.q_bs + (int64_t)h * p.q_hs + (int64_t)t0 * DHP;
     const float* kb = p.K + (int64_t)b * p.k_bs + (int64_t)h * p.k_hs;
     const float* vb = p.V + (int64_t)b * p.v_bs + (int64_t)h * p.v_hs;
@@ -272,10 +276,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(ick_attn_bwd_args p, int 
             }
             float pr = __expf(sc * p.scale - Ls[t]);
             if (p.causal && s > p.q_pos0 + t0 + t) pr = 0.f;
-            const float ds = pr * (dp - Dl[t]) * p.scale;
+            float mk = 1.f;
+            if (drop.on()) mk = drop.mask((uint32_t)((b * p.H + h) * p.T + t0 + t) * (uint32_t)S + (uint32_t)s);
+            const float ds = pr * (dp * mk - Dl[t]) * p.scale;
+            const float prd = pr * mk;
 #pragma unroll
             for (int j = 0; j < DHP; ++j) {
-                dv[j] = fmaf(pr, g[j], dv[j]);
+                dv[j] = fmaf(prd, g[j], dv[j]);
                 dk[j] = fmaf(ds, q[j], dk[j]);
             }
             dS[t * SLD + s] = ds;

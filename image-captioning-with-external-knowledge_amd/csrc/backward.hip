@@ -24,7 +24,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dz,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int64_t rows, int d, int rows_per_block) {
+                                                            int64_t rows, int d, int rows_per_block,
+                                                            float* __restrict__ dx_drop, Dropout drop) {
     extern __shared__ float sm[];  // 2 * d partial sums
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 2 * d; i += 256) sm[i] = 0.f;
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             float z = 0.f, dyv = 0.f;
             if (c < d) {
                 z = x[row * d + c];
+                if (drop.on()) z *= drop.mask((uint32_t)row * (uint32_t)d + (uint32_t)c);
                 if (res) z += res[row * d + c];
                 dyv = dy[row * d + c];
             }
@@ -64,7 +66,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < kMaxPerLane; ++j) {
             const int c = lane + 64 * j;
-            if (c < d) dz[row * d + c] = rs * (g[j] - s1 - zh[j] * s2);
+            if (c < d) {
+                const float v = rs * (g[j] - s1 - zh[j] * s2);
+                dz[row * d + c] = v;
+                if (dx_drop) dx_drop[row * d + c] = v * drop.mask((uint32_t)row * (uint32_t)d + (uint32_t)c);
+            }
         }
     }
 #pragma unroll
@@ -84,9 +90,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 
 // dpre = dpost where the forward activation was positive (ReLU), in place or out of place
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ act,
-                                                       float* __restrict__ dx, int64_t n) {
+                                                       float* __restrict__ dx, int64_t n, float scale) {
     const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dx[i] = act[i] > 0.f ? dy[i] : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        dx[i] = act[i] > 0.f ? dy[i] * scale : 0.f;
 }
 
 // out[n] += sum_m a[m, n]   (bias gradients).  grid (column blocks of 64, row slabs); each wave owns
@@ -115,7 +122,8 @@ __global__ __launch_bounds__(256) void caption_embed_bwd_kernel(const float* __r
                                                                 const int64_t* __restrict__ masks,
                                                                 float* __restrict__ dword, float* __restrict__ dee,
                                                                 float* __restrict__ dfe, int B, int L, int K, int F,
-                                                                int V, int d, int pad_token, float scale) {
+                                                                int V, int d, int pad_token, float scale,
+                                                                Dropout drop) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B * L) return;
@@ -138,7 +146,11 @@ __global__ __launch_bounds__(256) void caption_embed_bwd_kernel(const float* __r
         dst = dword + w * d;
     }
     const float* src = dx + (int64_t)row * d;
-    for (int c = lane; c < d; c += 64) atomicAdd(dst + c, src[c] * scale);
+    for (int c = lane; c < d; c += 64) {
+        float v = src[c] * scale;
+        if (drop.on()) v *= drop.mask((uint32_t)row * (uint32_t)d + (uint32_t)c);   // PositionEncoder dropout
+        atomicAdd(dst + c, v);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -344,18 +356,21 @@ using namespace ick;
 
 extern "C" int ick_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma,
                                  const float* mean, const float* rstd, float* dz, float* dgamma, float* dbeta,
-                                 int64_t rows, int32_t d, void* stream) {
+                                 int64_t rows, int32_t d, float* dx_drop, float drop_p, uint32_t drop_seed,
+                                 uint32_t drop_site, void* stream) {
     ICK_CHECK_ARG(dy && x && gamma && mean && rstd && dz && dgamma && dbeta && rows > 0 && d > 0 && d <= 1024);
+    ICK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || dx_drop != nullptr));
     const int rpb = 16;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(ceil_div(rows, rpb)), dim3(256), 2 * d * sizeof(float),
-                       (hipStream_t)stream, dy, x, res, gamma, mean, rstd, dz, dgamma, dbeta, rows, d, rpb);
+                       (hipStream_t)stream, dy, x, res, gamma, mean, rstd, dz, dgamma, dbeta, rows, d, rpb,
+                       drop_p > 0.f ? dx_drop : nullptr, make_dropout(drop_p, drop_seed, drop_site));
     ICK_LAUNCH_RET();
 }
 
-extern "C" int ick_relu_bwd(const float* dy, const float* act, float* dx, int64_t n, void* stream) {
+extern "C" int ick_relu_bwd(const float* dy, const float* act, float* dx, int64_t n, float scale, void* stream) {
     ICK_CHECK_ARG(dy && act && dx && n > 0);
     hipLaunchKernelGGL(relu_bwd_kernel, dim3((int)std::min<int64_t>(ceil_div(n, 256), 2048)), dim3(256), 0,
-                       (hipStream_t)stream, dy, act, dx, n);
+                       (hipStream_t)stream, dy, act, dx, n, scale);
     ICK_LAUNCH_RET();
 }
 
@@ -370,10 +385,12 @@ extern "C" int ick_colsum(const float* a, int64_t M, int32_t N, int64_t ld, floa
 
 extern "C" int ick_caption_embed_bwd(const float* dx, const int64_t* captions, const int64_t* masks, float* dword,
                                      float* dee, float* dfe, int32_t B, int32_t L, int32_t K, int32_t F, int32_t V,
-                                     int32_t d, int32_t pad_token, float scale, void* stream) {
+                                     int32_t d, int32_t pad_token, float scale, float drop_p, uint32_t drop_seed,
+                                     uint32_t drop_site, void* stream) {
     ICK_CHECK_ARG(dx && captions && masks && dee && B > 0 && L > 0 && K > 0 && d > 0);
     hipLaunchKernelGGL(caption_embed_bwd_kernel, dim3(ceil_div((int64_t)B * L, 4)), dim3(256), 0, (hipStream_t)stream,
-                       dx, captions, masks, dword, dee, dfe, B, L, K, F, V, d, pad_token, scale);
+                       dx, captions, masks, dword, dee, dfe, B, L, K, F, V, d, pad_token, scale,
+                       make_dropout(drop_p, drop_seed, drop_site));
     ICK_LAUNCH_RET();
 }
 

@@ -61,4 +61,27 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
     return r;
 }
 
+// Counter-based dropout: the keep decision of element `idx` at dropout site `site` of the step whose
+// seed is `seed` is a pure function of (seed, site, idx) (murmur3 finaliser), so the backward pass
+// regenerates the forward's mask without storing it.  thr = p * 2^32; keep iff hash >= thr.
+__device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t site, uint32_t idx) {
+    uint32_t x = idx * 0x9E3779B1u ^ (seed + site * 0x85EBCA6Bu);
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+struct Dropout {
+    uint32_t thr, seed, site;
+    float scale;  // 1 / (1 - p); p == 0 disables
+    __device__ __forceinline__ bool on() const { return thr != 0u; }
+    __device__ __forceinline__ float mask(uint32_t idx) const { return drop_hash(seed, site, idx) >= thr ? scale : 0.f; }
+};
+__host__ __device__ __forceinline__ Dropout make_dropout(float p, uint32_t seed, uint32_t site) {
+    Dropout d{0u, seed, site, 1.f};
+    if (p > 0.f) {
+        d.thr = (uint32_t)fminf(p * 4294967296.f, 4294967040.f);   // same IEEE float math on host and device
+        d.scale = 1.f / (1.f - p);
+    }
+    return d;
+}
+
 }  // namespace ick

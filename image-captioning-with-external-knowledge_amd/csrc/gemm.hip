@@ -264,11 +264,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m,
     }
     const float alpha = p.alpha;
     int64_t coff[TM][4];
+    int rowid[TM][4];
+    const Dropout drop = make_dropout(p.drop_p, p.drop_seed, p.drop_site);
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + (wm * TM + a) * 16 + fq * 4 + r;
+            rowid[a][r] = row;
             coff[a][r] = row < p.M ? cmap(row) + row_bias : -1;
         }
 #pragma unroll
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m,
             for (int b = 0; b < TN; ++b) {
                 v[b] = acc[a][b][r] * alpha + bv[b];
                 if (relu) v[b] = fmaxf(v[b], 0.f);
+                if (drop.on()) v[b] *= drop.mask((uint32_t)rowid[a][r] * (uint32_t)p.N + (uint32_t)cols[b]);
             }
             if (mode == 0) {
 #pragma unroll
@@ -402,6 +406,7 @@ __global__ __launch_bounds__(256) void gemm_kres_kernel(ick_gemm_args p, int til
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc1, 0, 0, 0);
     }
     const bool relu = p.flags & ICK_GEMM_RELU, accum = p.flags & ICK_GEMM_ACCUM;
+    const Dropout drop = make_dropout(p.drop_p, p.drop_seed, p.drop_site);
     const int col = n0 + wn * 16 + fi;
     if (col < p.N) {
         const float bv = p.bias ? p.bias[col] : 0.f;
@@ -411,6 +416,7 @@ __global__ __launch_bounds__(256) void gemm_kres_kernel(ick_gemm_args p, int til
             if (co >= 0) {
                 float x = (acc0[r] + acc1[r]) * p.alpha + bv;
                 if (relu) x = fmaxf(x, 0.f);
+                if (drop.on()) x *= drop.mask((uint32_t)(m0 + wm * 16 + fq * 4 + r) * (uint32_t)p.N + (uint32_t)col);
                 float* dst = p.C + co + col_offset(p, col);
                 if (accum) *dst += x; else *dst = x;
             }

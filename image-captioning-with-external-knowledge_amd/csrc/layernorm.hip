@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             int64_t rows, int d, float eps, int64_t x_ld,
                                                             int64_t res_ld, int64_t y_ld, float* save_mean,
-                                                            float* save_rstd) {
+                                                            float* save_rstd, Dropout drop) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
         bt[j] = 0.f;
         if (c < d) {
             t = xr[c];
+            if (drop.on()) t *= drop.mask((uint32_t)row * (uint32_t)d + (uint32_t)c);   // dropout1/2/3 of the layer
             if (rr) t += rr[c];
             g[j] = gamma[c];
             bt[j] = beta[c];
@@ -65,12 +66,14 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
 
 extern "C" int ick_add_layernorm(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                                  int64_t rows, int32_t d, float eps, int64_t x_ld, int64_t res_ld, int64_t y_ld,
-                                 float* save_mean, float* save_rstd, void* stream) {
+                                 float* save_mean, float* save_rstd, float drop_p, uint32_t drop_seed,
+                                 uint32_t drop_site, void* stream) {
     using namespace ick;
     ICK_CHECK_ARG(x && gamma && beta && y);
     ICK_CHECK_ARG(rows > 0 && d > 0 && d <= 64 * kMaxPerLane);
     ICK_CHECK_ARG((save_mean == nullptr) == (save_rstd == nullptr));
     hipLaunchKernelGGL(add_layernorm_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, res, gamma,
-                       beta, y, rows, d, eps, x_ld, res_ld, y_ld, save_mean, save_rstd);
+                       beta, y, rows, d, eps, x_ld, res_ld, y_ld, save_mean, save_rstd,
+                       make_dropout(drop_p, drop_seed, drop_site));
     ICK_LAUNCH_RET();
 }

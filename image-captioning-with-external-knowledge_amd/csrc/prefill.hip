@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void caption_embed_kernel(const int64_t* __res
                                                             const float* __restrict__ fe, const float* __restrict__ pe,
                                                             float* __restrict__ out, float* __restrict__ emb_out, int B,
                                                             int L, int K, int F, int V, int d, int pad_token,
-                                                            float scale, int pos0) {
+                                                            float scale, int pos0, Dropout drop) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B * L) return;
@@ -138,7 +138,9 @@ __global__ __launch_bounds__(256) void caption_embed_kernel(const int64_t* __res
     for (int c = lane; c < d; c += 64) {
         const float v = src[c];
         if (emb_out) emb_out[(int64_t)row * d + c] = v;
-        o[c] = __fadd_rn(__fmul_rn(v, scale), per[c]);
+        float y = __fadd_rn(__fmul_rn(v, scale), per[c]);
+        if (drop.on()) y *= drop.mask((uint32_t)row * (uint32_t)d + (uint32_t)c);   // PositionEncoder dropout (training)
+        o[c] = y;
     }
 }
 
@@ -207,6 +209,13 @@ __global__ __launch_bounds__(256) void context_indicators_kernel(const int64_t* 
     }
 }
 
+// mask[r, c] = keep ? 1/(1-p) : 0 of element index r * cols + c (test / inspection helper)
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, int64_t rows, int cols, Dropout drop) {
+    const int64_t n = rows * cols;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = drop.mask((uint32_t)i);
+}
+
 __global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                   float* __restrict__ y, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * 256;
@@ -243,14 +252,15 @@ extern "C" int ick_fact_encode(const int64_t* facts, const float* entities_encod
 extern "C" int ick_caption_embed(const int64_t* captions, const int64_t* masks, const float* word_emb,
                                  const float* entities_encoded, const float* facts_encoded, const float* pe,
                                  float* out, float* emb_out, int32_t B, int32_t L, int32_t K, int32_t F, int32_t V,
-                                 int32_t d, int32_t pad_token, float scale, int32_t pos0, void* stream) {
+                                 int32_t d, int32_t pad_token, float scale, int32_t pos0, float drop_p,
+                                 uint32_t drop_seed, uint32_t drop_site, void* stream) {
     using namespace ick;
     ICK_CHECK_ARG(captions && masks && word_emb && entities_encoded && pe && out);
     ICK_CHECK_ARG(B > 0 && L > 0 && K > 0 && V > 0 && d > 0 && pos0 >= 0);
     if (facts_encoded) ICK_CHECK_ARG(F > 0);
     hipLaunchKernelGGL(caption_embed_kernel, dim3(ceil_div((int64_t)B * L, 4)), dim3(256), 0, (hipStream_t)stream,
                        captions, masks, word_emb, entities_encoded, facts_encoded, pe, out, emb_out, B, L, K, F, V, d,
-                       pad_token, scale, pos0);
+                       pad_token, scale, pos0, make_dropout(drop_p, drop_seed, drop_site));
     ICK_LAUNCH_RET();
 }
 
@@ -274,5 +284,15 @@ extern "C" int ick_mul(const float* a, const float* b, float* y, int64_t n, void
     ICK_CHECK_ARG(a && b && y && n > 0);
     const int grid = (int)std::min<int64_t>(ceil_div(n, 256), 2048);
     hipLaunchKernelGGL(mul_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, y, n);
+    ICK_LAUNCH_RET();
+}
+
+extern "C" int ick_dropout_mask(float* out, int64_t rows, int32_t cols, float p, uint32_t seed, uint32_t site,
+                                void* stream) {
+    using namespace ick;
+    ICK_CHECK_ARG(out && rows > 0 && cols > 0 && p >= 0.f && p < 1.f && rows * cols < ((int64_t)1 << 32));
+    const int grid = (int)std::min<int64_t>(ceil_div(rows * cols, 256), 2048);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, rows, cols,
+                       make_dropout(p, seed, site));
     ICK_LAUNCH_RET();
 }

@@ -315,9 +315,6 @@ class DecoderTransformer(nn.Module):
 
     # ------------------------------------------------------------------ forward (teacher forced)
     def forward(self, captions, encoder_out, caption_masks, caption_lengths, entities, facts=None, stages=None):
-        if self.training and any(p > 0 for p in self._dropout_rates()):
-            raise IckError("training-mode dropout is not implemented in the HIP path yet: construct the decoder "
-                           "with dropout_dec=dropout_enc=dropout_pos=0 (or call .eval())")
         encoder_out, entities, facts = self._prepare_inputs(encoder_out, entities, facts)
         dev = encoder_out.device
         # length sort on the host, like the reference's CPU path (the result feeds a Python list anyway)

@@ -27,8 +27,21 @@ def _f32c(t, name):
 TIMED = None
 
 
+def _drop(a, drop):
+    """drop = (p, seed, site) or None -> fields of an args struct."""
+    if drop is not None and drop[0] > 0.0:
+        a.drop_p, a.drop_seed, a.drop_site = float(drop[0]), int(drop[1]) & 0xFFFFFFFF, int(drop[2]) & 0xFFFFFFFF
+
+
+def _dargs(drop):
+    if drop is not None and drop[0] > 0.0:
+        return float(drop[0]), int(drop[1]) & 0xFFFFFFFF, int(drop[2]) & 0xFFFFFFFF
+    return 0.0, 0, 0
+
+
 def gemm_raw(A, B, Cout, M, N, K, a_rs, a_ks, b_rs, b_ks, c_rs, bias=None, a_grp=0, a_gs=0, a_gmap=None,
-             c_grp=0, c_gs=0, c_gmap=None, relu=False, accumulate=False, atomic=False, split_k=1, alpha=1.0):
+             c_grp=0, c_gs=0, c_gmap=None, relu=False, accumulate=False, atomic=False, split_k=1, alpha=1.0,
+             drop=None):
     """C[m,n] = act(alpha * sum_k A(m,k) B(n,k) + bias[n]) with explicit element strides; A/B/Cout are
     tensors (only their data pointers are used -- the caller guarantees the strides stay in bounds)."""
     a = L.GemmArgs()
@@ -40,6 +53,7 @@ def gemm_raw(A, B, Cout, M, N, K, a_rs, a_ks, b_rs, b_ks, c_rs, bias=None, a_grp
     a.flags = (L.GEMM_RELU if relu else 0) | (L.GEMM_ACCUM if accumulate else 0) | (L.GEMM_ATOMIC if atomic else 0)
     a.split_k = split_k
     a.alpha = alpha
+    _drop(a, drop)
     timed = TIMED is not None and TIMED["shape"] == (M, N, K)
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -51,7 +65,7 @@ def gemm_raw(A, B, Cout, M, N, K, a_rs, a_ks, b_rs, b_ks, c_rs, bias=None, a_grp
     return Cout
 
 
-def linear(x, w, bias=None, out=None, relu=False):
+def linear(x, w, bias=None, out=None, relu=False, drop=None):
     """y = x @ w.T + bias for x (..., K) with contiguous last dim and uniform row stride, w (N, K)."""
     _f32c(x, "x"); _f32c(w, "w")
     K = x.shape[-1]
@@ -63,11 +77,12 @@ def linear(x, w, bias=None, out=None, relu=False):
     if out is None:
         out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32)
     o2 = out.view(-1, N) if out.is_contiguous() else out
-    gemm_raw(x2, w, o2, M, N, K, x2.stride(0), 1, w.stride(0), 1, o2.stride(0), bias=bias, relu=relu)
+    gemm_raw(x2, w, o2, M, N, K, x2.stride(0), 1, w.stride(0), 1, o2.stride(0), bias=bias, relu=relu, drop=drop)
     return out
 
 
-def add_layernorm(x, res, gamma, beta, eps=1e-5, out=None, save_stats=False):
+def add_layernorm(x, res, gamma, beta, eps=1e-5, out=None, save_stats=False, drop=None):
+    """LayerNorm(dropout(x) + res) * gamma + beta (dropout only in training: drop = (p, seed, site))."""
     d = x.shape[-1]
     x2 = x.reshape(-1, d)
     r2 = None if res is None else res.reshape(-1, d)
@@ -81,13 +96,13 @@ def add_layernorm(x, res, gamma, beta, eps=1e-5, out=None, save_stats=False):
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
     L.check(L.load().ick_add_layernorm(_p(x2), _p(r2), _p(gamma), _p(beta), _p(o2), rows, d, eps, x2.stride(0),
                                        0 if r2 is None else r2.stride(0), o2.stride(0), _p(mean), _p(rstd),
-                                       _stream()), "ick_add_layernorm")
+                                       *_dargs(drop), _stream()), "ick_add_layernorm")
     out = out.view(x.shape)
     return (out, mean, rstd) if save_stats else out
 
 
 def attention_raw(Q, K, V, O, B, H, T, S, dh, q_bs, q_hs, q_ts, k_bs, k_hs, k_ss, v_bs, v_hs, v_ss, o_bs, o_ts,
-                  causal=False, q_pos0=0, kv_len=None, lse=None, q_off=0, k_off=0, v_off=0):
+                  causal=False, q_pos0=0, kv_len=None, lse=None, q_off=0, k_off=0, v_off=0, drop=None):
     """Strides in elements: batch / head / row for Q, K, V (see include/ick_amd.h); q_off/k_off/v_off are
     element offsets of the first (segment) inside a packed buffer."""
     a = L.AttnArgs()
@@ -102,6 +117,7 @@ def attention_raw(Q, K, V, O, B, H, T, S, dh, q_bs, q_hs, q_ts, k_bs, k_hs, k_ss
     a.o_bs, a.o_ts = o_bs, o_ts
     a.scale = 1.0 / math.sqrt(dh)
     a.causal, a.q_pos0, a.kv_len = int(causal), q_pos0, _p(kv_len)
+    _drop(a, drop)
     L.check(L.load().ick_attention(C.byref(a), _stream()), "ick_attention")
     return O
 
@@ -146,14 +162,14 @@ def project_heads(x, w, bias, nseg, H, S, out=None, s0=0, grp=None, a_gmap=None,
 
 
 def attention_heads(q, kv, O, H, dh, T, S, q_seg=0, k_seg=0, v_seg=1, causal=False, kv_len=None, q_pos0=0, q_t0=0,
-                    lse=None):
+                    lse=None, drop=None):
     """Attention over head-major buffers: q (B, nq, H, Tq_alloc, DHP), kv (B, nkv, H, S_alloc, DHP);
     the first T query rows starting at q_t0 attend to the first S key rows."""
     B = q.shape[0]
     Tq, Sa = q.shape[3], kv.shape[3]
     attention_raw(q, kv, kv, O, B, H, T, S, dh,
                   q.stride(0), Tq * DHP, DHP, kv.stride(0), Sa * DHP, DHP, kv.stride(0), Sa * DHP, DHP,
-                  O.stride(0), O.stride(1), causal=causal, q_pos0=q_pos0, kv_len=kv_len, lse=lse,
+                  O.stride(0), O.stride(1), causal=causal, q_pos0=q_pos0, kv_len=kv_len, lse=lse, drop=drop,
                   q_off=q_seg * H * Tq * DHP + q_t0 * DHP, k_off=k_seg * H * Sa * DHP, v_off=v_seg * H * Sa * DHP)
     return O
 
@@ -178,7 +194,7 @@ def fact_encode(facts, entities_encoded, pred_emb):
 
 
 def caption_embed(captions, masks, word_emb, entities_encoded, facts_encoded, pe, V, pad_token, scale, pos0=0,
-                  want_emb=False):
+                  want_emb=False, drop=None):
     B, Lc = captions.shape
     K, d = entities_encoded.shape[1], entities_encoded.shape[2]
     F = 0 if facts_encoded is None else facts_encoded.shape[1]
@@ -186,7 +202,7 @@ def caption_embed(captions, masks, word_emb, entities_encoded, facts_encoded, pe
     emb = torch.empty_like(out) if want_emb else None
     L.check(L.load().ick_caption_embed(_p(captions), _p(masks), _p(word_emb), _p(entities_encoded),
                                        _p(facts_encoded), _p(pe), _p(out), _p(emb), B, Lc, K, F, V, d, pad_token,
-                                       scale, pos0, _stream()), "ick_caption_embed")
+                                       scale, pos0, *_dargs(drop), _stream()), "ick_caption_embed")
     return (out, emb) if want_emb else out
 
 
@@ -253,7 +269,8 @@ def packed_ce(scores, captions_sorted, decode_len, pad_token, want_grad=False):
 # ------------------------------------------------------------------------------------------------
 # Backward / training-step wrappers
 # ------------------------------------------------------------------------------------------------
-def attention_heads_bwd(q, kv, O, dO, lse, dQ, dK, dV, H, dh, T, S, q_seg=0, k_seg=0, v_seg=1, causal=False):
+def attention_heads_bwd(q, kv, O, dO, lse, dQ, dK, dV, H, dh, T, S, q_seg=0, k_seg=0, v_seg=1, causal=False,
+                        drop=None):
     """Backward of attention_heads.  q (B,nq,H,Tq,DHP), kv (B,nkv,H,Sa,DHP); O/dO (B,T,d) row-major;
     dQ (B,T,*) / dK, dV (B,S,*) row-major views (last-dim stride 1; their column offset selects the
     segment), written as [h*dh + j]."""
@@ -275,22 +292,34 @@ def attention_heads_bwd(q, kv, O, dO, lse, dQ, dK, dV, H, dh, T, S, q_seg=0, k_s
     a.dv_bs, a.dv_ss = dV.stride(0), dV.stride(1)
     a.scale = 1.0 / math.sqrt(dh)
     a.causal, a.q_pos0 = int(causal), 0
+    _drop(a, drop)
     L.check(L.load().ick_attention_bwd(C.byref(a), _stream()), "ick_attention_bwd")
 
 
-def layernorm_bwd(dy, x, res, gamma, mean, rstd, dgamma, dbeta):
+def layernorm_bwd(dy, x, res, gamma, mean, rstd, dgamma, dbeta, drop=None):
+    """Returns (dz, dx): dz = gradient of the residual operand (and of z), dx = gradient of the operand the
+    forward applied dropout to (the same tensor as dz when there was no dropout)."""
     d = x.shape[-1]
     rows = x.numel() // d
     dz = torch.empty_like(x)
+    on = drop is not None and drop[0] > 0.0
+    dxd = torch.empty_like(x) if on else None
     L.check(L.load().ick_layernorm_bwd(_p(dy), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(dgamma),
-                                       _p(dbeta), rows, d, _stream()), "ick_layernorm_bwd")
-    return dz
+                                       _p(dbeta), rows, d, _p(dxd), *_dargs(drop), _stream()), "ick_layernorm_bwd")
+    return dz, (dxd if on else dz)
 
 
-def relu_bwd(dy, act, out=None):
+def relu_bwd(dy, act, out=None, scale=1.0):
     if out is None:
         out = torch.empty_like(dy)
-    L.check(L.load().ick_relu_bwd(_p(dy), _p(act), _p(out), dy.numel(), _stream()), "ick_relu_bwd")
+    L.check(L.load().ick_relu_bwd(_p(dy), _p(act), _p(out), dy.numel(), scale, _stream()), "ick_relu_bwd")
+    return out
+
+
+def dropout_mask(rows, cols, p, seed, site, device="cuda"):
+    out = torch.empty(rows, cols, device=device, dtype=torch.float32)
+    L.check(L.load().ick_dropout_mask(_p(out), rows, cols, p, seed & 0xFFFFFFFF, site & 0xFFFFFFFF, _stream()),
+            "ick_dropout_mask")
     return out
 
 
@@ -318,12 +347,12 @@ def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False):
     return dx
 
 
-def caption_embed_bwd(dx, captions, masks, dword, dee, dfe, V, pad_token, scale):
+def caption_embed_bwd(dx, captions, masks, dword, dee, dfe, V, pad_token, scale, drop=None):
     B, Lc = captions.shape
     K, d = dee.shape[1], dee.shape[2]
     F = 0 if dfe is None else dfe.shape[1]
     L.check(L.load().ick_caption_embed_bwd(_p(dx), _p(captions), _p(masks), _p(dword), _p(dee), _p(dfe), B, Lc, K, F,
-                                           V, d, pad_token, scale, _stream()), "ick_caption_embed_bwd")
+                                           V, d, pad_token, scale, *_dargs(drop), _stream()), "ick_caption_embed_bwd")
 
 
 def pointer_scores_bwd(dscores, col0, h, ctx, w, ind, dh, dctx, dw, dbias):

@@ -33,6 +33,20 @@ class Tape:
         self.misc = {}
 
 
+class DropSites:
+    """Hands out (p, seed, site) triples: one site id per dropout call site of a step, so the backward
+    kernels regenerate exactly the masks the forward used (ick_dropout_mask in include/ick_amd.h)."""
+
+    def __init__(self, seed, enabled):
+        self.seed, self.enabled, self.next = seed, enabled, 0
+
+    def site(self, p):
+        if not self.enabled or p <= 0.0:
+            return None
+        self.next += 1
+        return (float(p), self.seed, self.next)
+
+
 def _p(x):
     return x.detach()
 
@@ -40,58 +54,65 @@ def _p(x):
 # ----------------------------------------------------------------------------------------------
 # forward with saved activations
 # ----------------------------------------------------------------------------------------------
-def _context_encoder_fwd(dec, stack, x, tape_list):
+def _context_encoder_fwd(dec, stack, x, tape_list, ds):
     H, d = dec.num_heads, dec.emb_dim
     B, T, _ = x.shape
     for layer in stack.layers:
-        t = {"x": x}
+        p = layer.dropout.p
+        t = {"x": x, "d_att": ds.site(layer.self_attn.dropout), "d1": ds.site(layer.dropout1.p), "d_ff": ds.site(p),
+             "d2": ds.site(layer.dropout2.p)}
         t["qkv"] = ops.project_heads(x, _p(layer.self_attn.in_proj_weight), _p(layer.self_attn.in_proj_bias), 3, H, T)
         t["sa"] = torch.empty_like(x)
         t["lse"] = torch.empty(B * H * T, device=x.device, dtype=torch.float32)
-        ops.attention_heads(t["qkv"], t["qkv"], t["sa"], H, d // H, T, T, 0, 1, 2, lse=t["lse"])
+        ops.attention_heads(t["qkv"], t["qkv"], t["sa"], H, d // H, T, T, 0, 1, 2, lse=t["lse"], drop=t["d_att"])
         t["o1"] = ops.linear(t["sa"], _p(layer.self_attn.out_proj.weight), _p(layer.self_attn.out_proj.bias))
         t["x1"], t["m1"], t["r1"] = ops.add_layernorm(t["o1"], x, _p(layer.norm1.weight), _p(layer.norm1.bias),
-                                                      layer.norm1.eps, save_stats=True)
-        t["f"] = ops.linear(t["x1"], _p(layer.linear1.weight), _p(layer.linear1.bias), relu=True)
+                                                      layer.norm1.eps, save_stats=True, drop=t["d1"])
+        t["f"] = ops.linear(t["x1"], _p(layer.linear1.weight), _p(layer.linear1.bias), relu=True, drop=t["d_ff"])
         t["o2"] = ops.linear(t["f"], _p(layer.linear2.weight), _p(layer.linear2.bias))
         x, t["m2"], t["r2"] = ops.add_layernorm(t["o2"], t["x1"], _p(layer.norm2.weight), _p(layer.norm2.bias),
-                                                layer.norm2.eps, save_stats=True)
+                                                layer.norm2.eps, save_stats=True, drop=t["d2"])
         tape_list.append(t)
     return x
 
 
-def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list):
+def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds):
     H, d = dec.num_heads, dec.emb_dim
     dh = d // H
     B, T, _ = x.shape
-    t = {"x": x}
+    t = {"x": x, "d_sa": ds.site(layer.self_attn.dropout), "d1": ds.site(layer.dropout1.p),
+         "d_ca": ds.site(layer.multihead_attn.dropout), "d2": ds.site(layer.dropout2.p),
+         "d_ff": ds.site(layer.dropout.p), "d3": ds.site(layer.dropout3.p)}
     t["qkv"] = ops.project_heads(x, _p(layer.self_attn.in_proj_weight), _p(layer.self_attn.in_proj_bias), 3, H, T)
     t["sa"] = torch.empty_like(x)
     t["lse_s"] = torch.empty(B * H * T, device=x.device, dtype=torch.float32)
-    ops.attention_heads(t["qkv"], t["qkv"], t["sa"], H, dh, T, T, 0, 1, 2, causal=True, lse=t["lse_s"])
+    ops.attention_heads(t["qkv"], t["qkv"], t["sa"], H, dh, T, T, 0, 1, 2, causal=True, lse=t["lse_s"],
+                        drop=t["d_sa"])
     t["o1"] = ops.linear(t["sa"], _p(layer.self_attn.out_proj.weight), _p(layer.self_attn.out_proj.bias))
     t["x1"], t["m1"], t["r1"] = ops.add_layernorm(t["o1"], x, _p(layer.norm1.weight), _p(layer.norm1.bias),
-                                                  layer.norm1.eps, save_stats=True)
+                                                  layer.norm1.eps, save_stats=True, drop=t["d1"])
     ca_w, ca_b = _p(layer.multihead_attn.in_proj_weight), _p(layer.multihead_attn.in_proj_bias)
     t["qc"] = ops.project_heads(t["x1"], ca_w[:d], ca_b[:d], 1, H, T)
     t["ca"] = torch.empty_like(x)
     t["lse_c"] = torch.empty(B * H * T, device=x.device, dtype=torch.float32)
-    ops.attention_heads(t["qc"], kv, t["ca"], H, dh, T, S, 0, 2 * li, 2 * li + 1, lse=t["lse_c"])
+    ops.attention_heads(t["qc"], kv, t["ca"], H, dh, T, S, 0, 2 * li, 2 * li + 1, lse=t["lse_c"], drop=t["d_ca"])
     t["o2"] = ops.linear(t["ca"], _p(layer.multihead_attn.out_proj.weight), _p(layer.multihead_attn.out_proj.bias))
     t["x2"], t["m2"], t["r2"] = ops.add_layernorm(t["o2"], t["x1"], _p(layer.norm2.weight), _p(layer.norm2.bias),
-                                                  layer.norm2.eps, save_stats=True)
-    t["f"] = ops.linear(t["x2"], _p(layer.linear1.weight), _p(layer.linear1.bias), relu=True)
+                                                  layer.norm2.eps, save_stats=True, drop=t["d2"])
+    t["f"] = ops.linear(t["x2"], _p(layer.linear1.weight), _p(layer.linear1.bias), relu=True, drop=t["d_ff"])
     t["o3"] = ops.linear(t["f"], _p(layer.linear2.weight), _p(layer.linear2.bias))
     x, t["m3"], t["r3"] = ops.add_layernorm(t["o3"], t["x2"], _p(layer.norm3.weight), _p(layer.norm3.bias),
-                                            layer.norm3.eps, save_stats=True)
+                                            layer.norm3.eps, save_stats=True, drop=t["d3"])
     tape_list.append(t)
     return x
 
 
-def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gmap):
-    """Teacher-forced forward on already length-sorted inputs; returns (scores, tape)."""
+def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gmap, seed=0):
+    """Teacher-forced forward on already length-sorted inputs; returns (scores, tape).  Dropout is
+    active iff the module is in train() mode (masks derive from `seed`)."""
     tape = Tape()
     m = tape.misc
+    ds = DropSites(seed, dec.training)
     d, V, H = dec.emb_dim, dec.vocab_size, dec.num_heads
     B, L = captions.shape
     P, K = enc_tok.shape[1], entities.shape[1]
@@ -103,11 +124,11 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         Fn = facts.shape[1]
         fe = ops.fact_encode(facts, ee, _p(dec.predicate_embedding.weight))
     tape.enc_layers["entities"] = []
-    ctx_e = _context_encoder_fwd(dec, dec.transformer_encoder_entities, ee, tape.enc_layers["entities"])
+    ctx_e = _context_encoder_fwd(dec, dec.transformer_encoder_entities, ee, tape.enc_layers["entities"], ds)
     ctx_f = None
     if dec.has_facts:
         tape.enc_layers["facts"] = []
-        ctx_f = _context_encoder_fwd(dec, dec.transformer_encoder_facts, fe, tape.enc_layers["facts"])
+        ctx_f = _context_encoder_fwd(dec, dec.transformer_encoder_facts, fe, tape.enc_layers["facts"], ds)
     # contiguous memory (B, S, d): the K/V projection and its weight gradient are then plain GEMMs
     img = enc_tok.index_select(0, gmap.long()) if gmap is not None else enc_tok
     mem = torch.cat([img, ctx_e] + ([ctx_f] if dec.has_facts else []), dim=1)
@@ -116,10 +137,11 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     nseg = wkv.shape[0] // d
     kv = ops.project_heads(mem, wkv, bkv, nseg, H, S)
     pe = dec.pos_encoder.pe.view(-1, d)
+    m["d_pos"] = ds.site(dec.pos_encoder.dropout.p)
     x = ops.caption_embed(captions, caption_masks, _p(dec.word_embedding.weight), ee, fe, pe, V,
-                          dec.word_map["<pad>"], math.sqrt(d))
+                          dec.word_map["<pad>"], math.sqrt(d), drop=m["d_pos"])
     for li, layer in enumerate(dec.transformer_decoder.layers):
-        x = _decoder_layer_fwd(dec, li, layer, x, kv, S, tape.dec_layers)
+        x = _decoder_layer_fwd(dec, li, layer, x, kv, S, tape.dec_layers, ds)
     eib = gate = hv = None
     if dec.has_facts:
         eib, gate = ops.context_indicators(captions, facts, K, V, dec._pred_wt(), _p(dec.fc_predicate.bias), mode=0)
@@ -139,6 +161,10 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
 # ----------------------------------------------------------------------------------------------
 # backward
 # ----------------------------------------------------------------------------------------------
+def _keep_scale(drop):
+    return 1.0 if drop is None else 1.0 / (1.0 - drop[0])
+
+
 def _g(grads, param):
     """Gradient buffer of a parameter (None when it is frozen)."""
     return grads.get(id(param))
@@ -160,19 +186,19 @@ def _context_encoder_bwd(dec, stack, tapes, dx, grads):
     for layer, t in zip(reversed(list(stack.layers)), reversed(tapes)):
         B, T, _ = t["x"].shape
         M = B * T
-        dz = ops.layernorm_bwd(dx, t["o2"], t["x1"], _p(layer.norm2.weight), t["m2"], t["r2"],
-                               _g(grads, layer.norm2.weight), _g(grads, layer.norm2.bias))
-        df = _lin_bwd(grads, dz.view(M, d), t["f"].view(M, -1), layer.linear2.weight, layer.linear2.bias)
-        dpre = ops.relu_bwd(df, t["f"].view(M, -1))
+        dz, do2 = ops.layernorm_bwd(dx, t["o2"], t["x1"], _p(layer.norm2.weight), t["m2"], t["r2"],
+                                    _g(grads, layer.norm2.weight), _g(grads, layer.norm2.bias), drop=t["d2"])
+        df = _lin_bwd(grads, do2.view(M, d), t["f"].view(M, -1), layer.linear2.weight, layer.linear2.bias)
+        dpre = ops.relu_bwd(df, t["f"].view(M, -1), scale=_keep_scale(t["d_ff"]))
         dx1 = _lin_bwd(grads, dpre, t["x1"].view(M, d), layer.linear1.weight, layer.linear1.bias, dx=dz.view(M, d),
                        acc=True)
-        dz = ops.layernorm_bwd(dx1.view(B, T, d), t["o1"], t["x"], _p(layer.norm1.weight), t["m1"], t["r1"],
-                               _g(grads, layer.norm1.weight), _g(grads, layer.norm1.bias))
-        dsa = _lin_bwd(grads, dz.view(M, d), t["sa"].view(M, d), layer.self_attn.out_proj.weight,
+        dz, do1 = ops.layernorm_bwd(dx1.view(B, T, d), t["o1"], t["x"], _p(layer.norm1.weight), t["m1"], t["r1"],
+                                    _g(grads, layer.norm1.weight), _g(grads, layer.norm1.bias), drop=t["d1"])
+        dsa = _lin_bwd(grads, do1.view(M, d), t["sa"].view(M, d), layer.self_attn.out_proj.weight,
                        layer.self_attn.out_proj.bias)
         dqkv = torch.zeros(B, T, 3 * d, device=dx.device, dtype=torch.float32)
         ops.attention_heads_bwd(t["qkv"], t["qkv"], t["sa"], dsa.view(B, T, d), t["lse"], dqkv[:, :, :d],
-                                dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:], H, d // H, T, T, 0, 1, 2)
+                                dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:], H, d // H, T, T, 0, 1, 2, drop=t["d_att"])
         dx = _lin_bwd(grads, dqkv.view(M, 3 * d), t["x"].view(M, d), layer.self_attn.in_proj_weight,
                       layer.self_attn.in_proj_bias, dx=dz.view(M, d), acc=True).view(B, T, d)
     return dx
@@ -183,29 +209,30 @@ def _decoder_layer_bwd(dec, li, layer, t, dx, dkv_rows, kv, S, grads):
     dh = d // H
     B, T, _ = t["x"].shape
     M = B * T
-    dz = ops.layernorm_bwd(dx, t["o3"], t["x2"], _p(layer.norm3.weight), t["m3"], t["r3"],
-                           _g(grads, layer.norm3.weight), _g(grads, layer.norm3.bias))
-    df = _lin_bwd(grads, dz.view(M, d), t["f"].view(M, -1), layer.linear2.weight, layer.linear2.bias)
-    dpre = ops.relu_bwd(df, t["f"].view(M, -1))
+    dz, do3 = ops.layernorm_bwd(dx, t["o3"], t["x2"], _p(layer.norm3.weight), t["m3"], t["r3"],
+                                _g(grads, layer.norm3.weight), _g(grads, layer.norm3.bias), drop=t["d3"])
+    df = _lin_bwd(grads, do3.view(M, d), t["f"].view(M, -1), layer.linear2.weight, layer.linear2.bias)
+    dpre = ops.relu_bwd(df, t["f"].view(M, -1), scale=_keep_scale(t["d_ff"]))
     dx2 = _lin_bwd(grads, dpre, t["x2"].view(M, d), layer.linear1.weight, layer.linear1.bias, dx=dz.view(M, d),
                    acc=True)
-    dz = ops.layernorm_bwd(dx2.view(B, T, d), t["o2"], t["x1"], _p(layer.norm2.weight), t["m2"], t["r2"],
-                           _g(grads, layer.norm2.weight), _g(grads, layer.norm2.bias))
-    dca = _lin_bwd(grads, dz.view(M, d), t["ca"].view(M, d), layer.multihead_attn.out_proj.weight,
+    dz, do2 = ops.layernorm_bwd(dx2.view(B, T, d), t["o2"], t["x1"], _p(layer.norm2.weight), t["m2"], t["r2"],
+                                _g(grads, layer.norm2.weight), _g(grads, layer.norm2.bias), drop=t["d2"])
+    dca = _lin_bwd(grads, do2.view(M, d), t["ca"].view(M, d), layer.multihead_attn.out_proj.weight,
                    layer.multihead_attn.out_proj.bias)
     dq = torch.empty(B, T, d, device=dx.device, dtype=torch.float32)
     c0 = 2 * li * d
     ops.attention_heads_bwd(t["qc"], kv, t["ca"], dca.view(B, T, d), t["lse_c"], dq, dkv_rows[:, :, c0:c0 + d],
-                            dkv_rows[:, :, c0 + d:c0 + 2 * d], H, dh, T, S, 0, 2 * li, 2 * li + 1)
+                            dkv_rows[:, :, c0 + d:c0 + 2 * d], H, dh, T, S, 0, 2 * li, 2 * li + 1, drop=t["d_ca"])
     dx1 = _lin_bwd(grads, dq.view(M, d), t["x1"].view(M, d), layer.multihead_attn.in_proj_weight,
                    layer.multihead_attn.in_proj_bias, w_rows=slice(0, d), dx=dz.view(M, d), acc=True)
-    dz = ops.layernorm_bwd(dx1.view(B, T, d), t["o1"], t["x"], _p(layer.norm1.weight), t["m1"], t["r1"],
-                           _g(grads, layer.norm1.weight), _g(grads, layer.norm1.bias))
-    dsa = _lin_bwd(grads, dz.view(M, d), t["sa"].view(M, d), layer.self_attn.out_proj.weight,
+    dz, do1 = ops.layernorm_bwd(dx1.view(B, T, d), t["o1"], t["x"], _p(layer.norm1.weight), t["m1"], t["r1"],
+                                _g(grads, layer.norm1.weight), _g(grads, layer.norm1.bias), drop=t["d1"])
+    dsa = _lin_bwd(grads, do1.view(M, d), t["sa"].view(M, d), layer.self_attn.out_proj.weight,
                    layer.self_attn.out_proj.bias)
     dqkv = torch.zeros(B, T, 3 * d, device=dx.device, dtype=torch.float32)
     ops.attention_heads_bwd(t["qkv"], t["qkv"], t["sa"], dsa.view(B, T, d), t["lse_s"], dqkv[:, :, :d],
-                            dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:], H, dh, T, T, 0, 1, 2, causal=True)
+                            dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:], H, dh, T, T, 0, 1, 2, causal=True,
+                            drop=t["d_sa"])
     return _lin_bwd(grads, dqkv.view(M, 3 * d), t["x"].view(M, d), layer.self_attn.in_proj_weight,
                     layer.self_attn.in_proj_bias, dx=dz.view(M, d), acc=True).view(B, T, d)
 
@@ -281,7 +308,8 @@ def backward_from_tape(dec, tape, dscores, grads):
         dfe += dfe_enc
     # ---- caption embedding, fact encoder, entity encoder
     gword = _g(grads, dec.word_embedding.weight)
-    ops.caption_embed_bwd(dx, m["captions"], m["masks"], gword, dee, dfe, V, dec.word_map["<pad>"], math.sqrt(d))
+    ops.caption_embed_bwd(dx, m["captions"], m["masks"], gword, dee, dfe, V, dec.word_map["<pad>"], math.sqrt(d),
+                          drop=m["d_pos"])
     if dec.has_facts:
         ops.fact_encode_bwd(dfe, m["facts"], dee, gbuf(dec.predicate_embedding.weight))
     ops.entity_encode_bwd(dec.variant, dee, m["entities"], ee, gbuf(dec.entity_encoder.type_embedding.weight),
@@ -295,7 +323,9 @@ def backward_from_tape(dec, tape, dscores, grads):
 class DecoderGraphFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dec, captions, masks, entities, facts, enc_tok, gmap, *params):
-        scores, tape = forward_with_tape(dec, captions, masks, entities, facts, enc_tok, gmap)
+        dec.__dict__["_drop_step"] = dec.__dict__.get("_drop_step", 0) + 1
+        seed = (dec.__dict__.get("_drop_seed", 0x1234567) * 2654435761 + dec.__dict__["_drop_step"]) & 0xFFFFFFFF
+        scores, tape = forward_with_tape(dec, captions, masks, entities, facts, enc_tok, gmap, seed=seed)
         ctx.dec, ctx.tape, ctx.params = dec, tape, params
         return scores
 
@@ -327,8 +357,9 @@ class TrainStep:
     all-reduce(sum) the bucket is divided by the global token count, clamped to +-grad_clip
     (geo-aware/train.py:287-288 clamps the full-batch gradient) and fed to Adam (lr 4e-4)."""
 
-    def __init__(self, decoder, lr=4e-4, grad_clip=5.0, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+    def __init__(self, decoder, lr=4e-4, grad_clip=5.0, betas=(0.9, 0.999), eps=1e-8, process_group=None, seed=0):
         self.dec = decoder
+        self.seed = seed  # dropout mask stream; give every rank its own seed
         self.lr, self.clip, self.betas, self.eps = lr, grad_clip, betas, eps
         self.pg = process_group
         self.step_count = 0
@@ -366,8 +397,9 @@ class TrainStep:
         enc_tok = dec._token_major(encoder_out)
         decode_len = (lengths - 1).to(torch.int32).to(dev)
         self.flat_g.zero_()
+        seed = (self.seed * 2654435761 + self.step_count + 1) & 0xFFFFFFFF
         scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok,
-                                         sort_dev.to(torch.int32))
+                                         sort_dev.to(torch.int32), seed=seed)
         loss_sum, count, dscores = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True)
         backward_from_tape(dec, tape, dscores, self.grads)
         self.flat_g[self.n:self.n + 1].copy_(loss_sum)

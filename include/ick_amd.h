@@ -63,6 +63,7 @@ typedef struct {
     int32_t split_k;       /* >1: K is split over blockIdx.z, partial sums added atomically */
     float   alpha;         /* scales the product before bias (1.0f normally) */
     int32_t hs_dh, hs_dhp, hs_H, hs_S, hs_s0;   /* head-split epilogue, see above (hs_dh == 0: off) */
+    float drop_p; uint32_t drop_seed, drop_site; /* training dropout on the output (after bias/ReLU), see ick_dropout_mask */
 } ick_gemm_args;
 
 #define ICK_GEMM_RELU 1
@@ -78,7 +79,9 @@ int ick_gemm(const ick_gemm_args* args, void* stream);
 int ick_add_layernorm(const float* x, const float* res, const float* gamma, const float* beta,
                       float* y, int64_t rows, int32_t d, float eps,
                       int64_t x_ld, int64_t res_ld, int64_t y_ld,
-                      float* save_mean, float* save_rstd, void* stream);
+                      float* save_mean, float* save_rstd,
+                      float drop_p, uint32_t drop_seed, uint32_t drop_site, /* dropout applied to x (dropout1/2/3) */
+                      void* stream);
 
 /* Multi-head attention core: O = softmax(Q K^T * scale [+ causal mask]) V per (batch, head).
  * Q element (b,t,h,j) at Q[b*q_bs + h*q_hs + t*q_ts + j]; K/V element (b,s,h,j) at
@@ -96,6 +99,7 @@ typedef struct {
     int32_t B, H, T, S, dh;
     int64_t q_bs, q_hs, q_ts, k_bs, k_hs, k_ss, v_bs, v_hs, v_ss, o_bs, o_ts;
     float scale; int32_t causal; int32_t q_pos0; const int32_t* kv_len;
+    float drop_p; uint32_t drop_seed, drop_site;   /* attention-weight dropout (training), element index ((b*H+h)*T+t)*S+s */
 } ick_attn_args;
 int ick_attention(const ick_attn_args* args, void* stream);
 
@@ -125,7 +129,9 @@ int ick_fact_encode(const int64_t* facts, const float* entities_encoded, const f
 int ick_caption_embed(const int64_t* captions, const int64_t* masks, const float* word_emb,
                       const float* entities_encoded, const float* facts_encoded, const float* pe,
                       float* out, float* emb_out, int32_t B, int32_t L, int32_t K, int32_t F, int32_t V,
-                      int32_t d, int32_t pad_token, float scale, int32_t pos0, void* stream);
+                      int32_t d, int32_t pad_token, float scale, int32_t pos0,
+                      float drop_p, uint32_t drop_seed, uint32_t drop_site, /* PositionEncoder dropout (training) */
+                      void* stream);
 
 /* get_context_indicators: knowledge-aware/models.py:380-418.  Produces, per (b, position p):
  *   eib (B,T,F) 0/1: subject of fact j was mentioned before p (T==L) / anywhere so far (T==1)
@@ -146,6 +152,12 @@ int ick_context_indicators(const int64_t* captions, const int64_t* facts, const 
 int ick_pointer_scores(const float* h, const float* ctx, const float* w, const float* bias,
                        const float* ind, float* out, int32_t B, int32_t T, int32_t Kc, int32_t d,
                        int64_t out_ld, int32_t col0, const int32_t* out_gmap, void* stream);
+
+/* Training dropout (nn.Dropout / MultiheadAttention(dropout=p) sites of the reference's layers): every
+ * kernel that drops takes (p, seed, site); element `idx` of a site is kept iff
+ * murmur3_fmix(idx * 0x9E3779B1 ^ (seed + site * 0x85EBCA6B)) >= p * 2^32 and scaled by 1/(1-p), so the
+ * backward kernels regenerate the mask.  This entry writes that mask (rows x cols, idx = r*cols + c). */
+int ick_dropout_mask(float* out, int64_t rows, int32_t cols, float p, uint32_t seed, uint32_t site, void* stream);
 
 /* elementwise y = a * b  (vocab_input = h * gate, knowledge-aware/models.py:437) */
 int ick_mul(const float* a, const float* b, float* y, int64_t n, void* stream);
@@ -192,21 +204,25 @@ typedef struct {
     int64_t q_bs, q_hs, q_ts, k_bs, k_hs, k_ss, v_bs, v_hs, v_ss, o_bs, o_ts;
     int64_t dq_bs, dq_ts, dk_bs, dk_ss, dv_bs, dv_ss;
     float scale; int32_t causal; int32_t q_pos0;
+    float drop_p; uint32_t drop_seed, drop_site;   /* must equal the forward's */
 } ick_attn_bwd_args;
 int ick_attention_bwd(const ick_attn_bwd_args* args, void* stream);
 
 /* dz = dLN/d(x+res) ; dgamma += ..., dbeta += ... (accumulated with float atomics). */
 int ick_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma, const float* mean,
                       const float* rstd, float* dz, float* dgamma, float* dbeta, int64_t rows, int32_t d,
-                      void* stream);
+                      float* dx_drop /* dz * mask: gradient of the dropped operand x (drop_p > 0) */,
+                      float drop_p, uint32_t drop_seed, uint32_t drop_site, void* stream);
 /* dx = dy where the forward ReLU output `act` was positive, else 0. */
-int ick_relu_bwd(const float* dy, const float* act, float* dx, int64_t n, void* stream);
+int ick_relu_bwd(const float* dy, const float* act, float* dx, int64_t n, float scale /* 1/(1-p) of the FFN dropout */,
+                 void* stream);
 /* out[n] += sum_m a[m*ld + n]  (bias gradients). */
 int ick_colsum(const float* a, int64_t M, int32_t N, int64_t ld, float* out, void* stream);
 /* Backward of ick_caption_embed: dx*scale is scatter-added to word_emb / entity / fact gradient rows. */
 int ick_caption_embed_bwd(const float* dx, const int64_t* captions, const int64_t* masks, float* dword,
                           float* dee, float* dfe, int32_t B, int32_t L, int32_t K, int32_t F, int32_t V,
-                          int32_t d, int32_t pad_token, float scale, void* stream);
+                          int32_t d, int32_t pad_token, float scale, float drop_p, uint32_t drop_seed,
+                          uint32_t drop_site, void* stream);
 /* Backward of ick_pointer_scores: ds = dscores[..., col0:col0+Kc] (row stride ds_ld);
  * dh += ..., dctx += ..., dw += ..., dbias += ... */
 int ick_pointer_scores_bwd(const float* ds, int64_t ds_ld, int32_t col0, const float* h, const float* ctx,

@@ -33,7 +33,8 @@ def test_layernorm_bwd(ops):
     F.layer_norm(xr + rr, (d,), gr, br, 1e-5).backward(dy.double())
     y, mean, rstd = ops.add_layernorm(dev(x), dev(r), dev(g), dev(b), save_stats=True)
     dg, db = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
-    dz = ops.layernorm_bwd(dev(dy), dev(x), dev(r), dev(g), mean, rstd, dg, db)
+    dz, dxd = ops.layernorm_bwd(dev(dy), dev(x), dev(r), dev(g), mean, rstd, dg, db)
+    assert dxd is dz
     close(dz, xr.grad, 5e-6, "ln dz")
     close(dg, gr.grad, 2e-5, "ln dgamma")
     close(db, br.grad, 2e-5, "ln dbeta")
@@ -142,7 +143,112 @@ def test_adam_clamp_matches_torch(ops):
         close(p, pt.detach(), 2e-6, "adam step %d" % step)
 
 
+# ------------------------------------------------------------------------------- dropout
+def test_dropout_mask_statistics_and_determinism(ops):
+    m1 = ops.dropout_mask(1280, 300, 0.5, 1234, 7)
+    m2 = ops.dropout_mask(1280, 300, 0.5, 1234, 7)
+    m3 = ops.dropout_mask(1280, 300, 0.5, 1234, 8)
+    assert torch.equal(m1, m2) and not torch.equal(m1, m3)
+    vals = set(m1.unique().tolist())
+    assert vals == {0.0, 2.0}
+    keep = (m1 > 0).float().mean().item()
+    assert abs(keep - 0.5) < 0.01
+    m4 = ops.dropout_mask(1280, 300, 0.1, 99, 1)
+    assert abs((m4 > 0).float().mean().item() - 0.9) < 0.01
+    assert abs(m4.max().item() - 1 / 0.9) < 1e-6
+    # neighbouring elements are uncorrelated
+    a = (m1[:, :-1] > 0).float() - 0.5
+    b = (m1[:, 1:] > 0).float() - 0.5
+    assert abs((a * b).mean().item()) < 0.01
+
+
+def test_dropout_sites_match_their_mask(ops):
+    """Every dropping kernel (GEMM epilogue, add_layernorm, attention fwd/bwd) against torch math that uses
+    the mask reported by ick_dropout_mask for the same (p, seed, site)."""
+    M, N, K, d = 130, 512, 300, 300
+    drop = (0.5, 4242, 3)
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
+    mask = ops.dropout_mask(M, N, *drop).cpu().double()
+    y = ops.linear(dev(x), dev(w), dev(b), relu=True, drop=drop)
+    close(y, F.relu(F.linear(x.double(), w.double(), b.double())) * mask, 2e-5, "gemm relu dropout")
+    # add_layernorm + backward
+    rows = 130
+    xx, r, g, be, dy = rnd(rows, d, seed=4), rnd(rows, d, seed=5), 1 + rnd(d, seed=6, scale=0.1), rnd(d, seed=7), \
+        rnd(rows, d, seed=8)
+    drop2 = (0.3, 77, 5)
+    m2 = ops.dropout_mask(rows, d, *drop2).cpu().double()
+    xr, rr, gr, br = (v.double().requires_grad_(True) for v in (xx, r, g, be))
+    ref = F.layer_norm(xr * m2 + rr, (d,), gr, br, 1e-5)
+    ref.backward(dy.double())
+    yy, mean, rstd = ops.add_layernorm(dev(xx), dev(r), dev(g), dev(be), save_stats=True, drop=drop2)
+    close(yy, ref.detach(), 5e-6, "ln dropout fwd")
+    dg, db = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+    dz, dxd = ops.layernorm_bwd(dev(dy), dev(xx), dev(r), dev(g), mean, rstd, dg, db, drop=drop2)
+    close(dz, rr.grad, 5e-6, "ln dropout dres")
+    close(dxd, xr.grad, 5e-6, "ln dropout dx")
+    close(dg, gr.grad, 2e-5, "ln dropout dgamma")
+    # attention with weight dropout
+    B, T, S, H = 2, 20, 216, 10
+    dh = d // H
+    drop3 = (0.5, 31337, 9)
+    q0, mem, do = rnd(B, T, d, seed=9), rnd(B, S, d, seed=10), rnd(B, T, d, seed=11)
+    wq, wkv = rnd(d, d, seed=12, scale=0.1), rnd(2 * d, d, seed=13, scale=0.1)
+    qh = ops.project_heads(dev(q0), dev(wq), None, 1, H, T)
+    kvh = ops.project_heads(dev(mem), dev(wkv), None, 2, H, S)
+    out = torch.empty(B, T, d, device="cuda")
+    lse = torch.empty(B * H * T, device="cuda")
+    ops.attention_heads(qh, kvh, out, H, dh, T, S, 0, 0, 1, lse=lse, drop=drop3)
+    m3 = ops.dropout_mask(B * H * T, S, *drop3).cpu().double().view(B, H, T, S)
+    qr = (q0.double() @ wq.double().t()).requires_grad_(True)
+    kvr = mem.double() @ wkv.double().t()
+    kr, vr = kvr[..., :d].clone().requires_grad_(True), kvr[..., d:].clone().requires_grad_(True)
+    att = (qr.view(B, T, H, dh).transpose(1, 2) @ kr.view(B, S, H, dh).transpose(1, 2).transpose(-1, -2)) / math.sqrt(dh)
+    ref = ((att.softmax(-1) * m3) @ vr.view(B, S, H, dh).transpose(1, 2)).transpose(1, 2).reshape(B, T, d)
+    ref.backward(do.double())
+    close(out, ref.detach(), 1e-5, "attn dropout fwd")
+    dq = torch.zeros(B, T, d, device="cuda")
+    dkv = torch.zeros(B, S, 2 * d, device="cuda")
+    ops.attention_heads_bwd(qh, kvh, out, dev(do), lse, dq, dkv[:, :, :d], dkv[:, :, d:], H, dh, T, S, 0, 0, 1,
+                            drop=drop3)
+    close(dq, qr.grad, 2e-5, "attn dropout dq")
+    close(dkv[:, :, :d], kr.grad, 2e-5, "attn dropout dk")
+    close(dkv[:, :, d:], vr.grad, 2e-5, "attn dropout dv")
+
+
+def test_training_with_reference_dropout_reduces_loss():
+    """The reference's training configuration (dropout 0.5/0.5/0.1, geo-aware/models.py:219): a few fused
+    steps on a fixed batch must drive the loss down, and eval-mode scores stay finite."""
+    from ick_amd.training import TrainStep
+    variant, B, L, K, V, seed = "geo", 16, 12, 8, 200, 8
+    m = ick_amd.load_models(variant)
+    torch.manual_seed(0)
+    dec = m.DecoderTransformer(synth.make_word_map(V), 300, 512, 512, 10, 3)   # default dropouts
+    dec.load_state_dict(synth.make_params(variant, V, seed), strict=False)
+    dec = dec.cuda().train()
+    batch = synth.make_batch(variant, B, L, K, V, 0, seed)
+    enc_out = synth.make_enc_out(B, seed).cuda()
+    ts = TrainStep(dec, lr=4e-4, seed=3)
+    losses = [ts(batch["captions"].cuda(), enc_out, batch["caption_masks"].cuda(), batch["caption_lengths"].cuda(),
+                 batch["entities"]).item() for _ in range(30)]
+    assert all(math.isfinite(v) for v in losses)
+    assert sum(losses[-5:]) / 5 < sum(losses[:5]) / 5 - 0.3, losses
+    dec.eval()
+    with torch.no_grad():
+        sc, _, _ = dec(batch["captions"].cuda(), enc_out, batch["caption_masks"].cuda(),
+                       batch["caption_lengths"].cuda(), batch["entities"])
+    assert torch.isfinite(sc).all()
+
+
 # ------------------------------------------------------------------------------- whole model
+def zero_dropout(dec):
+    for mod in dec.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    return dec
+
+
 def reference_loss(scores, caps_sorted, dl, pad):
     targets = caps_sorted[:, 1:]
     sp = pack_padded_sequence(scores, dl, batch_first=True).data
@@ -205,15 +311,7 @@ def test_train_step_matches_reference_sequence_and_dp_split():
         p.grad.clamp_(-5.0, 5.0)
     opt.step()
     # fused step
-    dec = build_decoder(variant, V, P).train()
-    for mod in dec.modules():
-        if isinstance(mod, torch.nn.Dropout):
-            mod.p = 0.0
-    for layer in list(dec.transformer_decoder.layers) + list(dec.transformer_encoder_entities.layers) + \
-            list(dec.transformer_encoder_facts.layers):
-        for att in (getattr(layer, "self_attn", None), getattr(layer, "multihead_attn", None)):
-            if att is not None:
-                att.dropout = 0.0
+    dec = zero_dropout(build_decoder(variant, V, P).train())
     ts = TrainStep(dec, lr=4e-4, grad_clip=5.0)
     loss = ts(batch["captions"].cuda(), enc_out.cuda(), batch["caption_masks"].cuda(),
               batch["caption_lengths"].cuda(), batch["entities"], batch["facts"].cuda())
@@ -225,10 +323,7 @@ def test_train_step_matches_reference_sequence_and_dp_split():
         err = (named[k].detach().cpu() - pr.detach()).abs().max().item()
         assert err < 5e-5, (k, err)   # Adam's first step moves every weight by ~lr=4e-4: a wrong gradient shows
     # ---- DP: two ranks, half the batch each; sum of the unnormalised buckets == full-batch bucket
-    dec2 = build_decoder(variant, V, P).train()
-    for mod in dec2.modules():
-        if isinstance(mod, torch.nn.Dropout):
-            mod.p = 0.0
+    dec2 = zero_dropout(build_decoder(variant, V, P).train())
     full = TrainStep(dec2, lr=4e-4)
     buckets = []
     for lo in (0, 3):
