@@ -3,11 +3,14 @@
     python bench.py [--gpus N --steps K --warmup W] [--mode forward|greedy] [--config cfg2]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One *step* = one pass of the hot path over one batch of synthetic input resident in HBM:
-mode forward (default) = Encoder.conv1 feature projection + DecoderTransformer.forward (teacher
-forced, exactly what train.py / validate() call) on cfg2 = B 64 x L 20 decode positions, 14x14x2048
-features, K=20 knowledge rows, vocab 10k => 1280 decode-steps per step and per GPU (weak scaling:
-every rank owns its own 64-sample shard; the forward path has no collective).
+One *step* = one pass of the hot path over one batch of synthetic input resident in HBM, on cfg2 =
+B 64 x L 20 decode positions, 14x14x2048 features, K=20 knowledge rows, vocab 10k => 1280 decode-steps
+per step and per GPU (weak scaling: every rank owns its own 64-sample shard):
+  --mode train (default)  Encoder.conv1 + DecoderTransformer forward + packed cross entropy + backward +
+                          ONE all-reduce of the flat gradient bucket (RCCL) + clamp + Adam: the body of
+                          train.py's loop (geo-aware/train.py:269-292), dropout on as the reference has it
+  --mode forward          Encoder.conv1 + teacher-forced forward only (validate(), no collective)
+  --mode greedy           Encoder.conv1 + predict() greedy decode, KV-cached (eval.py path; cfg5)
 Rank 0 prints ONE JSON line with the whole-job rate plus
   roofline      the dominant kernel (fp32 MFMA GEMM of the feature projection) timed with HIP events
                 on its launch stream inside the timed region, against the 157.3 TFLOP/s fp32 matrix peak
@@ -34,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", default="forward", choices=["forward", "greedy"])
+    ap.add_argument("--mode", default="train", choices=["train", "forward", "greedy"])
     ap.add_argument("--config", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -60,8 +63,10 @@ def usable_cores():
     return int(os.environ.get("ICK_CPU_THREADS", min(n, 16)))
 
 
-def cpu_baseline(cfg, seed, budget_s):
-    """Time the oracle's stock-module port of the reference on the host cores (same seeded workload)."""
+def cpu_baseline(cfg, seed, budget_s, mode="forward"):
+    """Time the oracle's stock-module port of the reference on the host cores (same seeded workload):
+    forward = conv1 + teacher-forced forward (eval); train = conv1 + forward + CE + backward + clamp + Adam
+    with the reference's default dropouts (train.py never passes its own, geo-aware/train.py:71-78)."""
     import ick_amd.synth as synth
     from oracle.stock import StockDecoder
     variant, B, L, K, V, Fn = cfg["variant"], cfg["B"], cfg["L"], cfg["K"], cfg["V"], cfg["F"]
@@ -69,15 +74,35 @@ def cpu_baseline(cfg, seed, budget_s):
     torch.set_num_threads(cores)
     P = synth.make_params(variant, V, seed)
     cw, cb = synth.make_conv1(seed)
-    m = StockDecoder(variant, synth.make_word_map(V)).load_reference_params(P, cw, cb).eval()
+    wm = synth.make_word_map(V)
     batch = synth.make_batch(variant, B, L, K, V, Fn, seed)
     feats = synth.make_feats(B, seed)
+    if mode == "train":
+        from oracle import restatement as R
+        m = StockDecoder(variant, wm, dropout=0.5).load_reference_params(P, cw, cb).train()
+        params = [p for n, p in m.named_parameters() if not n.startswith("conv1")]
+        opt = torch.optim.Adam(params, lr=4e-4)
 
-    def one():
-        with torch.no_grad():
-            enc = m.encode_image(feats)
-            return m(batch["captions"], enc, batch["caption_masks"], batch["caption_lengths"], batch["entities"],
-                     batch.get("facts"))
+        def one():
+            with torch.no_grad():
+                enc = m.encode_image(feats)
+            scores, caps, dl = m(batch["captions"], enc, batch["caption_masks"], batch["caption_lengths"],
+                                 batch["entities"], batch.get("facts"))
+            loss = R.packed_ce_loss(m.cfg, scores, caps, dl)
+            opt.zero_grad()
+            loss.backward()
+            for p in params:
+                if p.grad is not None:
+                    p.grad.clamp_(-5.0, 5.0)
+            opt.step()
+    else:
+        m = StockDecoder(variant, wm).load_reference_params(P, cw, cb).eval()
+
+        def one():
+            with torch.no_grad():
+                enc = m.encode_image(feats)
+                return m(batch["captions"], enc, batch["caption_masks"], batch["caption_lengths"], batch["entities"],
+                         batch.get("facts"))
 
     one()
     one()
@@ -89,8 +114,9 @@ def cpu_baseline(cfg, seed, budget_s):
         times.append(time.time() - t0)
     best = min(times)
     return {"value": B * L / best, "unit": "decode-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d full %s passes (conv1 + teacher-forced forward, B=%d L=%d V=%d) in %.1f s; best pass %.1f ms"
-                      % (len(times), variant, B, L, V, sum(times), best * 1e3),
+            "sample": "%d full %s %s passes (B=%d L=%d V=%d) in %.1f s; best pass %.1f ms"
+                      % (len(times), variant, "train steps (conv1 + fwd + CE + bwd + clamp + Adam, dropout on)"
+                         if mode == "train" else "conv1 + teacher-forced forward", B, L, V, sum(times), best * 1e3),
             "threads": torch.get_num_threads()}
 
 
@@ -119,7 +145,8 @@ def main():
     m = ick_amd.load_models(variant)
     dec = m.DecoderTransformer(synth.make_word_map(V), 300, 512, 512, 10, 3)
     dec.load_state_dict(synth.make_params(variant, V, 0), strict=False)  # same weights on every rank
-    dec = dec.cuda().eval()
+    dec = dec.cuda()
+    dec = dec.train() if args.mode == "train" else dec.eval()
     enc = m.Encoder(emb_dim=300)
     cw, cb = synth.make_conv1(0)
     with torch.no_grad():
@@ -130,11 +157,22 @@ def main():
     feats = synth.make_feats(B, seed).cuda()
     extra = [batch["facts"]] if variant != "geo" else []
 
-    if args.mode == "forward":
+    if args.mode == "train":
+        from ick_amd.training import TrainStep
+        ts = TrainStep(dec, lr=4e-4, grad_clip=5.0, seed=rank)   # all-reduces its bucket when world > 1
+
         def step():
-            e = enc(feats)
-            return dec(batch["captions"], e, batch["caption_masks"], batch["caption_lengths"], batch["entities"],
-                       *extra)
+            with torch.no_grad():
+                e = enc(feats)
+            return ts(batch["captions"], e, batch["caption_masks"], batch["caption_lengths"], batch["entities"],
+                      *extra)
+        units_per_step = B * L
+    elif args.mode == "forward":
+        def step():
+            with torch.no_grad():
+                e = enc(feats)
+                return dec(batch["captions"], e, batch["caption_masks"], batch["caption_lengths"], batch["entities"],
+                           *extra)
         units_per_step = B * L
     else:
         def step():
@@ -178,9 +216,13 @@ def main():
             "config": {"workload": "%s: %s variant, per-GPU batch %d x %d decode positions, 14x14x2048 features, "
                                    "K=%d knowledge rows%s, vocab %d" % (cfgname, variant, B, L, K,
                                                                          (", F=%d facts" % Fn) if Fn else "", V),
-                       "mode": "teacher_forced_forward (Encoder.conv1 + DecoderTransformer.forward)"
-                       if args.mode == "forward" else "greedy_decode (Encoder.conv1 + predict, KV-cached)",
-                       "global_batch": world * B, "parallelism": "dp%d (independent shards)" % world},
+                       "mode": {"train": "train_step (Encoder.conv1 + forward + packed CE + backward + RCCL all-reduce "
+                                         "+ clamp + Adam; dropout 0.5/0.5/0.1 as the reference's train.py builds it)",
+                                "forward": "teacher_forced_forward (Encoder.conv1 + DecoderTransformer.forward)",
+                                "greedy": "greedy_decode (Encoder.conv1 + predict, KV-cached)"}[args.mode],
+                       "global_batch": world * B,
+                       "parallelism": ("dp%d (one flat-bucket all-reduce per step)" if args.mode == "train"
+                                       else "dp%d (independent shards)") % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                          "kernel": "gemm_kernel<2,2,2,2,A k-major,B k-contig,vec> (Encoder.conv1: [%d x %d] x [%d x %d])"
@@ -188,7 +230,7 @@ def main():
                          "kernel_ms": kern_ms, "flops_per_launch": flops, "launches_timed": len(events)},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, seed, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(cfg, seed, args.cpu_seconds, args.mode if args.mode == "train" else "forward")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
