@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(ick_attn_bwd_args p, int 
     float* dS = Gs + TQ * DHP;         // TQ * SLD
     float* Dl = dS + TQ * SLD;         // TQ  rowsum(dO * O)
     float* Ls = Dl + TQ;               // TQ  lse
+    float* Tr = Ls + TQ + ((4 - ((TQ * (2 * DHP + SLD + 2)) & 3)) & 3);   // 256 * DHP transpose staging, 16-byte aligned
 
     const int h = blockIdx.x, b = blockIdx.y, t0 = blockIdx.z * TQ;
     const int nt = min(TQ, p.T - t0);
@@ -246,12 +247,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(ick_attn_bwd_args p, int 
     }
     __syncthreads();
 
-    for (int s = tid; s < S; s += 256) {
+    // Phase 1 runs once per 256-key block (S <= 256 on this path's bench shapes: one block); the lane's
+    // dK / dV rows stay in registers until they are written out through LDS (coalesced row segments)
+    for (int s0 = 0; s0 < S; s0 += 256) {
+        const int s = s0 + tid;
+        const bool live = s < S;
+        const int sc_ = live ? s : S - 1;
         float kreg[DHP], vreg[DHP], dk[DHP], dv[DHP];
-        const float4* vr = reinterpret_cast<const float4*>(vb + (int64_t)s * DHP);
+        const float4* vr = reinterpret_cast<const float4*>(vb + (int64_t)sc_ * DHP);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const float4 kx = *reinterpret_cast<const float4*>(Ks + s * VLD + 4 * g);
+            const float4 kx = *reinterpret_cast<const float4*>(Ks + sc_ * VLD + 4 * g);
             const float4 vx = vr[g];
             kreg[4 * g + 0] = kx.x; kreg[4 * g + 1] = kx.y; kreg[4 * g + 2] = kx.z; kreg[4 * g + 3] = kx.w;
             vreg[4 * g + 0] = 4 * g + 0 < dh ? vx.x : 0.f; vreg[4 * g + 1] = 4 * g + 1 < dh ? vx.y : 0.f;
@@ -259,42 +265,58 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(ick_attn_bwd_args p, int 
         }
 #pragma unroll
         for (int j = 0; j < DHP; ++j) { dk[j] = 0.f; dv[j] = 0.f; }
-        for (int t = 0; t < nt; ++t) {
-            float sc = 0.f, dp = 0.f;
-            float q[DHP], g[DHP];
+        if (live) {
+            for (int t = 0; t < nt; ++t) {
+                float sc = 0.f, dp = 0.f;
+                float q[DHP], g[DHP];
 #pragma unroll
-            for (int j4 = 0; j4 < G; ++j4) {
-                const float4 qx = *reinterpret_cast<const float4*>(Qs + t * DHP + 4 * j4);
-                const float4 gx = *reinterpret_cast<const float4*>(Gs + t * DHP + 4 * j4);
-                q[4 * j4 + 0] = qx.x; q[4 * j4 + 1] = qx.y; q[4 * j4 + 2] = qx.z; q[4 * j4 + 3] = qx.w;
-                g[4 * j4 + 0] = gx.x; g[4 * j4 + 1] = gx.y; g[4 * j4 + 2] = gx.z; g[4 * j4 + 3] = gx.w;
-            }
+                for (int j4 = 0; j4 < G; ++j4) {
+                    const float4 qx = *reinterpret_cast<const float4*>(Qs + t * DHP + 4 * j4);
+                    const float4 gx = *reinterpret_cast<const float4*>(Gs + t * DHP + 4 * j4);
+                    q[4 * j4 + 0] = qx.x; q[4 * j4 + 1] = qx.y; q[4 * j4 + 2] = qx.z; q[4 * j4 + 3] = qx.w;
+                    g[4 * j4 + 0] = gx.x; g[4 * j4 + 1] = gx.y; g[4 * j4 + 2] = gx.z; g[4 * j4 + 3] = gx.w;
+                }
 #pragma unroll
-            for (int j = 0; j < DHP; ++j) {
-                sc = fmaf(q[j], kreg[j], sc);
-                dp = fmaf(g[j], vreg[j], dp);
-            }
-            float pr = __expf(sc * p.scale - Ls[t]);
-            if (p.causal && s > p.q_pos0 + t0 + t) pr = 0.f;
-            float mk = 1.f;
-            if (drop.on()) mk = drop.mask((uint32_t)((b * p.H + h) * p.T + t0 + t) * (uint32_t)S + (uint32_t)s);
-            const float ds = pr * (dp * mk - Dl[t]) * p.scale;
-            const float prd = pr * mk;
+                for (int j = 0; j < DHP; ++j) {
+                    sc = fmaf(q[j], kreg[j], sc);
+                    dp = fmaf(g[j], vreg[j], dp);
+                }
+                float pr = __expf(sc * p.scale - Ls[t]);
+                if (p.causal && s > p.q_pos0 + t0 + t) pr = 0.f;
+                float mk = 1.f;
+                if (drop.on()) mk = drop.mask((uint32_t)((b * p.H + h) * p.T + t0 + t) * (uint32_t)S + (uint32_t)s);
+                const float ds = pr * (dp * mk - Dl[t]) * p.scale;
+                const float prd = pr * mk;
 #pragma unroll
-            for (int j = 0; j < DHP; ++j) {
-                dv[j] = fmaf(prd, g[j], dv[j]);
-                dk[j] = fmaf(ds, q[j], dk[j]);
+                for (int j = 0; j < DHP; ++j) {
+                    dv[j] = fmaf(prd, g[j], dv[j]);
+                    dk[j] = fmaf(ds, q[j], dk[j]);
+                }
+                dS[t * SLD + s] = ds;
             }
-            dS[t * SLD + s] = ds;
         }
-        float* dkr = p.dK + (int64_t)b * p.dk_bs + (int64_t)s * p.dk_ss + h * dh;
-        float* dvr = p.dV + (int64_t)b * p.dv_bs + (int64_t)s * p.dv_ss + h * dh;
-        if (multi) {
-            for (int j = 0; j < dh; ++j) { atomicAdd(dkr + j, dk[j]); atomicAdd(dvr + j, dv[j]); }
-        } else {
+        // hand the rows over through LDS: [key][DHP] per matrix, then lanes walk (key, column) in
+        // column-fastest order so that a wave's stores cover whole 120-byte row segments
+        const int nkeys = min(256, S - s0);
+        for (int which = 0; which < 2; ++which) {
+            __syncthreads();
+            if (live) {
 #pragma unroll
-            for (int j = 0; j < DHP; ++j)
-                if (j < dh) { dkr[j] = dk[j]; dvr[j] = dv[j]; }
+                for (int g = 0; g < G; ++g) {
+                    const float* src = which == 0 ? dk : dv;
+                    *reinterpret_cast<float4*>(Tr + tid * DHP + 4 * g) =
+                        make_float4(src[4 * g], src[4 * g + 1], src[4 * g + 2], src[4 * g + 3]);
+                }
+            }
+            __syncthreads();
+            float* base = which == 0 ? p.dK + (int64_t)b * p.dk_bs + h * dh : p.dV + (int64_t)b * p.dv_bs + h * dh;
+            const int64_t rs = which == 0 ? p.dk_ss : p.dv_ss;
+            for (int idx = tid; idx < nkeys * dh; idx += 256) {
+                const int kk = idx / dh, j = idx - kk * dh;
+                float* dst = base + (int64_t)(s0 + kk) * rs + j;
+                const float v = Tr[kk * DHP + j];
+                if (multi) atomicAdd(dst, v); else *dst = v;
+            }
         }
     }
     __syncthreads();
@@ -325,8 +347,9 @@ int launch_attn_bwd(const ick_attn_bwd_args& a, hipStream_t s) {
     const size_t fixed = (size_t)a.S * VLD;
     int TQ = a.T;
     const size_t budget = 150 * 1024 / sizeof(float);
-    while (TQ > 1 && fixed + (size_t)TQ * (2 * DHP + SLD + 2) > budget) TQ = (TQ + 1) / 2;
-    const size_t fl = fixed + (size_t)TQ * (2 * DHP + SLD + 2);
+    const size_t stage = (size_t)256 * DHP + 4;
+    while (TQ > 1 && fixed + stage + (size_t)TQ * (2 * DHP + SLD + 2) > budget) TQ = (TQ + 1) / 2;
+    const size_t fl = fixed + stage + (size_t)TQ * (2 * DHP + SLD + 2);
     if (fl > budget) return ICK_EINVAL;
     auto kern = attn_bwd_kernel<DHP>;
     static bool attr_set = false;

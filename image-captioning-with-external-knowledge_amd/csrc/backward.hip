@@ -18,6 +18,7 @@ constexpr int kMaxPerLane = 16;
 // One wave per row; per-workgroup partial dgamma/dbeta go through LDS, then one float atomic per
 // column per workgroup.
 // ---------------------------------------------------------------------------------------------
+template <int NJ>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ res,
                                                             const float* __restrict__ gamma,
@@ -30,9 +31,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 2 * d; i += 256) sm[i] = 0.f;
     __syncthreads();
-    float ag[kMaxPerLane], ab[kMaxPerLane], gm[kMaxPerLane];
+    float ag[NJ], ab[NJ], gm[NJ];
 #pragma unroll
-    for (int j = 0; j < kMaxPerLane; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int c = lane + 64 * j;
         ag[j] = 0.f; ab[j] = 0.f;
         gm[j] = c < d ? gamma[c] : 0.f;
@@ -42,10 +43,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const int64_t row = row0 + r;
         if (row >= rows) break;
         const float mu = mean[row], rs = rstd[row];
-        float zh[kMaxPerLane], g[kMaxPerLane];
+        float zh[NJ], g[NJ];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < kMaxPerLane; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int c = lane + 64 * j;
             float z = 0.f, dyv = 0.f;
             if (c < d) {
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         s1 = wave_sum(s1) / (float)d;
         s2 = wave_sum(s2) / (float)d;
 #pragma unroll
-        for (int j = 0; j < kMaxPerLane; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int c = lane + 64 * j;
             if (c < d) {
                 const float v = rs * (g[j] - s1 - zh[j] * s2);
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         }
     }
 #pragma unroll
-    for (int j = 0; j < kMaxPerLane; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int c = lane + 64 * j;
         if (c < d) {
             atomicAdd(&sm[c], ag[j]);
@@ -360,10 +361,21 @@ extern "C" int ick_layernorm_bwd(const float* dy, const float* x, const float* r
                                  uint32_t drop_site, void* stream) {
     ICK_CHECK_ARG(dy && x && gamma && mean && rstd && dz && dgamma && dbeta && rows > 0 && d > 0 && d <= 1024);
     ICK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || dx_drop != nullptr));
-    const int rpb = 16;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(ceil_div(rows, rpb)), dim3(256), 2 * d * sizeof(float),
-                       (hipStream_t)stream, dy, x, res, gamma, mean, rstd, dz, dgamma, dbeta, rows, d, rpb,
-                       drop_p > 0.f ? dx_drop : nullptr, make_dropout(drop_p, drop_seed, drop_site));
+    const int rpb = 8;   // two rows per wave: 160 workgroups for the 1280 rows of a layer
+    const Dropout dr = make_dropout(drop_p, drop_seed, drop_site);
+    float* dxd = drop_p > 0.f ? dx_drop : nullptr;
+    const dim3 grid(ceil_div(rows, rpb));
+    const size_t sm = 2 * d * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (d <= 320)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<5>, grid, dim3(256), sm, s, dy, x, res, gamma, mean, rstd, dz, dgamma,
+                           dbeta, rows, d, rpb, dxd, dr);
+    else if (d <= 512)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, dim3(256), sm, s, dy, x, res, gamma, mean, rstd, dz, dgamma,
+                           dbeta, rows, d, rpb, dxd, dr);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel<16>, grid, dim3(256), sm, s, dy, x, res, gamma, mean, rstd, dz, dgamma,
+                           dbeta, rows, d, rpb, dxd, dr);
     ICK_LAUNCH_RET();
 }
 

@@ -324,131 +324,6 @@ int launch(const ick_gemm_args& a, hipStream_t s) {
     ICK_LAUNCH_RET();
 }
 
-// ---------------------------------------------------------------------------------------------
-// K-resident variant for the short, wide chain GEMMs of the transformer layers
-// (M = B*L rows, N in {300, 512, 900}, K in {300, 512}): at 0.2-0.7 GFLOP each they are bound by
-// the global->LDS round trips of a K loop, not by the matrix cores.  Here a workgroup takes a
-// 32 x 32 output tile, pulls BOTH operand panels (32 rows x K each, k-contiguous) into LDS with
-// every load in flight at once, and runs the whole K reduction from LDS: one memory round trip
-// per workgroup.  Each wave owns one 16x16 tile and alternates two accumulators so consecutive
-// MFMAs are independent (40-cycle dependent latency vs 32-cycle issue).
-// ---------------------------------------------------------------------------------------------
-template <int NLOAD>
-__global__ __launch_bounds__(256) void gemm_kres_kernel(ick_gemm_args p, int tiles_m, int tiles_n, int KP,
-                                                        unsigned magic) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int LD4 = KP / 4 + 1;  // LDS row stride in float4: KP (K rounded up to 16) + 4 floats of padding,
-    const int LD = LD4 * 4;      // which keeps the ds_read_b128 fragment rows on distinct banks
-    float* As = smem;
-    float* Bs = smem + 32 * LD;
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-    }
-    const int tm = bid % tiles_m, tn = bid / tiles_m;  // consecutive workgroups share the weight panel
-    const int m0 = tm * 32, n0 = tn * 32;
-    const RowMap amap{p.a_grp, p.a_gs, p.a_gmap, p.a_rs};
-    const bool hs = p.hs_dh > 0;
-    const RowMap cmap{p.c_grp, p.c_gs, p.c_gmap, hs ? (int64_t)p.hs_dhp : p.c_rs};
-    const int64_t row_bias = hs ? (int64_t)p.hs_s0 * p.hs_dhp : 0;
-    const int tid = threadIdx.x;
-    const int CH = KP / 4;           // float4 per LDS row (zero filled beyond K)
-    const int total = 64 * CH;       // rows 0..31 = A tile, 32..63 = B tile
-    // row offsets (may involve a group-map lookup) are resolved once, by one lane per row
-    __shared__ int64_t rowoff[96];   // [0,32) A rows, [32,64) B rows, [64,96) C rows; -1 = out of range
-    if (tid < 32) {
-        const int gr = m0 + tid;
-        rowoff[tid] = gr < p.M ? amap(gr) : -1;
-        rowoff[64 + tid] = gr < p.M ? cmap(gr) + row_bias : -1;
-    } else if (tid < 64) {
-        const int gr = n0 + tid - 32;
-        rowoff[tid] = gr < p.N ? (int64_t)gr * p.b_rs : -1;
-    }
-    __syncthreads();
-    float4 v[NLOAD];
-    // issue every load first (clamped addresses, no data-dependent control flow)
-    // idx / CH by multiply-shift (magic = ceil(2^20 / CH), exact for idx < 64 * CH; checked on the host)
-#pragma unroll
-    for (int j = 0; j < NLOAD; ++j) {
-        const int idx = min(tid + 256 * j, total - 1);
-        const int row = (int)(((unsigned)idx * magic) >> 20), c = idx - row * CH;
-        const int64_t ro = rowoff[row];
-        const float* src = (row < 32 ? p.A : p.B) + (ro < 0 ? 0 : ro) + (4 * c < p.K ? 4 * c : 0);
-        v[j] = *reinterpret_cast<const float4*>(src);
-    }
-#pragma unroll
-    for (int j = 0; j < NLOAD; ++j) {
-        const int idx = tid + 256 * j;
-        const int ci = min(idx, total - 1);
-        const int row = (int)(((unsigned)ci * magic) >> 20), c = ci - row * CH;
-        const bool good = rowoff[row] >= 0 && 4 * c < p.K;
-        float4 x = v[j];
-        x.x = good ? x.x : 0.f; x.y = good ? x.y : 0.f; x.z = good ? x.z : 0.f; x.w = good ? x.w : 0.f;
-        if (idx < total) reinterpret_cast<float4*>(smem)[row * LD4 + c] = x;
-    }
-    __syncthreads();
-
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int fi = lane & 15, fq = lane >> 4;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const float* ap = As + (wm * 16 + fi) * LD + 4 * fq;
-    const float* bp = Bs + (wn * 16 + fi) * LD + 4 * fq;
-    const int nchunk = KP / 16;
-    for (int t = 0; t < nchunk; ++t) {
-        const float4 a = *reinterpret_cast<const float4*>(ap + 16 * t);
-        const float4 b = *reinterpret_cast<const float4*>(bp + 16 * t);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc1, 0, 0, 0);
-    }
-    const bool relu = p.flags & ICK_GEMM_RELU, accum = p.flags & ICK_GEMM_ACCUM;
-    const Dropout drop = make_dropout(p.drop_p, p.drop_seed, p.drop_site);
-    const int col = n0 + wn * 16 + fi;
-    if (col < p.N) {
-        const float bv = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t co = rowoff[64 + wm * 16 + fq * 4 + r];
-            if (co >= 0) {
-                float x = (acc0[r] + acc1[r]) * p.alpha + bv;
-                if (relu) x = fmaxf(x, 0.f);
-                if (drop.on()) x *= drop.mask((uint32_t)(m0 + wm * 16 + fq * 4 + r) * (uint32_t)p.N + (uint32_t)col);
-                float* dst = p.C + co + col_offset(p, col);
-                if (accum) *dst += x; else *dst = x;
-            }
-        }
-    }
-}
-
-template <int NLOAD>
-int launch_kres(const ick_gemm_args& a, int KP, hipStream_t s) {
-    const size_t smem = (size_t)64 * (KP + 4) * sizeof(float);
-    const int tiles_m = ceil_div(a.M, 32), tiles_n = ceil_div(a.N, 32);
-    auto kern = gemm_kres_kernel<NLOAD>;
-    static bool attr_set = false;
-    if (!attr_set) {  // 768 B of static LDS (rowoff) come on top of the dynamic panel
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    const int CH = KP / 4;
-    const unsigned magic = ((1u << 20) + CH - 1) / CH;
-    static signed char magic_ok[129] = {0};  // 0 unknown, 1 exact, -1 not exact
-    if (CH > 128) return ICK_EINVAL;
-    if (magic_ok[CH] == 0) {
-        magic_ok[CH] = 1;
-        for (int idx = 0; idx < 64 * CH; ++idx)
-            if ((int)(((unsigned)idx * magic) >> 20) != idx / CH) magic_ok[CH] = -1;
-    }
-    if (magic_ok[CH] < 0) return ICK_EINVAL;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), smem, s, a, tiles_m, tiles_n, KP, magic);
-    ICK_LAUNCH_RET();
-}
-
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -483,22 +358,12 @@ extern "C" int ick_gemm(const ick_gemm_args* in, void* stream) {
     if (bkm) bvec = aligned16(a.B) && a.b_ks % 4 == 0 && a.N % 4 == 0;
     else bvec = aligned16(a.B) && a.b_rs % 4 == 0 && a.K % 4 == 0;
     const bool vec = avec && bvec;
-    const bool split_one = a.split_k <= 1;
     a.flags &= 0xff;
     hipStream_t s = (hipStream_t)stream;
 
     // Tile selection: 64x64 per wave on large problems; N<=320 keeps 4 waves stacked along M so a
     // 300-wide output costs 5 x 64 columns instead of 3 x 128; small problems use small tiles so
     // that enough workgroups exist to cover the 256 CUs.
-    // chain GEMMs (short K, k-contiguous operands, not enough work to fill the chip with 64x64 wave
-    // tiles): K-resident 32x32 tiles, one memory round trip per workgroup
-    if (vec && !akm && !bkm && a.K <= 304 && split_one && !(a.flags & ICK_GEMM_ATOMIC) && !getenv("ICK_GEMM_TILE") &&
-        (int64_t)a.M * a.N <= (int64_t)1280 * 320) {
-        const int KP = ceil_div(a.K, 16) * 16;
-        const int nload = ceil_div(64 * (KP / 4), 256);
-        if (nload <= 20) return launch_kres<20>(a, KP, s);
-        return launch_kres<33>(a, KP, s);
-    }
     const int64_t tiles_big = (int64_t)ceil_div(a.M, 128) * ceil_div(a.N, 128);
     const int64_t work = (int64_t)a.M * a.N;
 #define ICK_DISPATCH(WM, WN, TM, TN)                                                  \
@@ -526,8 +391,11 @@ extern "C" int ick_gemm(const ick_gemm_args* in, void* stream) {
     // Measured on MI355X (tools/probes/probe_ops, profiles/r01_*): with exact-fp32 MFMA a 64x64 wave tile
     // alone needs ~18 us for K = 300, so latency and occupancy favour 64x64 workgroup tiles (32x32 per
     // wave, 4+ waves per SIMD) on every shape of this path; larger tiles stay available for experiments.
-    (void)tiles_big;
-    if (work >= (int64_t)64 * 64 * 16) ICK_DISPATCH(2, 2, 2, 2);   // 64 x 64 tiles
-    ICK_DISPATCH(2, 2, 1, 1);                                      // 32 x 32 tiles
+    // Small outputs (the chain GEMMs of the layers and their data/weight gradients) take 32x32 tiles so
+    // that ~1000 workgroups exist: 7.7 vs 11.7 us for 1280x300x300, 18.5 vs 30.6 us for K = 900.
+    (void)tiles_big; (void)work;
+    const int64_t wgs64 = (int64_t)ceil_div(a.M, 64) * ceil_div(a.N, 64) * (a.split_k > 1 ? a.split_k : 1);
+    if (wgs64 > 1024) ICK_DISPATCH(2, 2, 2, 2);   // 64 x 64 tiles
+    ICK_DISPATCH(2, 2, 1, 1);                     // 32 x 32 tiles
 #undef ICK_DISPATCH
 }

@@ -10,6 +10,7 @@ namespace {
 
 constexpr int kMaxPerLane = 16;  // 16 * 64 = 1024
 
+template <int NJ>
 __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
@@ -21,11 +22,11 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
     if (row >= rows) return;
     const float* xr = x + row * x_ld;
     const float* rr = res ? res + row * res_ld : nullptr;
-    float v[kMaxPerLane], g[kMaxPerLane], bt[kMaxPerLane];
+    float v[NJ], g[NJ], bt[NJ];
     float sum = 0.f;
     // every load of the row (x, residual, gamma, beta) is issued up front: one memory round trip
 #pragma unroll
-    for (int j = 0; j < kMaxPerLane; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int c = lane + 64 * j;
         float t = 0.f;
         g[j] = 0.f;
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
     const float mean = wave_sum(sum) / (float)d;
     float var = 0.f;
 #pragma unroll
-    for (int j = 0; j < kMaxPerLane; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int c = lane + 64 * j;
         const float t = c < d ? v[j] - mean : 0.f;
         var = fmaf(t, t, var);
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
     const float rstd = rsqrtf(wave_sum(var) / (float)d + eps);
     float* yr = y + row * y_ld;
 #pragma unroll
-    for (int j = 0; j < kMaxPerLane; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int c = lane + 64 * j;
         if (c < d) yr[c] = (v[j] - mean) * rstd * g[j] + bt[j];
     }
@@ -72,8 +73,17 @@ extern "C" int ick_add_layernorm(const float* x, const float* res, const float* 
     ICK_CHECK_ARG(x && gamma && beta && y);
     ICK_CHECK_ARG(rows > 0 && d > 0 && d <= 64 * kMaxPerLane);
     ICK_CHECK_ARG((save_mean == nullptr) == (save_rstd == nullptr));
-    hipLaunchKernelGGL(add_layernorm_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, res, gamma,
-                       beta, y, rows, d, eps, x_ld, res_ld, y_ld, save_mean, save_rstd,
-                       make_dropout(drop_p, drop_seed, drop_site));
+    const Dropout dr = make_dropout(drop_p, drop_seed, drop_site);
+    const dim3 grid(ceil_div(rows, 4));
+    hipStream_t s = (hipStream_t)stream;
+    if (d <= 320)
+        hipLaunchKernelGGL(add_layernorm_kernel<5>, grid, dim3(256), 0, s, x, res, gamma, beta, y, rows, d, eps, x_ld,
+                           res_ld, y_ld, save_mean, save_rstd, dr);
+    else if (d <= 512)
+        hipLaunchKernelGGL(add_layernorm_kernel<8>, grid, dim3(256), 0, s, x, res, gamma, beta, y, rows, d, eps, x_ld,
+                           res_ld, y_ld, save_mean, save_rstd, dr);
+    else
+        hipLaunchKernelGGL(add_layernorm_kernel<16>, grid, dim3(256), 0, s, x, res, gamma, beta, y, rows, d, eps, x_ld,
+                           res_ld, y_ld, save_mean, save_rstd, dr);
     ICK_LAUNCH_RET();
 }

@@ -341,9 +341,18 @@ def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False):
     if db is not None:
         colsum(dy, db)
     if need_dx:
-        if dx is None:
-            dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
-        gemm_raw(dy, w, dx, M, K, N, dy.stride(0), 1, 1, w.stride(0), dx.stride(0), accumulate=accumulate_dx)
+        # a long reduction (the vocabulary: N = 10k..50k) over few output tiles is split over workgroups
+        split = max(1, min(16, N // 1024)) if (M * K) <= 1280 * 512 else 1
+        if split > 1:
+            if dx is None:
+                dx = torch.zeros(M, K, device=dy.device, dtype=torch.float32)
+            elif not accumulate_dx:
+                dx.zero_()
+            gemm_raw(dy, w, dx, M, K, N, dy.stride(0), 1, 1, w.stride(0), dx.stride(0), atomic=True, split_k=split)
+        else:
+            if dx is None:
+                dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+            gemm_raw(dy, w, dx, M, K, N, dy.stride(0), 1, 1, w.stride(0), dx.stride(0), accumulate=accumulate_dx)
     return dx
 
 

@@ -57,6 +57,29 @@ int main(int argc, char** argv) {
     gemm("decode-step qkv B=64", 64, 900, 300, false, 0);
     gemm("decode-step vocab B=64", 64, 10000, 300, false, 0);
     gemm("square 4096", 4096, 4096, 2048, false, 0);
+    // backward shapes: dgrad (B operand k-major) and wgrad (both k-major, split-K atomics)
+    auto gemm_bwd = [&](const char* name, int M, int N, int K, bool wgrad, int split) {
+        ick_gemm_args a; memset(&a, 0, sizeof(a));
+        a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.alpha = 1.f; a.split_k = split;
+        if (wgrad) { a.a_rs = 1; a.a_ks = M; a.b_rs = 1; a.b_ks = N; }
+        else { a.a_rs = K; a.a_ks = 1; a.b_rs = 1; a.b_ks = N; }
+        a.c_rs = N;
+        if (split > 1 || wgrad) a.flags = ICK_GEMM_ATOMIC;
+        int rc = ick_gemm(&a, st);
+        if (rc) { printf("%s rc=%d\n", name, rc); return; }
+        float us = timeit([&] { ick_gemm(&a, st); }, iters);
+        printf("%-28s M=%5d N=%5d K=%5d s=%2d: %8.2f us  %6.1f TFLOP/s\n", name, M, N, K, split, us, 2.0 * M * N * K / us * 1e-6);
+    };
+    gemm_bwd("dgrad out-proj", 1280, 300, 300, false, 1);
+    gemm_bwd("dgrad ffn2->f", 1280, 512, 300, false, 1);
+    gemm_bwd("dgrad ffn1->x", 1280, 300, 512, false, 1);
+    gemm_bwd("dgrad qkv->x", 1280, 300, 900, false, 1);
+    gemm_bwd("dgrad vocab->h", 1280, 300, 10000, false, 1);
+    gemm_bwd("dgrad vocab->h split8", 1280, 300, 10000, false, 8);
+    gemm_bwd("wgrad out-proj", 300, 300, 1280, true, 5);
+    gemm_bwd("wgrad qkv", 900, 300, 1280, true, 5);
+    gemm_bwd("wgrad vocab", 10000, 300, 1280, true, 5);
+    gemm_bwd("wgrad cross kv", 600, 300, 13824, true, 16);
     // attention
     float* Q = A; float* KV = B; float* O = C;
     auto attn = [&](const char* name, int Bn, int T, int S, int causal) {
@@ -73,7 +96,7 @@ int main(int argc, char** argv) {
     attn("cross attention", 64, 20, 216, 0);
     attn("self attention", 64, 20, 20, 1);
     attn("decode cross", 64, 1, 216, 0);
-    float us = timeit([&] { ick_add_layernorm(A, B, bias, bias, C, 1280, 300, 1e-5f, 300, 300, 300, nullptr, nullptr, st); }, iters);
+    float us = timeit([&] { ick_add_layernorm(A, B, bias, bias, C, 1280, 300, 1e-5f, 300, 300, 300, nullptr, nullptr, 0.f, 0, 0, st); }, iters);
     printf("%-28s rows=1280               : %8.2f us\n", "add_layernorm", us);
     return 0;
 }
