@@ -392,10 +392,11 @@ extern "C" int ick_gemm(const ick_gemm_args* in, void* stream) {
     // alone needs ~18 us for K = 300, so latency and occupancy favour 64x64 workgroup tiles (32x32 per
     // wave, 4+ waves per SIMD) on every shape of this path; larger tiles stay available for experiments.
     // Small outputs (the chain GEMMs of the layers and their data/weight gradients) take 32x32 tiles so
-    // that ~1000 workgroups exist: 7.7 vs 11.7 us for 1280x300x300, 18.5 vs 30.6 us for K = 900.
+    // that ~1000 workgroups exist: 7.7 vs 11.7 us for 1280x300x300, 18.5 vs 30.6 us for K = 900; from
+    // ~500 64x64 tiles on (cross K/V, vocabulary, feature projection) the larger tile wins (175 vs 212 us).
     (void)tiles_big; (void)work;
     const int64_t wgs64 = (int64_t)ceil_div(a.M, 64) * ceil_div(a.N, 64) * (a.split_k > 1 ? a.split_k : 1);
-    if (wgs64 > 1024) ICK_DISPATCH(2, 2, 2, 2);   // 64 x 64 tiles
+    if (wgs64 >= 512) ICK_DISPATCH(2, 2, 2, 2);   // 64 x 64 tiles
     ICK_DISPATCH(2, 2, 1, 1);                     // 32 x 32 tiles
 #undef ICK_DISPATCH
 }
