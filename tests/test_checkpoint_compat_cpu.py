@@ -1,0 +1,67 @@
+"""Checkpoint layout: the reference pickles whole objects (geo-aware/utils.py:32-49), so a
+checkpoint written by the REAL reference must unpickle into our drop-in classes once `models` resolves to our
+module, and state_dicts must interchange.  Needs /root/reference (authoring container only; skipped on the GPU box)."""
+import importlib.util
+import os
+import sys
+import types
+
+import pytest
+import torch
+
+import ick_amd
+import ick_amd.synth as synth
+
+REF = "/root/reference"
+DIRS = {"geo": "geo-aware", "knowledge": "knowledge-aware", "news": "news-knowledge-aware"}
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference sources not present")
+
+
+def _load_reference_models(variant):
+    sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+    spec = importlib.util.spec_from_file_location("models", os.path.join(REF, DIRS[variant], "models.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("variant", ["geo", "knowledge", "news"])
+def test_reference_checkpoint_unpickles_into_drop_in(tmp_path, variant):
+    V = 40
+    wm = synth.make_word_map(V)
+    ref_models = _load_reference_models(variant)
+    saved = sys.modules.get("models")
+    try:
+        sys.modules["models"] = ref_models                      # the reference pickles classes as models.<Name>
+        ref_dec = ref_models.DecoderTransformer(word_map=wm, emb_dim=300, decoder_dim=512, encoder_dim=512,
+                                                num_heads=10, num_layers=3)
+        ref_dec.load_state_dict(synth.make_params(variant, V, 1), strict=False)
+        opt = torch.optim.Adam(ref_dec.parameters(), lr=4e-4)
+        path = str(tmp_path / "checkpoint_geo_aware.pth.tar")
+        state = {"epoch": 3, "epochs_since_improvement": 1, "loss": 2.5, "encoder": None, "decoder": ref_dec,
+                 "encoder_optimizer": None, "decoder_optimizer": opt}              # utils.save_checkpoint's dict
+        torch.save(state, path)
+        ours = ick_amd.load_models(variant)
+        sys.modules["models"] = ours                            # what INTEGRATION.md tells a maintainer to do
+        ck = torch.load(path, weights_only=False)
+    finally:
+        if saved is None:
+            sys.modules.pop("models", None)
+        else:
+            sys.modules["models"] = saved
+    dec = ck["decoder"]
+    assert type(dec) is ours.DecoderTransformer and dec.variant == variant
+    assert ck["epoch"] == 3 and isinstance(ck["decoder_optimizer"], torch.optim.Adam)
+    # everything our forward / predict read exists on the unpickled object
+    assert dec.vocab_size == V and dec.emb_dim == 300 and dec.num_heads == 10
+    assert dec.pos_encoder.pe.shape == (5000, 1, 300) and dec.pos_encoder.dropout.p == 0.1
+    assert dec.has_facts == (variant != "geo")
+    ref_sd = ref_dec.state_dict()
+    sd = dec.state_dict()
+    assert list(sd.keys()) == list(ref_sd.keys())
+    assert all(torch.equal(sd[k], ref_sd[k]) for k in sd)
+    # and a freshly built drop-in accepts the reference's state_dict verbatim
+    fresh = ours.DecoderTransformer(wm, 300, 512, 512, 10, 3)
+    assert list(fresh.state_dict().keys()) == list(ref_sd.keys())
+    fresh.load_state_dict(ref_sd, strict=True)
