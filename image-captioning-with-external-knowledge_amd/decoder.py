@@ -35,6 +35,32 @@ def _sinusoid_table(max_len, d):
     return table.unsqueeze(1)
 
 
+class _GraphedCall:
+    """hipGraph capture of a pure-device function of static-shaped tensors (torch.cuda.CUDAGraph is the
+    HIP graph API on ROCm).  The kernels are launched through ctypes on torch's current stream, which is the
+    capture stream inside torch.cuda.graph(), so the whole launch sequence -- ~75 kernels for a teacher-forced
+    forward, ~900 for a 20-step greedy decode -- replays from one hipGraphLaunch with no host work in between."""
+
+    def __init__(self, fn, example_inputs):
+        self.static_in = [None if t is None else t.clone() for t in example_inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):            # warm-up off the capture: lazy hipFuncSetAttribute, caches
+            for _ in range(2):
+                fn(*self.static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = fn(*self.static_in)
+
+    def __call__(self, *inputs):
+        for dst, src in zip(self.static_in, inputs):
+            if dst is not None:
+                dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.static_out
+
+
 class PositionEncoder(nn.Module):
     """Holds the sinusoid buffer `pe` and the dropout rate; applied inside ick_caption_embed."""
 
@@ -107,6 +133,7 @@ class Encoder(nn.Module):
 
 class DecoderTransformer(nn.Module):
     variant = "geo"
+    use_hip_graphs = True   # inference forward / predict replay a captured hipGraph per input shape
 
     def __init__(self, word_map, emb_dim, decoder_dim, encoder_dim, num_heads, num_layers, dropout_dec=0.5,
                  dropout_enc=0.5, dropout_pos=0.1):
@@ -180,6 +207,14 @@ class DecoderTransformer(nn.Module):
 
     def _wants_grad(self):
         return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+    def invalidate_caches(self):
+        """Call after parameters were modified outside torch's version tracking (the fused Adam kernel
+        writes the flat bucket directly): drops the packed cross-K/V weights, the transposed predicate
+        weights and every captured graph."""
+        self.__dict__["_param_epoch"] = self.__dict__.get("_param_epoch", 0) + 1
+        for k in ("_kv_pack", "_pred_wt_cache", "_graphs"):
+            self.__dict__.pop(k, None)
 
     def _token_major(self, encoder_out):
         """(B, d, P) -> contiguous (B, P, d) storage.  Our Encoder already stores token-major."""
@@ -314,30 +349,10 @@ class DecoderTransformer(nn.Module):
         return encoder_out.to(dev), entities, facts
 
     # ------------------------------------------------------------------ forward (teacher forced)
-    def forward(self, captions, encoder_out, caption_masks, caption_lengths, entities, facts=None, stages=None):
-        encoder_out, entities, facts = self._prepare_inputs(encoder_out, entities, facts)
-        dev = encoder_out.device
-        # length sort on the host, like the reference's CPU path (the result feeds a Python list anyway)
-        lengths, sort_ind = caption_lengths.detach().squeeze(1).cpu().sort(dim=0, descending=True)
-        decode_lengths = (lengths - 1).tolist()
-        sort_dev = sort_ind.to(dev)
-        captions = captions.to(dev)[sort_dev].contiguous()
-        caption_masks = caption_masks.to(dev)[sort_dev].contiguous()
-        entities = entities[sort_dev].contiguous()
-        if self.has_facts:
-            facts = facts[sort_dev].contiguous()
-        enc_tok = self._token_major(encoder_out)
-        gmap = sort_dev.to(torch.int32)
-        B, L = captions.shape
+    def _forward_device(self, captions, caption_masks, entities, facts, enc_tok, gmap, stages=None):
+        """Device-only part of forward() on length-sorted inputs (no host synchronisation inside)."""
         d, V = self.emb_dim, self.vocab_size
-        P, K = enc_tok.shape[1], entities.shape[1]
-        if self._wants_grad() and stages is None:
-            # autograd bridge: the HIP backward pass runs when the caller's loss.backward() reaches us
-            from . import training
-            scores = training.DecoderGraphFn.apply(self, captions, caption_masks, entities, facts, enc_tok.detach(),
-                                                   gmap, *training.unique_parameters(self))
-            return scores, captions, decode_lengths
-
+        K = entities.shape[1]
         ee, fe, kv, ctx = self._encode_context(enc_tok, entities, facts, gmap)
         pe = self.pos_encoder.pe.view(-1, d)
         x, emb = ops.caption_embed(captions, caption_masks, self.word_embedding.weight.detach(), ee, fe, pe, V,
@@ -353,18 +368,56 @@ class DecoderTransformer(nn.Module):
         if stages is not None:
             stages.update(entities_encoded=ee, facts_encoded=fe, embeddings=emb, entity_context=ctx[0],
                           fact_context=ctx[1], h=x, kv=kv, eib=eib, gate=gate)
-        return scores, captions, decode_lengths
+        return scores
 
-    # ------------------------------------------------------------------ greedy decode (KV cached)
-    @torch.no_grad()
-    def predict(self, encoder_out, max_pred_len, entities, facts=None):
-        """Greedy decode with the reference's semantics per caption (argmax, <end> stop, repeated
-        n-gram clean-up, pointer masks), KV-cached: step i only projects position i.  Works for any
-        batch size (B independent captions); returns LongTensor (max_pred_len, B), <pad> after <end>."""
+    def _graphed(self, kind, key, fn, inputs):
+        """Replay (capturing on first use) the hipGraph of `fn` for this shape key; parameters are read
+        through their device pointers, so in-place weight updates are seen, re-allocation is not
+        (the key includes the parameters' storage pointers)."""
+        cache = self.__dict__.setdefault("_graphs", {})
+        pkey = (self.__dict__.get("_param_epoch", 0),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        full = (kind, key, pkey)
+        g = cache.get(full)
+        if g is None:
+            if len(cache) >= 8:
+                cache.clear()
+            g = cache[full] = _GraphedCall(fn, inputs)
+        return g(*inputs)
+
+    def forward(self, captions, encoder_out, caption_masks, caption_lengths, entities, facts=None, stages=None):
         encoder_out, entities, facts = self._prepare_inputs(encoder_out, entities, facts)
         dev = encoder_out.device
-        entities = entities.contiguous()
+        # length sort on the host, like the reference's CPU path (the result feeds a Python list anyway)
+        lengths, sort_ind = caption_lengths.detach().squeeze(1).cpu().sort(dim=0, descending=True)
+        decode_lengths = (lengths - 1).tolist()
+        sort_dev = sort_ind.to(dev)
+        captions = captions.to(dev)[sort_dev].contiguous()
+        caption_masks = caption_masks.to(dev)[sort_dev].contiguous()
+        entities = entities[sort_dev].contiguous()
+        if self.has_facts:
+            facts = facts[sort_dev].contiguous()
         enc_tok = self._token_major(encoder_out)
+        gmap = sort_dev.to(torch.int32)
+        if self._wants_grad() and stages is None:
+            # autograd bridge: the HIP backward pass runs when the caller's loss.backward() reaches us
+            from . import training
+            scores = training.DecoderGraphFn.apply(self, captions, caption_masks, entities, facts, enc_tok.detach(),
+                                                   gmap, *training.unique_parameters(self))
+            return scores, captions, decode_lengths
+        if stages is None and self.use_hip_graphs:
+            key = (tuple(captions.shape), tuple(enc_tok.shape), tuple(entities.shape),
+                   None if facts is None else tuple(facts.shape))
+            scores = self._graphed("fwd", key, lambda c, m, e, f, t, g: self._forward_device(c, m, e, f, t, g),
+                                   [captions, caption_masks, entities, facts, enc_tok.contiguous(), gmap])
+            return scores, captions, decode_lengths
+        return self._forward_device(captions, caption_masks, entities, facts, enc_tok, gmap, stages), captions, \
+            decode_lengths
+
+    # ------------------------------------------------------------------ greedy decode (KV cached)
+    def _predict_device(self, enc_tok, entities, facts, max_pred_len):
+        """Whole greedy decode on the device: every step's token choice, clean-up and stop flag are computed
+        by kernels (no host round trip), so the loop can be captured as one hipGraph."""
+        dev = enc_tok.device
         B = enc_tok.shape[0]
         d, V, K = self.emb_dim, self.vocab_size, entities.shape[1]
         ee, fe, kv, _ = self._encode_context(enc_tok, entities, facts, None)
@@ -396,4 +449,21 @@ class DecoderTransformer(nn.Module):
                               self.has_facts, self.word_map["<end>"])
             if self.has_facts and i + 1 < max_pred_len:
                 cap_buf[:, i + 1] = tok.view(-1)
+        return output
+
+    @torch.no_grad()
+    def predict(self, encoder_out, max_pred_len, entities, facts=None):
+        """Greedy decode with the reference's semantics per caption (argmax, <end> stop, repeated
+        n-gram clean-up, pointer masks), KV-cached: step i only projects position i.  Works for any
+        batch size (B independent captions); returns LongTensor (max_pred_len, B), <pad> after <end>."""
+        encoder_out, entities, facts = self._prepare_inputs(encoder_out, entities, facts)
+        entities = entities.contiguous()
+        enc_tok = self._token_major(encoder_out).contiguous()
+        if self.use_hip_graphs:
+            key = (tuple(enc_tok.shape), tuple(entities.shape), None if facts is None else tuple(facts.shape),
+                   max_pred_len)
+            output = self._graphed("greedy", key, lambda t, e, f: self._predict_device(t, e, f, max_pred_len),
+                                   [enc_tok, entities, facts])
+        else:
+            output = self._predict_device(enc_tok, entities, facts, max_pred_len)
         return output.t().contiguous()

@@ -410,5 +410,6 @@ class TrainStep:
         self.step_count += 1
         ops.adam_clamp(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count, self.lr, self.clip, 1.0,
                        self.betas[0], self.betas[1], self.eps)
+        dec.invalidate_caches()   # the update went around torch's version counters
         # token-mean loss of the global batch, still on the device
         return self.flat_g[self.n:self.n + 1] / self.flat_g[self.n + 1:]

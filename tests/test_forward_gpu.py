@@ -203,3 +203,34 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libick_amd.so")
     with pytest.raises(L.IckError):
         L.load()
+
+
+def test_graph_replay_equals_eager_and_tracks_new_inputs():
+    """Inference forward / predict replay a captured hipGraph: results must equal the eager launch sequence,
+    follow fresh inputs on every replay, and follow parameter updates (re-capture)."""
+    variant, B, L, K, V, Fn, seed = "knowledge", 5, 9, 6, 80, 5, 12
+    P = synth.make_params(variant, V, seed)
+    dec = build_decoder(variant, V, P)
+    outs = {}
+    for use in (False, True):
+        dec.use_hip_graphs = use
+        res = []
+        for s2 in (1, 2, 1):      # third call replays the graph captured by the first shape-identical call
+            batch = synth.make_batch(variant, B, L, K, V, Fn, s2)
+            enc_out = synth.make_enc_out(B, s2)
+            with torch.no_grad():
+                sc, caps, dl = dec(batch["captions"].cuda(), enc_out.cuda(), batch["caption_masks"].cuda(),
+                                   batch["caption_lengths"].cuda(), batch["entities"], batch["facts"].cuda())
+                seq = dec.predict(enc_out[:2].cuda(), 8, batch["entities"][:2], batch["facts"][:2].cuda())
+            res.append((sc.clone(), seq.clone()))
+        outs[use] = res
+    for (a, sa), (b, sb) in zip(outs[False], outs[True]):
+        assert torch.equal(a, b) and torch.equal(sa, sb)
+    assert not torch.equal(outs[True][0][0], outs[True][1][0])
+    # parameter change -> new capture, new result
+    with torch.no_grad():
+        dec.fc_vocab.bias.add_(1.0)
+        batch = synth.make_batch(variant, B, L, K, V, Fn, 1)
+        sc, _, _ = dec(batch["captions"].cuda(), synth.make_enc_out(B, 1).cuda(), batch["caption_masks"].cuda(),
+                       batch["caption_lengths"].cuda(), batch["entities"], batch["facts"].cuda())
+    assert (sc[..., :V] - outs[True][0][0][..., :V] - 1.0).abs().max().item() < 1e-5

@@ -232,6 +232,11 @@ def test_training_with_reference_dropout_reduces_loss():
                  batch["entities"]).item() for _ in range(30)]
     assert all(math.isfinite(v) for v in losses)
     assert sum(losses[-5:]) / 5 < sum(losses[:5]) / 5 - 0.3, losses
+    # the packed cross-K/V weights used by the next forward must follow the in-place Adam update
+    d = dec.emb_dim
+    wkv, _ = dec._packed_cross_kv()
+    l0 = dec.transformer_decoder.layers[0].multihead_attn.in_proj_weight
+    assert torch.equal(wkv[:2 * d], l0.detach()[d:])
     dec.eval()
     with torch.no_grad():
         sc, _, _ = dec(batch["captions"].cuda(), enc_out, batch["caption_masks"].cuda(),
