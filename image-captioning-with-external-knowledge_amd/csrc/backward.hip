@@ -26,8 +26,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ rstd, float* __restrict__ dz,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int64_t rows, int d, int rows_per_block,
-                                                            float* __restrict__ dx_drop, Dropout drop) {
+                                                            float* __restrict__ dx_drop, DropArg darg) {
     extern __shared__ float sm[];  // 2 * d partial sums
+    const Dropout drop = darg.get();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 2 * d; i += 256) sm[i] = 0.f;
     __syncthreads();
@@ -124,7 +125,8 @@ __global__ __launch_bounds__(256) void caption_embed_bwd_kernel(const float* __r
                                                                 float* __restrict__ dword, float* __restrict__ dee,
                                                                 float* __restrict__ dfe, int B, int L, int K, int F,
                                                                 int V, int d, int pad_token, float scale,
-                                                                Dropout drop) {
+                                                                DropArg darg) {
+    const Dropout drop = darg.get();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B * L) return;
@@ -328,8 +330,11 @@ __global__ __launch_bounds__(256) void context_gate_bwd_kernel(const int64_t* __
 __global__ __launch_bounds__(256) void adam_clamp_kernel(float* __restrict__ p, float* __restrict__ g,
                                                          float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                          float gscale, float clip, float lr, float b1, float b2,
-                                                         float eps, float bc1, float bc2_sqrt) {
+                                                         float eps, int step0, const uint32_t* step_ptr) {
     const int64_t stride = (int64_t)gridDim.x * 256;
+    const float t = (float)(step0 + (step_ptr ? (int)*step_ptr : 0));
+    const float bc1 = 1.f - powf(b1, t);
+    const float bc2_sqrt = sqrtf(1.f - powf(b2, t));
     const float step = lr / bc1;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         float gi = g[i] * gscale;
@@ -342,6 +347,8 @@ __global__ __launch_bounds__(256) void adam_clamp_kernel(float* __restrict__ p, 
         p[i] -= step * mi / (sqrtf(vi) / bc2_sqrt + eps);
     }
 }
+
+__global__ void counter_add_kernel(uint32_t* c, uint32_t inc) { *c += inc; }
 
 __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, int64_t n, const float* __restrict__ num,
                                                     const float* __restrict__ den) {
@@ -358,11 +365,11 @@ using namespace ick;
 extern "C" int ick_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma,
                                  const float* mean, const float* rstd, float* dz, float* dgamma, float* dbeta,
                                  int64_t rows, int32_t d, float* dx_drop, float drop_p, uint32_t drop_seed,
-                                 uint32_t drop_site, void* stream) {
+                                 uint32_t drop_site, const uint32_t* drop_epoch, void* stream) {
     ICK_CHECK_ARG(dy && x && gamma && mean && rstd && dz && dgamma && dbeta && rows > 0 && d > 0 && d <= 1024);
     ICK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || dx_drop != nullptr));
     const int rpb = 8;   // two rows per wave: 160 workgroups for the 1280 rows of a layer
-    const Dropout dr = make_dropout(drop_p, drop_seed, drop_site);
+    const DropArg dr{drop_p, drop_seed, drop_site, drop_epoch};
     float* dxd = drop_p > 0.f ? dx_drop : nullptr;
     const dim3 grid(ceil_div(rows, rpb));
     const size_t sm = 2 * d * sizeof(float);
@@ -398,11 +405,11 @@ extern "C" int ick_colsum(const float* a, int64_t M, int32_t N, int64_t ld, floa
 extern "C" int ick_caption_embed_bwd(const float* dx, const int64_t* captions, const int64_t* masks, float* dword,
                                      float* dee, float* dfe, int32_t B, int32_t L, int32_t K, int32_t F, int32_t V,
                                      int32_t d, int32_t pad_token, float scale, float drop_p, uint32_t drop_seed,
-                                     uint32_t drop_site, void* stream) {
+                                     uint32_t drop_site, const uint32_t* drop_epoch, void* stream) {
     ICK_CHECK_ARG(dx && captions && masks && dee && B > 0 && L > 0 && K > 0 && d > 0);
     hipLaunchKernelGGL(caption_embed_bwd_kernel, dim3(ceil_div((int64_t)B * L, 4)), dim3(256), 0, (hipStream_t)stream,
                        dx, captions, masks, dword, dee, dfe, B, L, K, F, V, d, pad_token, scale,
-                       make_dropout(drop_p, drop_seed, drop_site));
+                       DropArg{drop_p, drop_seed, drop_site, drop_epoch});
     ICK_LAUNCH_RET();
 }
 
@@ -447,12 +454,11 @@ extern "C" int ick_context_gate_bwd(const int64_t* captions, const int64_t* fact
 }
 
 extern "C" int ick_adam_clamp(float* p, float* g, float* m, float* v, int64_t n, float gscale, float clip, float lr,
-                              float beta1, float beta2, float eps, int32_t step, void* stream) {
-    ICK_CHECK_ARG(p && g && m && v && n > 0 && step >= 1);
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2 = 1.f - powf(beta2, (float)step);
+                              float beta1, float beta2, float eps, int32_t step, const uint32_t* step_ptr,
+                              void* stream) {
+    ICK_CHECK_ARG(p && g && m && v && n > 0 && (step >= 1 || step_ptr != nullptr));
     hipLaunchKernelGGL(adam_clamp_kernel, dim3((int)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0,
-                       (hipStream_t)stream, p, g, m, v, n, gscale, clip, lr, beta1, beta2, eps, bc1, sqrtf(bc2));
+                       (hipStream_t)stream, p, g, m, v, n, gscale, clip, lr, beta1, beta2, eps, step, step_ptr);
     ICK_LAUNCH_RET();
 }
 
@@ -460,5 +466,11 @@ extern "C" int ick_scale_by_ratio(float* x, int64_t n, const float* num, const f
     ICK_CHECK_ARG(x && num && den && n > 0);
     hipLaunchKernelGGL(scale_kernel, dim3((int)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0,
                        (hipStream_t)stream, x, n, num, den);
+    ICK_LAUNCH_RET();
+}
+
+extern "C" int ick_counter_add(uint32_t* counter, uint32_t inc, void* stream) {
+    ICK_CHECK_ARG(counter != nullptr);
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, inc);
     ICK_LAUNCH_RET();
 }

@@ -83,5 +83,13 @@ __host__ __device__ __forceinline__ Dropout make_dropout(float p, uint32_t seed,
     }
     return d;
 }
+// Kernel-side form: the effective seed is `seed + *epoch` when a device-resident step counter is given, so a
+// captured hipGraph draws fresh masks on every replay (the counter is bumped by ick_counter_add in the graph).
+struct DropArg {
+    float p;
+    uint32_t seed, site;
+    const uint32_t* epoch;
+    __device__ __forceinline__ Dropout get() const { return make_dropout(p, epoch ? seed + *epoch : seed, site); }
+};
 
 }  // namespace ick

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m,
     const float alpha = p.alpha;
     int64_t coff[TM][4];
     int rowid[TM][4];
-    const Dropout drop = make_dropout(p.drop_p, p.drop_seed, p.drop_site);
+    const Dropout drop = make_dropout(p.drop_p, p.drop_epoch ? p.drop_seed + *p.drop_epoch : p.drop_seed, p.drop_site);
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll

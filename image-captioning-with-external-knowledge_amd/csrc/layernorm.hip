@@ -16,10 +16,11 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             int64_t rows, int d, float eps, int64_t x_ld,
                                                             int64_t res_ld, int64_t y_ld, float* save_mean,
-                                                            float* save_rstd, Dropout drop) {
+                                                            float* save_rstd, DropArg darg) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    const Dropout drop = darg.get();
     const float* xr = x + row * x_ld;
     const float* rr = res ? res + row * res_ld : nullptr;
     float v[NJ], g[NJ], bt[NJ];
@@ -68,12 +69,12 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
 extern "C" int ick_add_layernorm(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                                  int64_t rows, int32_t d, float eps, int64_t x_ld, int64_t res_ld, int64_t y_ld,
                                  float* save_mean, float* save_rstd, float drop_p, uint32_t drop_seed,
-                                 uint32_t drop_site, void* stream) {
+                                 uint32_t drop_site, const uint32_t* drop_epoch, void* stream) {
     using namespace ick;
     ICK_CHECK_ARG(x && gamma && beta && y);
     ICK_CHECK_ARG(rows > 0 && d > 0 && d <= 64 * kMaxPerLane);
     ICK_CHECK_ARG((save_mean == nullptr) == (save_rstd == nullptr));
-    const Dropout dr = make_dropout(drop_p, drop_seed, drop_site);
+    const DropArg dr{drop_p, drop_seed, drop_site, drop_epoch};
     const dim3 grid(ceil_div(rows, 4));
     hipStream_t s = (hipStream_t)stream;
     if (d <= 320)

@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256) void caption_embed_kernel(const int64_t* __res
                                                             const float* __restrict__ fe, const float* __restrict__ pe,
                                                             float* __restrict__ out, float* __restrict__ emb_out, int B,
                                                             int L, int K, int F, int V, int d, int pad_token,
-                                                            float scale, int pos0, Dropout drop) {
+                                                            float scale, int pos0, DropArg darg) {
+    const Dropout drop = darg.get();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B * L) return;
@@ -253,14 +254,14 @@ extern "C" int ick_caption_embed(const int64_t* captions, const int64_t* masks, 
                                  const float* entities_encoded, const float* facts_encoded, const float* pe,
                                  float* out, float* emb_out, int32_t B, int32_t L, int32_t K, int32_t F, int32_t V,
                                  int32_t d, int32_t pad_token, float scale, int32_t pos0, float drop_p,
-                                 uint32_t drop_seed, uint32_t drop_site, void* stream) {
+                                 uint32_t drop_seed, uint32_t drop_site, const uint32_t* drop_epoch, void* stream) {
     using namespace ick;
     ICK_CHECK_ARG(captions && masks && word_emb && entities_encoded && pe && out);
     ICK_CHECK_ARG(B > 0 && L > 0 && K > 0 && V > 0 && d > 0 && pos0 >= 0);
     if (facts_encoded) ICK_CHECK_ARG(F > 0);
     hipLaunchKernelGGL(caption_embed_kernel, dim3(ceil_div((int64_t)B * L, 4)), dim3(256), 0, (hipStream_t)stream,
                        captions, masks, word_emb, entities_encoded, facts_encoded, pe, out, emb_out, B, L, K, F, V, d,
-                       pad_token, scale, pos0, make_dropout(drop_p, drop_seed, drop_site));
+                       pad_token, scale, pos0, DropArg{drop_p, drop_seed, drop_site, drop_epoch});
     ICK_LAUNCH_RET();
 }
 

@@ -29,7 +29,7 @@ class GemmArgs(C.Structure):
         ("c_rs", i64), ("c_grp", i32), ("c_gs", i64), ("c_gmap", vp),
         ("flags", i32), ("split_k", i32), ("alpha", f32),
         ("hs_dh", i32), ("hs_dhp", i32), ("hs_H", i32), ("hs_S", i32), ("hs_s0", i32),
-        ("drop_p", f32), ("drop_seed", u32), ("drop_site", u32),
+        ("drop_p", f32), ("drop_seed", u32), ("drop_site", u32), ("drop_epoch", vp),
     ]
 
 
@@ -40,7 +40,7 @@ class AttnArgs(C.Structure):
         ("q_bs", i64), ("q_hs", i64), ("q_ts", i64), ("k_bs", i64), ("k_hs", i64), ("k_ss", i64),
         ("v_bs", i64), ("v_hs", i64), ("v_ss", i64), ("o_bs", i64), ("o_ts", i64),
         ("scale", f32), ("causal", i32), ("q_pos0", i32), ("kv_len", vp),
-        ("drop_p", f32), ("drop_seed", u32), ("drop_site", u32),
+        ("drop_p", f32), ("drop_seed", u32), ("drop_site", u32), ("drop_epoch", vp),
     ]
 
 
@@ -52,7 +52,7 @@ class AttnBwdArgs(C.Structure):
         ("v_bs", i64), ("v_hs", i64), ("v_ss", i64), ("o_bs", i64), ("o_ts", i64),
         ("dq_bs", i64), ("dq_ts", i64), ("dk_bs", i64), ("dk_ss", i64), ("dv_bs", i64), ("dv_ss", i64),
         ("scale", f32), ("causal", i32), ("q_pos0", i32),
-        ("drop_p", f32), ("drop_seed", u32), ("drop_site", u32),
+        ("drop_p", f32), ("drop_seed", u32), ("drop_site", u32), ("drop_epoch", vp),
     ]
 
 
@@ -61,12 +61,12 @@ SIGNATURES = {
     "ick_version": [],
     "ick_device_info": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int],
     "ick_gemm": [C.POINTER(GemmArgs), vp],
-    "ick_add_layernorm": [vp, vp, vp, vp, vp, i64, i32, f32, i64, i64, i64, vp, vp, f32, u32, u32, vp],
+    "ick_add_layernorm": [vp, vp, vp, vp, vp, i64, i32, f32, i64, i64, i64, vp, vp, f32, u32, u32, vp, vp],
     "ick_attention": [C.POINTER(AttnArgs), vp],
     "ick_entity_encode": [i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp],
     "ick_fact_encode": [vp, vp, vp, i32, vp, i32, i32, i32, i32, vp],
     "ick_caption_embed": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, f32, u32, u32,
-                          vp],
+                          vp, vp],
     "ick_context_indicators": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "ick_pointer_scores": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i32, vp, vp],
     "ick_mul": [vp, vp, vp, i64, vp],
@@ -75,15 +75,16 @@ SIGNATURES = {
     "ick_greedy_update": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "ick_packed_ce": [vp, i64, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "ick_attention_bwd": [C.POINTER(AttnBwdArgs), vp],
-    "ick_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, f32, u32, u32, vp],
+    "ick_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, f32, u32, u32, vp, vp],
     "ick_relu_bwd": [vp, vp, vp, i64, f32, vp],
     "ick_colsum": [vp, i64, i32, i64, vp, vp],
-    "ick_caption_embed_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, u32, u32, vp],
+    "ick_caption_embed_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, u32, u32, vp, vp],
     "ick_pointer_scores_bwd": [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "ick_entity_encode_bwd": [i32, vp, vp, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, vp],
     "ick_fact_encode_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "ick_context_gate_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
-    "ick_adam_clamp": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, i32, vp],
+    "ick_adam_clamp": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, i32, vp, vp],
+    "ick_counter_add": [vp, u32, vp],
     "ick_scale_by_ratio": [vp, i64, vp, vp, vp],
 }
 

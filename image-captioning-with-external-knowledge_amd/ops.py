@@ -28,15 +28,17 @@ TIMED = None
 
 
 def _drop(a, drop):
-    """drop = (p, seed, site) or None -> fields of an args struct."""
+    """drop = (p, seed, site[, epoch_tensor]) or None -> fields of an args struct."""
     if drop is not None and drop[0] > 0.0:
         a.drop_p, a.drop_seed, a.drop_site = float(drop[0]), int(drop[1]) & 0xFFFFFFFF, int(drop[2]) & 0xFFFFFFFF
+        a.drop_epoch = _p(drop[3]) if len(drop) > 3 else None
 
 
 def _dargs(drop):
     if drop is not None and drop[0] > 0.0:
-        return float(drop[0]), int(drop[1]) & 0xFFFFFFFF, int(drop[2]) & 0xFFFFFFFF
-    return 0.0, 0, 0
+        return (float(drop[0]), int(drop[1]) & 0xFFFFFFFF, int(drop[2]) & 0xFFFFFFFF,
+                _p(drop[3]) if len(drop) > 3 else None)
+    return 0.0, 0, 0, None
 
 
 def gemm_raw(A, B, Cout, M, N, K, a_rs, a_ks, b_rs, b_ks, c_rs, bias=None, a_grp=0, a_gs=0, a_gmap=None,
@@ -330,16 +332,57 @@ def colsum(a2d, out):
     return out
 
 
+class SideStream:
+    """Second HIP stream for work that is off the critical path of the backward pass: the weight and bias
+    gradients of a Linear only feed the optimizer, while the data gradient feeds the next layer's backward.
+    fork(): the side stream waits for everything enqueued so far on the main stream; join(): the main stream
+    waits for the side stream (before the all-reduce / optimizer, or before a tensor the side stream reads is
+    overwritten)."""
+
+    def __init__(self):
+        self.stream = torch.cuda.Stream()
+        self.pending = False
+        self.keep = []   # tensors the side stream reads stay referenced until the pass ends, so the caching
+                         # allocator cannot hand their memory to the main stream meanwhile (also under capture)
+
+    def fork(self, *tensors):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.stream.wait_event(ev)
+        self.keep.extend(t for t in tensors if t is not None)
+        self.pending = True
+        return torch.cuda.stream(self.stream)
+
+    def join(self):
+        if self.pending:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.pending = False
+
+
+SIDE = None   # set by training.TrainStep / backward_from_tape for the duration of a backward pass
+
+
 def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False):
     """Backward of y = x @ w.T + b for row-major 2-D views dy (M,N), x (M,K), w (N,K):
-    dw += dy.T @ x (split-K over M, float atomics), db += colsum(dy), dx = dy @ w."""
+    dw += dy.T @ x (split-K over M, float atomics), db += colsum(dy), dx = dy @ w.
+    With a SideStream installed the two parameter gradients run beside the data gradient."""
     M, N = dy.shape
     K = x.shape[1]
-    if dw is not None:
-        gemm_raw(dy, x, dw, N, K, M, 1, dy.stride(0), 1, x.stride(0), dw.stride(0), atomic=True,
-                 split_k=max(1, min(16, M // 256)))
-    if db is not None:
-        colsum(dy, db)
+
+    def param_grads():
+        if dw is not None:
+            gemm_raw(dy, x, dw, N, K, M, 1, dy.stride(0), 1, x.stride(0), dw.stride(0), atomic=True,
+                     split_k=max(1, min(16, M // 256)))
+        if db is not None:
+            colsum(dy, db)
+
+    if SIDE is not None and (dw is not None or db is not None):
+        if accumulate_dx:
+            SIDE.join()          # dx may alias a tensor an earlier parameter-gradient kernel still reads
+        with SIDE.fork(dy, x):
+            param_grads()
+    else:
+        param_grads()
     if need_dx:
         # a long reduction (the vocabulary: N = 10k..50k) over few output tiles is split over workgroups
         split = max(1, min(16, N // 1024)) if (M * K) <= 1280 * 512 else 1
@@ -396,9 +439,14 @@ def context_gate_bwd(captions, facts, dgate, dw, dbias, K, V, mode=0):
                                           dw.shape[1], d, mode, _stream()), "ick_context_gate_bwd")
 
 
-def adam_clamp(p, g, m, v, step, lr, clip=5.0, gscale=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
+def adam_clamp(p, g, m, v, step, lr, clip=5.0, gscale=1.0, beta1=0.9, beta2=0.999, eps=1e-8, step_tensor=None):
+    """step (+ the uint32 device counter step_tensor, if given) is Adam's 1-based step count."""
     L.check(L.load().ick_adam_clamp(_p(p), _p(g), _p(m), _p(v), p.numel(), gscale, clip, lr, beta1, beta2, eps, step,
-                                    _stream()), "ick_adam_clamp")
+                                    _p(step_tensor), _stream()), "ick_adam_clamp")
+
+
+def counter_add(counter, inc=1):
+    L.check(L.load().ick_counter_add(_p(counter), inc, _stream()), "ick_counter_add")
 
 
 def scale_by_ratio(x, num, den):

@@ -37,14 +37,15 @@ class DropSites:
     """Hands out (p, seed, site) triples: one site id per dropout call site of a step, so the backward
     kernels regenerate exactly the masks the forward used (ick_dropout_mask in include/ick_amd.h)."""
 
-    def __init__(self, seed, enabled):
-        self.seed, self.enabled, self.next = seed, enabled, 0
+    def __init__(self, seed, enabled, epoch=None):
+        self.seed, self.enabled, self.next, self.epoch = seed, enabled, 0, epoch
 
     def site(self, p):
         if not self.enabled or p <= 0.0:
             return None
         self.next += 1
-        return (float(p), self.seed, self.next)
+        return (float(p), self.seed, self.next, self.epoch) if self.epoch is not None else \
+            (float(p), self.seed, self.next)
 
 
 def _p(x):
@@ -107,12 +108,15 @@ def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds):
     return x
 
 
-def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gmap, seed=0):
+def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gmap, seed=0, epoch=None,
+                      fresh_pack=False):
     """Teacher-forced forward on already length-sorted inputs; returns (scores, tape).  Dropout is
-    active iff the module is in train() mode (masks derive from `seed`)."""
+    active iff the module is in train() mode (masks derive from `seed` + the device counter `epoch`).
+    fresh_pack: rebuild the packed cross-K/V / transposed predicate weights from the live parameters
+    (needed when they are updated behind torch's version counters, and inside captured graphs)."""
     tape = Tape()
     m = tape.misc
-    ds = DropSites(seed, dec.training)
+    ds = DropSites(seed, dec.training, epoch)
     d, V, H = dec.emb_dim, dec.vocab_size, dec.num_heads
     B, L = captions.shape
     P, K = enc_tok.shape[1], entities.shape[1]
@@ -133,7 +137,12 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     img = enc_tok.index_select(0, gmap.long()) if gmap is not None else enc_tok
     mem = torch.cat([img, ctx_e] + ([ctx_f] if dec.has_facts else []), dim=1)
     S = mem.shape[1]
-    wkv, bkv = dec._packed_cross_kv()
+    if fresh_pack:
+        layers_ = dec.transformer_decoder.layers
+        wkv = torch.cat([_p(l.multihead_attn.in_proj_weight)[d:] for l in layers_])
+        bkv = torch.cat([_p(l.multihead_attn.in_proj_bias)[d:] for l in layers_])
+    else:
+        wkv, bkv = dec._packed_cross_kv()
     nseg = wkv.shape[0] // d
     kv = ops.project_heads(mem, wkv, bkv, nseg, H, S)
     pe = dec.pos_encoder.pe.view(-1, d)
@@ -144,7 +153,8 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         x = _decoder_layer_fwd(dec, li, layer, x, kv, S, tape.dec_layers, ds)
     eib = gate = hv = None
     if dec.has_facts:
-        eib, gate = ops.context_indicators(captions, facts, K, V, dec._pred_wt(), _p(dec.fc_predicate.bias), mode=0)
+        pred_wt = _p(dec.fc_predicate.weight).t().contiguous() if fresh_pack else dec._pred_wt()
+        eib, gate = ops.context_indicators(captions, facts, K, V, pred_wt, _p(dec.fc_predicate.bias), mode=0)
         hv = ops.mul(x, gate)
     Vx = V + K + Fn
     scores = torch.empty(B, L, Vx, device=x.device, dtype=torch.float32)
@@ -237,9 +247,21 @@ def _decoder_layer_bwd(dec, li, layer, t, dx, dkv_rows, kv, S, grads):
                     layer.self_attn.in_proj_bias, dx=dz.view(M, d), acc=True).view(B, T, d)
 
 
-def backward_from_tape(dec, tape, dscores, grads):
+def backward_from_tape(dec, tape, dscores, grads, overlap=True):
     """Accumulate parameter gradients of `dec` into `grads` (dict id(param) -> zero-initialised
-    tensor shaped like the parameter; frozen parameters are simply absent)."""
+    tensor shaped like the parameter; frozen parameters are simply absent).  With `overlap` the weight /
+    bias gradients of the Linear layers run on a second HIP stream beside the data-gradient chain."""
+    side = ops.SideStream() if overlap else None
+    ops.SIDE = side
+    try:
+        _backward_from_tape(dec, tape, dscores, grads)
+    finally:
+        ops.SIDE = None
+        if side is not None:
+            side.join()
+
+
+def _backward_from_tape(dec, tape, dscores, grads):
     m = tape.misc
     d, V, H = dec.emb_dim, dec.vocab_size, dec.num_heads
     h, ee, fe = m["h"], m["ee"], m["fe"]
@@ -355,13 +377,23 @@ class TrainStep:
     Gradient semantics equal the single-process full-batch step of the reference: every rank
     contributes the SUM of its token losses' gradients plus its token count; after the
     all-reduce(sum) the bucket is divided by the global token count, clamped to +-grad_clip
-    (geo-aware/train.py:287-288 clamps the full-batch gradient) and fed to Adam (lr 4e-4)."""
+    (geo-aware/train.py:287-288 clamps the full-batch gradient) and fed to Adam (lr 4e-4).
 
-    def __init__(self, decoder, lr=4e-4, grad_clip=5.0, betas=(0.9, 0.999), eps=1e-8, process_group=None, seed=0):
+    With use_graph the device work is two captured hipGraphs around the (eager) collective:
+      A  zero the bucket, forward with saved activations, packed cross entropy, backward -- the
+         weight / bias gradients run on a second stream beside the data-gradient chain (fork/join
+         edges of the graph);
+      B  divide by the reduced token count, clamp, Adam, bump the step counter.
+    The step counter lives on the device: it seeds the dropout masks and Adam's bias correction, so
+    replays advance without re-capturing."""
+
+    def __init__(self, decoder, lr=4e-4, grad_clip=5.0, betas=(0.9, 0.999), eps=1e-8, process_group=None, seed=0,
+                 use_graph=True):
         self.dec = decoder
         self.seed = seed  # dropout mask stream; give every rank its own seed
         self.lr, self.clip, self.betas, self.eps = lr, grad_clip, betas, eps
         self.pg = process_group
+        self.use_graph = use_graph
         self.step_count = 0
         params = [p for p in unique_parameters(decoder) if p.requires_grad]
         dev = params[0].device
@@ -372,6 +404,8 @@ class TrainStep:
         self.flat_g = torch.zeros(n + 2, device=dev, dtype=torch.float32)
         self.flat_m = torch.zeros(n, device=dev, dtype=torch.float32)
         self.flat_v = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.counter = torch.zeros(1, device=dev, dtype=torch.int32)   # steps done (read as uint32 by the kernels)
+        self.one = torch.ones(1, device=dev, dtype=torch.float32)
         self.grads = {}
         off = 0
         with torch.no_grad():
@@ -382,6 +416,40 @@ class TrainStep:
                 self.grads[id(p)] = self.flat_g[off:off + k].view(p.shape)
                 off += k
         self.params = params
+        self._graphs = {}
+
+    # ---- device-only halves -------------------------------------------------------------------
+    def _part_a(self, captions, caption_masks, entities, facts, enc_tok, gmap, decode_len):
+        dec = self.dec
+        self.flat_g.zero_()
+        scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gmap,
+                                         seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True)
+        loss_sum, count, dscores = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True)
+        backward_from_tape(dec, tape, dscores, self.grads, overlap=self.use_graph)
+        self.flat_g[self.n:self.n + 1].copy_(loss_sum)
+        self.flat_g[self.n + 1:].copy_(count)
+        return self.flat_g
+
+    def _part_b(self):
+        # divide by the global token count (device-resident), clamp, Adam with the device step counter
+        ops.scale_by_ratio(self.flat_g[:self.n], self.one, self.flat_g[self.n + 1:])
+        ops.adam_clamp(self.flat_p, self.flat_g, self.flat_m, self.flat_v, 1, self.lr, self.clip, 1.0,
+                       self.betas[0], self.betas[1], self.eps, step_tensor=self.counter)
+        ops.counter_add(self.counter, 1)
+        return self.flat_g
+
+    def _capture(self, fn, inputs):
+        static = [None if t is None else t.clone() for t in inputs]
+        # warm-up off the capture (lazy kernel attributes); the warm-up steps touch the gradient bucket only
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn(*static)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn(*static)
+        return g, static
 
     def __call__(self, captions, encoder_out, caption_masks, caption_lengths, entities, facts=None):
         dec = self.dec
@@ -394,22 +462,34 @@ class TrainStep:
         entities = entities[sort_dev].contiguous()
         if dec.has_facts:
             facts = facts[sort_dev].contiguous()
-        enc_tok = dec._token_major(encoder_out)
+        enc_tok = dec._token_major(encoder_out).contiguous()
         decode_len = (lengths - 1).to(torch.int32).to(dev)
-        self.flat_g.zero_()
-        seed = (self.seed * 2654435761 + self.step_count + 1) & 0xFFFFFFFF
-        scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok,
-                                         sort_dev.to(torch.int32), seed=seed)
-        loss_sum, count, dscores = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True)
-        backward_from_tape(dec, tape, dscores, self.grads)
-        self.flat_g[self.n:self.n + 1].copy_(loss_sum)
-        self.flat_g[self.n + 1:].copy_(count)
-        dp.allreduce_bucket(self.flat_g, self.pg)
-        # divide by the global token count (device-resident), clamp, Adam
-        ops.scale_by_ratio(self.flat_g[:self.n], torch.ones_like(count), self.flat_g[self.n + 1:])
+        inputs = [captions, caption_masks, entities, facts, enc_tok, sort_dev.to(torch.int32), decode_len]
+        if self.use_graph:
+            key = tuple(None if t is None else tuple(t.shape) for t in inputs)
+            if key not in self._graphs:
+                if len(self._graphs) >= 4:
+                    self._graphs.clear()
+                # the eager warm-up run of part B is a real optimizer step: snapshot and rewind its state
+                state = (self.flat_p, self.flat_m, self.flat_v, self.counter)
+                snap = [t.clone() for t in state]
+                ga, static = self._capture(self._part_a, inputs)
+                gb, _ = self._capture(self._part_b, [])
+                for t, sv in zip(state, snap):
+                    t.copy_(sv)
+                self._graphs[key] = (ga, static, gb)
+            ga, static, gb = self._graphs[key]
+            for dst, src in zip(static, inputs):
+                if dst is not None:
+                    dst.copy_(src, non_blocking=True)
+            ga.replay()
+            dp.allreduce_bucket(self.flat_g, self.pg)
+            gb.replay()
+        else:
+            self._part_a(*inputs)
+            dp.allreduce_bucket(self.flat_g, self.pg)
+            self._part_b()
         self.step_count += 1
-        ops.adam_clamp(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count, self.lr, self.clip, 1.0,
-                       self.betas[0], self.betas[1], self.eps)
         dec.invalidate_caches()   # the update went around torch's version counters
         # token-mean loss of the global batch, still on the device
         return self.flat_g[self.n:self.n + 1] / self.flat_g[self.n + 1:]

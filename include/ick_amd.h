@@ -64,6 +64,7 @@ typedef struct {
     float   alpha;         /* scales the product before bias (1.0f normally) */
     int32_t hs_dh, hs_dhp, hs_H, hs_S, hs_s0;   /* head-split epilogue, see above (hs_dh == 0: off) */
     float drop_p; uint32_t drop_seed, drop_site; /* training dropout on the output (after bias/ReLU), see ick_dropout_mask */
+    const uint32_t* drop_epoch;                  /* optional device counter added to drop_seed (graph replays) */
 } ick_gemm_args;
 
 #define ICK_GEMM_RELU 1
@@ -81,7 +82,7 @@ int ick_add_layernorm(const float* x, const float* res, const float* gamma, cons
                       int64_t x_ld, int64_t res_ld, int64_t y_ld,
                       float* save_mean, float* save_rstd,
                       float drop_p, uint32_t drop_seed, uint32_t drop_site, /* dropout applied to x (dropout1/2/3) */
-                      void* stream);
+                      const uint32_t* drop_epoch, void* stream);
 
 /* Multi-head attention core: O = softmax(Q K^T * scale [+ causal mask]) V per (batch, head).
  * Q element (b,t,h,j) at Q[b*q_bs + h*q_hs + t*q_ts + j]; K/V element (b,s,h,j) at
@@ -100,6 +101,7 @@ typedef struct {
     int64_t q_bs, q_hs, q_ts, k_bs, k_hs, k_ss, v_bs, v_hs, v_ss, o_bs, o_ts;
     float scale; int32_t causal; int32_t q_pos0; const int32_t* kv_len;
     float drop_p; uint32_t drop_seed, drop_site;   /* attention-weight dropout (training), element index ((b*H+h)*T+t)*S+s */
+    const uint32_t* drop_epoch;
 } ick_attn_args;
 int ick_attention(const ick_attn_args* args, void* stream);
 
@@ -131,7 +133,7 @@ int ick_caption_embed(const int64_t* captions, const int64_t* masks, const float
                       float* out, float* emb_out, int32_t B, int32_t L, int32_t K, int32_t F, int32_t V,
                       int32_t d, int32_t pad_token, float scale, int32_t pos0,
                       float drop_p, uint32_t drop_seed, uint32_t drop_site, /* PositionEncoder dropout (training) */
-                      void* stream);
+                      const uint32_t* drop_epoch, void* stream);
 
 /* get_context_indicators: knowledge-aware/models.py:380-418.  Produces, per (b, position p):
  *   eib (B,T,F) 0/1: subject of fact j was mentioned before p (T==L) / anywhere so far (T==1)
@@ -205,6 +207,7 @@ typedef struct {
     int64_t dq_bs, dq_ts, dk_bs, dk_ss, dv_bs, dv_ss;
     float scale; int32_t causal; int32_t q_pos0;
     float drop_p; uint32_t drop_seed, drop_site;   /* must equal the forward's */
+    const uint32_t* drop_epoch;
 } ick_attn_bwd_args;
 int ick_attention_bwd(const ick_attn_bwd_args* args, void* stream);
 
@@ -212,7 +215,7 @@ int ick_attention_bwd(const ick_attn_bwd_args* args, void* stream);
 int ick_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma, const float* mean,
                       const float* rstd, float* dz, float* dgamma, float* dbeta, int64_t rows, int32_t d,
                       float* dx_drop /* dz * mask: gradient of the dropped operand x (drop_p > 0) */,
-                      float drop_p, uint32_t drop_seed, uint32_t drop_site, void* stream);
+                      float drop_p, uint32_t drop_seed, uint32_t drop_site, const uint32_t* drop_epoch, void* stream);
 /* dx = dy where the forward ReLU output `act` was positive, else 0. */
 int ick_relu_bwd(const float* dy, const float* act, float* dx, int64_t n, float scale /* 1/(1-p) of the FFN dropout */,
                  void* stream);
@@ -222,7 +225,7 @@ int ick_colsum(const float* a, int64_t M, int32_t N, int64_t ld, float* out, voi
 int ick_caption_embed_bwd(const float* dx, const int64_t* captions, const int64_t* masks, float* dword,
                           float* dee, float* dfe, int32_t B, int32_t L, int32_t K, int32_t F, int32_t V,
                           int32_t d, int32_t pad_token, float scale, float drop_p, uint32_t drop_seed,
-                          uint32_t drop_site, void* stream);
+                          uint32_t drop_site, const uint32_t* drop_epoch, void* stream);
 /* Backward of ick_pointer_scores: ds = dscores[..., col0:col0+Kc] (row stride ds_ld);
  * dh += ..., dctx += ..., dw += ..., dbias += ... */
 int ick_pointer_scores_bwd(const float* ds, int64_t ds_ld, int32_t col0, const float* h, const float* ctx,
@@ -241,9 +244,12 @@ int ick_context_gate_bwd(const int64_t* captions, const int64_t* facts, const fl
                          float* dbias, int32_t B, int32_t L, int32_t T, int32_t K, int32_t F, int32_t V,
                          int32_t num_pred, int32_t d, int32_t mode, void* stream);
 /* g = clamp(g*gscale, +-clip) (clip <= 0: no clamp) followed by torch.optim.Adam's update, one flat
- * fp32 bucket; `step` is the 1-based step count. */
+ * fp32 bucket; the 1-based step count is step + *step_ptr (step_ptr may be NULL; a device-resident counter
+ * lets a captured graph advance the bias correction on every replay). */
 int ick_adam_clamp(float* p, float* g, float* m, float* v, int64_t n, float gscale, float clip, float lr,
-                   float beta1, float beta2, float eps, int32_t step, void* stream);
+                   float beta1, float beta2, float eps, int32_t step, const uint32_t* step_ptr, void* stream);
+/* *counter += inc on the stream (step / dropout-epoch counter of captured training graphs). */
+int ick_counter_add(uint32_t* counter, uint32_t inc, void* stream);
 /* x *= num[0] / den[0] with device-resident scalars (token-mean normalisation without a host sync). */
 int ick_scale_by_ratio(float* x, int64_t n, const float* num, const float* den, void* stream);
 

@@ -96,7 +96,7 @@ int main(int argc, char** argv) {
     attn("cross attention", 64, 20, 216, 0);
     attn("self attention", 64, 20, 20, 1);
     attn("decode cross", 64, 1, 216, 0);
-    float us = timeit([&] { ick_add_layernorm(A, B, bias, bias, C, 1280, 300, 1e-5f, 300, 300, 300, nullptr, nullptr, 0.f, 0, 0, st); }, iters);
+    float us = timeit([&] { ick_add_layernorm(A, B, bias, bias, C, 1280, 300, 1e-5f, 300, 300, 300, nullptr, nullptr, 0.f, 0, 0, nullptr, st); }, iters);
     printf("%-28s rows=1280               : %8.2f us\n", "add_layernorm", us);
     return 0;
 }
