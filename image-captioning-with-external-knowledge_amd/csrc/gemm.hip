@@ -57,13 +57,14 @@ __device__ __forceinline__ int64_t col_offset(const ick_gemm_args& p, int col) {
 // unconditional global_load_dwordx4 from clamped (always valid) addresses and out-of-range rows
 // or k-slices are zeroed by selects -- no branches, all loads of a slice stay in flight together.
 // !VEC is the generic element-wise fallback for ragged / unaligned operands.
-template <int R, bool KM, bool VEC>
+template <int R, bool KM, bool VEC, int BKT = BK>
 struct Stager {
-    static constexpr int NP = R / 32;                // float4 per thread
-    static constexpr int CH = KM ? R / 4 : BK / 4;   // float4 chunks along the contiguous dim
-    static constexpr int LD = KM ? R + 4 : LDK;
-    static constexpr int FLOATS = KM ? BK * LD : R * LD;
+    static constexpr int NP = R * BKT / 1024;        // float4 per thread (256 threads)
+    static constexpr int CH = KM ? R / 4 : BKT / 4;  // float4 chunks along the contiguous dim
+    static constexpr int LD = KM ? R + 4 : BKT + 4;
+    static constexpr int FLOATS = KM ? BKT * LD : R * LD;
     static constexpr int KP = 256 / CH;              // k-major: k lines covered per pass
+    static constexpr int RP = 256 / CH;              // k-contiguous: rows covered per pass
     const float* base;
     int64_t off[KM ? 4 : NP];  // k-contig: one clamped row offset per pass; k-major: this thread's 4 rows
     int64_t ks;
@@ -87,7 +88,7 @@ struct Stager {
         } else {
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
-                const int gr = tile_row0 + r0 + 32 * j;
+                const int gr = tile_row0 + r0 + RP * j;
                 if (gr < rows) ok |= 1u << j;
                 off[j] = m(min(gr, rows - 1));
             }
@@ -156,21 +157,22 @@ struct Stager {
                     x.x = (rv && k + 0 < kend) ? x.x : 0.f; x.y = (rv && k + 1 < kend) ? x.y : 0.f;
                     x.z = (rv && k + 2 < kend) ? x.z : 0.f; x.w = (rv && k + 3 < kend) ? x.w : 0.f;
                 }
-                *reinterpret_cast<float4*>(lds + (r0 + 32 * j) * LD + 4 * c) = x;
+                *reinterpret_cast<float4*>(lds + (r0 + RP * j) * LD + 4 * c) = x;
             }
         }
     }
 };
 
 // One 16-row fragment for the four MFMA steps of k-chunk t.
-template <int R, bool KM>
+template <int R, bool KM, int BKT = BK>
 __device__ __forceinline__ void read_frag(const float* lds, int row0, int t, int i, int q, float (&f)[4]) {
     if constexpr (KM) {
         constexpr int LD = R + 4;
 #pragma unroll
         for (int u = 0; u < 4; ++u) f[u] = lds[(16 * t + 4 * q + u) * LD + row0 + i];
     } else {
-        const float4 x = *reinterpret_cast<const float4*>(lds + (row0 + i) * LDK + 16 * t + 4 * q);
+        constexpr int LD = BKT + 4;
+        const float4 x = *reinterpret_cast<const float4*>(lds + (row0 + i) * LD + 16 * t + 4 * q);
         f[0] = x.x; f[1] = x.y; f[2] = x.z; f[3] = x.w;
     }
 }

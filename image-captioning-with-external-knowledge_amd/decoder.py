@@ -281,20 +281,26 @@ class DecoderTransformer(nn.Module):
         if self.has_facts:
             Fn = facts.shape[1]
             fe = ops.fact_encode(facts, ee, self.predicate_embedding.weight.detach())
-        ctx_e = self._context_encoder(self.transformer_encoder_entities, ee)
-        ctx_f = self._context_encoder(self.transformer_encoder_facts, fe) if self.has_facts else None
         wkv, bkv = self._packed_cross_kv()
         nseg = wkv.shape[0] // d
         S = P + K + Fn
         kv = torch.empty(B, nseg, H, S, ops.DHP, device=enc_tok.device, dtype=torch.float32)
-        # image rows (gathered through gmap = sort order), then entity and fact context rows
+        # The context-encoder chain (small, latency-bound kernels) runs on a second stream beside the
+        # large image-row projection; both write disjoint key/value rows of `kv`.  The caller joins the
+        # side stream before the first cross-attention (`side.join()`).
+        side = ops.SideStream()
+        with side.fork(ee, fe, kv, wkv, bkv):
+            ctx_e = self._context_encoder(self.transformer_encoder_entities, ee)
+            ops.project_heads(ctx_e, wkv, bkv, nseg, H, S, out=kv, s0=P, grp=K)
+            ctx_f = None
+            if self.has_facts:
+                ctx_f = self._context_encoder(self.transformer_encoder_facts, fe)
+                ops.project_heads(ctx_f, wkv, bkv, nseg, H, S, out=kv, s0=P + K, grp=Fn)
+        # image rows (gathered through gmap = sort order)
         ops.project_heads(enc_tok, wkv, bkv, nseg, H, S, out=kv, s0=0, grp=P, a_gmap=gmap, a_gs=enc_tok.stride(0))
-        ops.project_heads(ctx_e, wkv, bkv, nseg, H, S, out=kv, s0=P, grp=K)
-        if self.has_facts:
-            ops.project_heads(ctx_f, wkv, bkv, nseg, H, S, out=kv, s0=P + K, grp=Fn)
-        return ee, fe, kv, (ctx_e, ctx_f)
+        return ee, fe, kv, (ctx_e, ctx_f), side
 
-    def _decoder_layer(self, li, layer, x, kv, S, qkv_buf=None, pos=None):
+    def _decoder_layer(self, li, layer, x, kv, S, qkv_buf=None, pos=None, side=None):
         """One post-LN decoder layer on x (B, T, d).  With qkv_buf (B, 3, H, max_len, 32) the layer runs
         one KV-cached decode step: the new q|k|v row is written at position `pos` and attends to [0, pos]."""
         H, d = self.num_heads, self.emb_dim
@@ -314,6 +320,8 @@ class DecoderTransformer(nn.Module):
         ca_w, ca_b = layer.multihead_attn.in_proj_weight.detach(), layer.multihead_attn.in_proj_bias.detach()
         q = ops.project_heads(x, ca_w[:d], ca_b[:d], 1, H, T)
         ca = torch.empty_like(x)
+        if side is not None:
+            side.join()    # entity / fact rows of kv come from the side stream
         ops.attention_heads(q, kv, ca, H, dh, T, S, q_seg=0, k_seg=2 * li, v_seg=2 * li + 1)
         o = ops.linear(ca, layer.multihead_attn.out_proj.weight.detach(), layer.multihead_attn.out_proj.bias.detach())
         x = ops.add_layernorm(o, x, layer.norm2.weight.detach(), layer.norm2.bias.detach(), layer.norm2.eps)
@@ -353,13 +361,14 @@ class DecoderTransformer(nn.Module):
         """Device-only part of forward() on length-sorted inputs (no host synchronisation inside)."""
         d, V = self.emb_dim, self.vocab_size
         K = entities.shape[1]
-        ee, fe, kv, ctx = self._encode_context(enc_tok, entities, facts, gmap)
+        ee, fe, kv, ctx, side = self._encode_context(enc_tok, entities, facts, gmap)
         pe = self.pos_encoder.pe.view(-1, d)
         x, emb = ops.caption_embed(captions, caption_masks, self.word_embedding.weight.detach(), ee, fe, pe, V,
                                    self.word_map["<pad>"], math.sqrt(d), want_emb=True)
         S = kv.shape[3]
         for li, layer in enumerate(self.transformer_decoder.layers):
-            x = self._decoder_layer(li, layer, x, kv, S)
+            x = self._decoder_layer(li, layer, x, kv, S, side=side if li == 0 else None)
+        side.join()
         eib = gate = None
         if self.has_facts:
             eib, gate = ops.context_indicators(captions, facts, K, V, self._pred_wt(),
@@ -420,7 +429,8 @@ class DecoderTransformer(nn.Module):
         dev = enc_tok.device
         B = enc_tok.shape[0]
         d, V, K = self.emb_dim, self.vocab_size, entities.shape[1]
-        ee, fe, kv, _ = self._encode_context(enc_tok, entities, facts, None)
+        ee, fe, kv, _, side = self._encode_context(enc_tok, entities, facts, None)
+        side.join()
         S = kv.shape[3]
         pe = self.pos_encoder.pe.view(-1, d)
         nl = len(self.transformer_decoder.layers)

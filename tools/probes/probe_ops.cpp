@@ -27,12 +27,12 @@ int main(int argc, char** argv) {
     float *A, *B, *C, *bias;
     size_t na = (size_t)64 * 2048 * 196, nb = (size_t)64 * 6 * 10 * 256 * 32 /* >= KV of 64 samples */, nc = (size_t)13824 * 2048;
     setvbuf(stdout, nullptr, _IONBF, 0);
-    CK(hipMalloc(&A, na * 4)); CK(hipMalloc(&B, nb * 4)); CK(hipMalloc(&C, nc * 4)); CK(hipMalloc(&bias, 65536));
+    CK(hipMalloc(&A, na * 4)); CK(hipMalloc(&B, nb * 4)); CK(hipMalloc(&C, nc * 4)); CK(hipMalloc(&bias, 65536 * 4));
     std::vector<float> h(na);
     for (size_t i = 0; i < na; ++i) h[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
     CK(hipMemcpy(A, h.data(), na * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(B, h.data(), std::min(na, nb) * 4, hipMemcpyHostToDevice));
-    CK(hipMemset(bias, 0, 65536));
+    CK(hipMemset(bias, 0, 65536 * 4));
     auto gemm = [&](const char* name, int M, int N, int K, bool feat, int hs) {
         ick_gemm_args a; memset(&a, 0, sizeof(a));
         a.A = A; a.B = B; a.C = C; a.bias = bias; a.M = M; a.N = N; a.K = K; a.alpha = 1.f; a.split_k = 1;
@@ -98,5 +98,27 @@ int main(int argc, char** argv) {
     attn("decode cross", 64, 1, 216, 0);
     float us = timeit([&] { ick_add_layernorm(A, B, bias, bias, C, 1280, 300, 1e-5f, 300, 300, 300, nullptr, nullptr, 0.f, 0, 0, nullptr, st); }, iters);
     printf("%-28s rows=1280               : %8.2f us\n", "add_layernorm", us);
+    // backward probes
+    float *mean = bias + 4096, *rstd = bias + 8192;
+    us = timeit([&] { ick_layernorm_bwd(A, B, C, bias, mean, rstd, C + 4000000, bias + 1024, bias + 2048, 1280, 300, nullptr, 0.f, 0, 0, nullptr, st); }, iters);
+    printf("%-28s rows=1280               : %8.2f us\n", "layernorm_bwd", us);
+    us = timeit([&] { ick_colsum(A, 1280, 900, 900, bias + 1024, st); }, iters);
+    printf("%-28s 1280x900                : %8.2f us\n", "colsum", us);
+    auto attn_bwd = [&](const char* name, int Bn, int T, int S, int causal) {
+        ick_attn_bwd_args a; memset(&a, 0, sizeof(a));
+        a.Q = Q; a.K = KV; a.V = KV + (size_t)10 * S * 32; a.O = O; a.dO = O + 2000000; a.lse = bias;
+        a.dQ = O + 4000000; a.dK = O + 6000000; a.dV = O + 12000000;
+        a.B = Bn; a.H = 10; a.T = T; a.S = S; a.dh = 30;
+        a.q_bs = (int64_t)10 * T * 32; a.q_hs = T * 32; a.q_ts = 32;
+        a.k_bs = (int64_t)6 * 10 * S * 32; a.k_hs = S * 32; a.k_ss = 32; a.v_bs = a.k_bs; a.v_hs = a.k_hs; a.v_ss = 32;
+        a.o_bs = T * 300; a.o_ts = 300; a.dq_bs = T * 300; a.dq_ts = 300; a.dk_bs = S * 300; a.dk_ss = 300; a.dv_bs = S * 300; a.dv_ss = 300;
+        a.scale = 0.18f; a.causal = causal;
+        int rc = ick_attention_bwd(&a, st);
+        if (rc) { printf("%s rc=%d\n", name, rc); return; }
+        float t = timeit([&] { ick_attention_bwd(&a, st); }, iters);
+        printf("%-28s B=%3d T=%3d S=%3d       : %8.2f us\n", name, Bn, T, S, t);
+    };
+    attn_bwd("cross attention bwd", 64, 20, 216, 0);
+    attn_bwd("self attention bwd", 64, 20, 20, 1);
     return 0;
 }
