@@ -50,7 +50,8 @@ class _GraphedCall:
                 fn(*self.static_in)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: other threads (e.g. the RCCL watchdog) may touch the HIP runtime while we capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.static_out = fn(*self.static_in)
 
     def __call__(self, *inputs):

@@ -447,7 +447,8 @@ class TrainStep:
             fn(*static)
         torch.cuda.current_stream().wait_stream(side)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: the RCCL watchdog thread may query events while this thread captures
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             fn(*static)
         return g, static
 
@@ -465,19 +466,25 @@ class TrainStep:
         enc_tok = dec._token_major(encoder_out).contiguous()
         decode_len = (lengths - 1).to(torch.int32).to(dev)
         inputs = [captions, caption_masks, entities, facts, enc_tok, sort_dev.to(torch.int32), decode_len]
-        if self.use_graph:
-            key = tuple(None if t is None else tuple(t.shape) for t in inputs)
-            if key not in self._graphs:
-                if len(self._graphs) >= 4:
-                    self._graphs.clear()
-                # the eager warm-up run of part B is a real optimizer step: snapshot and rewind its state
-                state = (self.flat_p, self.flat_m, self.flat_v, self.counter)
-                snap = [t.clone() for t in state]
+        key = tuple(None if t is None else tuple(t.shape) for t in inputs)
+        if self.use_graph and key not in self._graphs:
+            if len(self._graphs) >= 4:
+                self._graphs.clear()
+            # the eager warm-up run of part B is a real optimizer step: snapshot and rewind its state
+            state = (self.flat_p, self.flat_m, self.flat_v, self.counter)
+            snap = [t.clone() for t in state]
+            try:
                 ga, static = self._capture(self._part_a, inputs)
                 gb, _ = self._capture(self._part_b, [])
-                for t, sv in zip(state, snap):
-                    t.copy_(sv)
                 self._graphs[key] = (ga, static, gb)
+            except RuntimeError as e:   # capture refused (driver / collective library state): run eagerly
+                import warnings
+                warnings.warn("ick_amd TrainStep: hipGraph capture failed (%s); continuing without graphs" % e)
+                torch.cuda.synchronize()
+                self.use_graph = False
+            for t, sv in zip(state, snap):
+                t.copy_(sv)
+        if self.use_graph:
             ga, static, gb = self._graphs[key]
             for dst, src in zip(static, inputs):
                 if dst is not None:

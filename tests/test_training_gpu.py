@@ -360,3 +360,28 @@ def test_train_step_matches_reference_sequence_and_dp_split():
     assert cnt.item() == summed[full.n + 1].item()
     err = (summed[:full.n] - full.flat_g[:full.n]).abs().max().item()
     assert err < 1e-4 * max(1.0, full.flat_g[:full.n].abs().max().item()), err
+
+
+def test_bench_two_ranks_share_the_gpu_over_gloo():
+    """The driver's multi-GPU launch line, rehearsed with two ranks on the one GPU of this box (collectives
+    over gloo instead of RCCL): rendezvous, per-rank shards, the bucket all-reduce inside the timed loop and
+    the single JSON line from rank 0."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, ICK_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["value"] > 0 and d["scaling"] == "weak"
