@@ -18,7 +18,9 @@
 //     ds_read_b32 in that same k order; both strides are bank-conflict free (<=2-way);
 //   * the tile index is remapped so the 8 XCDs (round-robin over blockIdx) each walk a
 //     contiguous run of tiles and the smaller operand panel stays in that XCD's L2.
+#include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -53,10 +55,16 @@ __device__ __forceinline__ int64_t col_offset(const ick_gemm_args& p, int col) {
 }
 
 // Global -> register -> LDS stager for one operand tile of R rows x BK k.
-// VEC: every row offset / K / base pointer is 16-byte friendly, so the tile is fetched with
-// unconditional global_load_dwordx4 from clamped (always valid) addresses and out-of-range rows
-// or k-slices are zeroed by selects -- no branches, all loads of a slice stay in flight together.
+// VEC: every row offset / K / base pointer is 16-byte friendly.  The tile is fetched with
+// buffer_load_dwordx4 through a raw buffer descriptor whose num_records is the operand's byte extent:
+// the per-lane byte offset of a row is fixed for the whole K loop (rows outside the matrix get an offset
+// beyond the extent), the K position is the scalar offset, and the hardware range check returns zeros
+// for anything out of bounds -- no address arithmetic, selects or branches in the loop, so the loads of
+// two slices stay in flight behind the MFMAs.  Only the last, partial K slice is masked (at LDS-store time).
 // !VEC is the generic element-wise fallback for ragged / unaligned operands.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr uint32_t kOobOffset = 0x80000000u;   // >= any extent the vector path accepts (< 2 GiB)
+
 template <int R, bool KM, bool VEC, int BKT = BK>
 struct Stager {
     static constexpr int NP = R * BKT / 1024;        // float4 per thread (256 threads)
@@ -66,21 +74,39 @@ struct Stager {
     static constexpr int KP = 256 / CH;              // k-major: k lines covered per pass
     static constexpr int RP = 256 / CH;              // k-contiguous: rows covered per pass
     const float* base;
-    int64_t off[KM ? 4 : NP];  // k-contig: one clamped row offset per pass; k-major: this thread's 4 rows
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[NP];         // VEC: byte offset of this thread's float4 of pass j at k = 0
+    int64_t off[KM ? 4 : NP];  // !VEC: clamped element offsets of the rows
     int64_t ks;
     int c, r0;
-    uint32_t ok;               // validity bits of the rows behind off[]
-    float4 v[NP];
+    uint32_t ok;               // !VEC: validity bits of the rows behind off[]
+    float4 v[2][NP];           // two register sets: the loads of slice i+2 fly while slice i+1 waits to be stored
 
-    __device__ __forceinline__ void init(const float* p, const RowMap& m, int64_t kstride, int tile_row0, int rows) {
+    __device__ __forceinline__ void init(const float* p, const RowMap& m, int64_t kstride, int tile_row0, int rows,
+                                         int64_t extent) {
         base = p; ks = kstride;
         const int t = threadIdx.x;
         c = t % CH;
         r0 = t / CH;
         ok = 0;
-        if constexpr (KM) {
+        if constexpr (VEC) {
+            rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), (short)0, (int)(extent * 4), 0x00020000);
+            if constexpr (KM) {
+                const int gr = tile_row0 + 4 * c;
+                const uint32_t ro = gr < rows ? (uint32_t)(m(gr) * 4) : kOobOffset;
 #pragma unroll
-            for (int q = 0; q < (VEC ? 1 : 4); ++q) {
+                for (int j = 0; j < NP; ++j)
+                    voff[j] = gr < rows ? ro + (uint32_t)((int64_t)(r0 + KP * j) * ks * 4) : kOobOffset;
+            } else {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const int gr = tile_row0 + r0 + RP * j;
+                    voff[j] = gr < rows ? (uint32_t)((m(gr) + 4 * c) * 4) : kOobOffset;
+                }
+            }
+        } else if constexpr (KM) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
                 const int gr = tile_row0 + 4 * c + q;
                 if (gr < rows) ok |= 1u << q;
                 off[q] = m(min(gr, rows - 1));
@@ -95,52 +121,47 @@ struct Stager {
         }
     }
 
-    // Issue the global loads of slice [k0, k0+BK) from clamped addresses; nothing here depends on the
-    // loaded data, so the loads stay in flight behind the MFMAs of the current slice.
+    // Issue the global loads of slice [k0, k0+BK); nothing here depends on loaded data.
+    template <int SET>
     __device__ __forceinline__ void load(int k0, int kend) {
-        if constexpr (KM) {
+        if constexpr (VEC) {
+            const int soff = KM ? (int)((int64_t)k0 * ks * 4) : k0 * 4;   // wave-uniform: scalar offset
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+                v[SET][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff[j], soff, 0));
+        } else if constexpr (KM) {
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 const int k = k0 + r0 + KP * j;
                 const int64_t ko = (int64_t)(k < kend ? k : 0) * ks;
-                if constexpr (VEC) {
-                    v[j] = *reinterpret_cast<const float4*>(base + off[0] + ko);
-                } else {
-                    v[j].x = base[off[0] + ko]; v[j].y = base[off[1] + ko];
-                    v[j].z = base[off[2] + ko]; v[j].w = base[off[3] + ko];
-                }
+                v[SET][j].x = base[off[0] + ko]; v[SET][j].y = base[off[1] + ko];
+                v[SET][j].z = base[off[2] + ko]; v[SET][j].w = base[off[3] + ko];
             }
         } else {
             const int k = k0 + 4 * c;
-            if constexpr (VEC) {
-                const int kk = k < kend ? k : 0;
 #pragma unroll
-                for (int j = 0; j < NP; ++j) v[j] = *reinterpret_cast<const float4*>(base + off[j] + kk);
-            } else {
-#pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    v[j].x = base[off[j] + (k + 0 < kend ? k + 0 : 0)];
-                    v[j].y = base[off[j] + (k + 1 < kend ? k + 1 : 0)];
-                    v[j].z = base[off[j] + (k + 2 < kend ? k + 2 : 0)];
-                    v[j].w = base[off[j] + (k + 3 < kend ? k + 3 : 0)];
-                }
+            for (int j = 0; j < NP; ++j) {
+                v[SET][j].x = base[off[j] + (k + 0 < kend ? k + 0 : 0)];
+                v[SET][j].y = base[off[j] + (k + 1 < kend ? k + 1 : 0)];
+                v[SET][j].z = base[off[j] + (k + 2 < kend ? k + 2 : 0)];
+                v[SET][j].w = base[off[j] + (k + 3 < kend ? k + 3 : 0)];
             }
         }
     }
 
-    // Zero what lies outside the matrix (rows >= rows_total, k >= kend) and write the slice to LDS.
+    // Write the slice to LDS; zero what lies beyond kend (VEC: rows outside the matrix are already zero).
+    template <int SET>
     __device__ __forceinline__ void store(float* lds, int k0, int kend) const {
+        const bool tail = k0 + BKT > kend;   // uniform: only the last slice of the K range needs masking
         if constexpr (KM) {
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
-                const bool kv = k0 + r0 + KP * j < kend;
-                float4 x = v[j];
-                if constexpr (VEC) {
-                    const bool g = kv && (ok & 1u);
-                    x.x = g ? x.x : 0.f; x.y = g ? x.y : 0.f; x.z = g ? x.z : 0.f; x.w = g ? x.w : 0.f;
-                } else {
-                    x.x = (kv && (ok & 1u)) ? x.x : 0.f; x.y = (kv && (ok & 2u)) ? x.y : 0.f;
-                    x.z = (kv && (ok & 4u)) ? x.z : 0.f; x.w = (kv && (ok & 8u)) ? x.w : 0.f;
+                float4 x = v[SET][j];
+                if (!VEC || tail) {
+                    const bool kv = k0 + r0 + KP * j < kend;
+                    const uint32_t m = VEC ? 0xfu : ok;
+                    x.x = (kv && (m & 1u)) ? x.x : 0.f; x.y = (kv && (m & 2u)) ? x.y : 0.f;
+                    x.z = (kv && (m & 4u)) ? x.z : 0.f; x.w = (kv && (m & 8u)) ? x.w : 0.f;
                 }
                 *reinterpret_cast<float4*>(lds + (r0 + KP * j) * LD + 4 * c) = x;
             }
@@ -148,12 +169,9 @@ struct Stager {
             const int k = k0 + 4 * c;
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
-                const bool rv = (ok >> j) & 1u;
-                float4 x = v[j];
-                if constexpr (VEC) {
-                    const bool g = rv && k < kend;
-                    x.x = g ? x.x : 0.f; x.y = g ? x.y : 0.f; x.z = g ? x.z : 0.f; x.w = g ? x.w : 0.f;
-                } else {
+                float4 x = v[SET][j];
+                if (!VEC || tail) {
+                    const bool rv = VEC ? true : (bool)((ok >> j) & 1u);
                     x.x = (rv && k + 0 < kend) ? x.x : 0.f; x.y = (rv && k + 1 < kend) ? x.y : 0.f;
                     x.z = (rv && k + 2 < kend) ? x.z : 0.f; x.w = (rv && k + 3 < kend) ? x.w : 0.f;
                 }
@@ -202,8 +220,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m,
     const RowMap amap{p.a_grp, p.a_gs, p.a_gmap, p.a_rs};
     const RowMap bmap{0, 0, nullptr, p.b_rs};
     SA sa; SB sb;
-    sa.init(p.A, amap, p.a_ks, m0, p.M);
-    sb.init(p.B, bmap, p.b_ks, n0, p.N);
+    sa.init(p.A, amap, p.a_ks, m0, p.M, p.a_extent);
+    sb.init(p.B, bmap, p.b_ks, n0, p.N, p.b_extent);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -216,17 +234,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m,
         for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (kend - kbeg + BK - 1) / BK;
+    // Software pipeline, two slices deep: slice i is in LDS buffer i&1, slice i+1 is in flight (or landed)
+    // in register set (i+1)&1 and is written to the other LDS buffer after the MFMAs of slice i, slice i+2
+    // is requested into register set i&1 before them -- every global load has two MFMA phases to land.
     if (nk > 0) {
-        sa.load(kbeg, kend); sb.load(kbeg, kend);
-        sa.store(smem, kbeg, kend); sb.store(smem + SA::FLOATS, kbeg, kend);
+        sa.template load<0>(kbeg, kend); sb.template load<0>(kbeg, kend);
+        if (nk > 1) { sa.template load<1>(kbeg + BK, kend); sb.template load<1>(kbeg + BK, kend); }
+        sa.template store<0>(smem, kbeg, kend); sb.template store<0>(smem + SA::FLOATS, kbeg, kend);
     }
     __syncthreads();
-    for (int it = 0; it < nk; ++it) {
-        const float* As = smem + (it & 1) * STAGE;
+    auto phase = [&](int it, auto cur) {
+        constexpr int CUR = decltype(cur)::value, NXT = 1 - CUR;
+        const float* As = smem + CUR * STAGE;
         const float* Bs = As + SA::FLOATS;
         const int k0 = kbeg + it * BK;
-        const bool more = it + 1 < nk;
-        if (more) { sa.load(k0 + BK, kend); sb.load(k0 + BK, kend); }
+        if (it + 2 < nk) { sa.template load<CUR>(k0 + 2 * BK, kend); sb.template load<CUR>(k0 + 2 * BK, kend); }
         const int nchunk = (kend - k0 > 16) ? 2 : 1;
         for (int t = 0; t < nchunk; ++t) {
             float af[TM][4], bf[TN][4];
@@ -242,11 +264,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m,
                     for (int b = 0; b < TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][u], bf[b][u], acc[a][b], 0, 0, 0);
         }
-        if (more) {
-            float* An = smem + ((it + 1) & 1) * STAGE;
-            sa.store(An, k0 + BK, kend); sb.store(An + SA::FLOATS, k0 + BK, kend);
+        if (it + 1 < nk) {
+            float* An = smem + NXT * STAGE;
+            sa.template store<NXT>(An, k0 + BK, kend); sb.template store<NXT>(An + SA::FLOATS, k0 + BK, kend);
         }
         __syncthreads();
+    };
+    for (int it = 0; it < nk; it += 2) {
+        phase(it, std::integral_constant<int, 0>{});
+        if (it + 1 < nk) phase(it + 1, std::integral_constant<int, 1>{});
     }
 
     // Epilogue.  C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.
@@ -359,7 +385,25 @@ extern "C" int ick_gemm(const ick_gemm_args* in, void* stream) {
     }
     if (bkm) bvec = aligned16(a.B) && a.b_ks % 4 == 0 && a.N % 4 == 0;
     else bvec = aligned16(a.B) && a.b_rs % 4 == 0 && a.K % 4 == 0;
-    const bool vec = avec && bvec;
+    // operand extents (elements addressable from the base pointer) bound the buffer descriptors of the vector
+    // path; without a group map they follow from the strides, with one the caller must state them
+    auto extent_of = [](int64_t rows, int64_t rs, int64_t K, int64_t ks, int grp, int64_t gs, bool has_map) -> int64_t {
+        if (has_map) return 0;
+        if (grp <= 0) return (rows - 1) * rs + (K - 1) * ks + 1;
+        const int64_t ng = (rows + grp - 1) / grp;
+        return (ng - 1) * gs + (std::min<int64_t>(grp, rows) - 1) * rs + (K - 1) * ks + 1;
+    };
+    if (a.a_extent <= 0) a.a_extent = extent_of(a.M, a.a_rs, a.K, a.a_ks, a.a_grp, a.a_gs, a.a_gmap != nullptr);
+    if (a.b_extent <= 0) a.b_extent = extent_of(a.N, a.b_rs, a.K, a.b_ks, 0, 0, false);
+    const int64_t kMaxExtent = ((int64_t)1 << 29) - 64;   // < 2 GiB of floats, so kOobOffset is out of range
+    // every float4 of the vector path starts at a multiple of 4 floats, so a bound rounded down to one
+    // (views into a larger buffer, e.g. the flat parameter bucket) and capped below 2 GiB never cuts a valid one
+    a.a_extent = std::min(a.a_extent & ~(int64_t)3, kMaxExtent - 4);
+    a.b_extent = std::min(a.b_extent & ~(int64_t)3, kMaxExtent - 4);
+    const int64_t a_need = extent_of(a.M, a.a_rs, a.K, a.a_ks, a.a_grp, a.a_gs, a.a_gmap != nullptr);
+    const int64_t b_need = extent_of(a.N, a.b_rs, a.K, a.b_ks, 0, 0, false);
+    const bool vec = avec && bvec && a.a_extent >= 4 && a.b_extent >= 4 && a_need <= a.a_extent + 3 &&
+                     b_need <= a.b_extent + 3;
     a.flags &= 0xff;
     hipStream_t s = (hipStream_t)stream;
 

@@ -30,6 +30,7 @@ class GemmArgs(C.Structure):
         ("flags", i32), ("split_k", i32), ("alpha", f32),
         ("hs_dh", i32), ("hs_dhp", i32), ("hs_H", i32), ("hs_S", i32), ("hs_s0", i32),
         ("drop_p", f32), ("drop_seed", u32), ("drop_site", u32), ("drop_epoch", vp),
+        ("a_extent", i64), ("b_extent", i64),
     ]
 
 

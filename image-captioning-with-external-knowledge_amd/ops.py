@@ -27,6 +27,11 @@ def _f32c(t, name):
 TIMED = None
 
 
+def _extent(t):
+    """Floats addressable from t.data_ptr() inside t's storage (bounds the kernel's buffer descriptor)."""
+    return (t.untyped_storage().nbytes() - t.storage_offset() * t.element_size()) // 4
+
+
 def _drop(a, drop):
     """drop = (p, seed, site[, epoch_tensor]) or None -> fields of an args struct."""
     if drop is not None and drop[0] > 0.0:
@@ -55,6 +60,7 @@ def gemm_raw(A, B, Cout, M, N, K, a_rs, a_ks, b_rs, b_ks, c_rs, bias=None, a_grp
     a.flags = (L.GEMM_RELU if relu else 0) | (L.GEMM_ACCUM if accumulate else 0) | (L.GEMM_ATOMIC if atomic else 0)
     a.split_k = split_k
     a.alpha = alpha
+    a.a_extent, a.b_extent = _extent(A), _extent(B)
     _drop(a, drop)
     timed = TIMED is not None and TIMED["shape"] == (M, N, K)
     if timed:
@@ -158,6 +164,7 @@ def project_heads(x, w, bias, nseg, H, S, out=None, s0=0, grp=None, a_gmap=None,
     a.b_rs, a.b_ks = w.stride(0), 1
     a.c_rs, a.c_grp, a.c_gs = 0, grp, out.stride(0)
     a.split_k, a.alpha = 1, 1.0
+    a.a_extent, a.b_extent = _extent(x2), _extent(w)
     a.hs_dh, a.hs_dhp, a.hs_H, a.hs_S, a.hs_s0 = d // H, DHP, H, S, s0
     L.check(L.load().ick_gemm(C.byref(a), _stream()), "ick_gemm(head-split)")
     return out

@@ -65,6 +65,8 @@ typedef struct {
     int32_t hs_dh, hs_dhp, hs_H, hs_S, hs_s0;   /* head-split epilogue, see above (hs_dh == 0: off) */
     float drop_p; uint32_t drop_seed, drop_site; /* training dropout on the output (after bias/ReLU), see ick_dropout_mask */
     const uint32_t* drop_epoch;                  /* optional device counter added to drop_seed (graph replays) */
+    int64_t a_extent, b_extent;   /* floats addressable from A / B (bounds of the buffer descriptors); 0 = derive from
+                                     the strides -- required when a_gmap is given, otherwise the slow path is taken */
 } ick_gemm_args;
 
 #define ICK_GEMM_RELU 1

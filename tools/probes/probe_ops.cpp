@@ -36,6 +36,7 @@ int main(int argc, char** argv) {
     auto gemm = [&](const char* name, int M, int N, int K, bool feat, int hs) {
         ick_gemm_args a; memset(&a, 0, sizeof(a));
         a.A = A; a.B = B; a.C = C; a.bias = bias; a.M = M; a.N = N; a.K = K; a.alpha = 1.f; a.split_k = 1;
+        a.a_extent = (int64_t)na; a.b_extent = (int64_t)nb;
         if (feat) { a.a_rs = 1; a.a_ks = 196; a.a_grp = 196; a.a_gs = (int64_t)K * 196; }
         else { a.a_rs = K; a.a_ks = 1; }
         a.b_rs = K; a.b_ks = 1; a.c_rs = N;
@@ -61,6 +62,7 @@ int main(int argc, char** argv) {
     auto gemm_bwd = [&](const char* name, int M, int N, int K, bool wgrad, int split) {
         ick_gemm_args a; memset(&a, 0, sizeof(a));
         a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.alpha = 1.f; a.split_k = split;
+        a.a_extent = (int64_t)na; a.b_extent = (int64_t)nb;
         if (wgrad) { a.a_rs = 1; a.a_ks = M; a.b_rs = 1; a.b_ks = N; }
         else { a.a_rs = K; a.a_ks = 1; a.b_rs = 1; a.b_ks = N; }
         a.c_rs = N;
