@@ -1,0 +1,77 @@
+"""CaptionDataset over the reference's on-disk formats (geo-aware/datasets.py:10-56,
+knowledge-aware/datasets.py:10-64): per split <SPLIT>_CAPTIONS/_CAPLENS/_CAPMASKS_<name>.json,
+<SPLIT>_ENT_FEATURES/_ENT_NAMES[/_FACTS/_FACT_NAMES]_<name>.pkl and the images.  BASELINE configs use
+precomputed 14x14x2048 ResNet-101 features, so the image source is, in order of preference,
+<SPLIT>_FEATURES_<name>.npy ((N, 2048, 14, 14) float16/float32, memory-mapped) or the reference's
+<SPLIT>_IMAGES_<name>.hdf5 ((N, 3, 256, 256) uint8-range floats; needs h5py and a ResNet trunk in front of
+Encoder).  __getitem__ yields the reference's tuple order:
+(img, caption, caplen, capmask, entity_features, entity_names[, facts, fact_names])."""
+import json
+import os
+import pickle
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+
+class CaptionDataset(Dataset):
+    def __init__(self, data_dir, data_name, split, transform=None):
+        assert split in {"TRAIN", "VAL", "TEST"}
+        self.split = split
+        self.transform = transform
+
+        def path(kind, ext):
+            return os.path.join(data_dir, "%s_%s_%s.%s" % (split, kind, data_name, ext))
+
+        feat = path("FEATURES", "npy")
+        if os.path.exists(feat):
+            self.imgs = np.load(feat, mmap_mode="r")
+            self.precomputed = True
+        else:
+            try:
+                import h5py
+            except ImportError as e:
+                raise FileNotFoundError("%s not found and h5py (for %s) is unavailable" %
+                                        (feat, path("IMAGES", "hdf5"))) from e
+            self.h = h5py.File(path("IMAGES", "hdf5"), "r")
+            self.imgs = self.h["images"]
+            self.precomputed = False
+
+        def load_json(kind):
+            with open(path(kind, "json")) as f:
+                return json.load(f)
+
+        def load_pickle(kind):
+            with open(path(kind, "pkl"), "rb") as f:
+                return pickle.load(f)
+
+        self.captions = load_json("CAPTIONS")
+        self.caplens = load_json("CAPLENS")
+        self.capmasks = load_json("CAPMASKS")
+        self.entity_features = load_pickle("ENT_FEATURES")
+        self.entity_names = load_pickle("ENT_NAMES")
+        self.has_facts = os.path.exists(path("FACTS", "pkl"))
+        if self.has_facts:
+            self.facts = load_pickle("FACTS")
+            self.fact_names = load_pickle("FACT_NAMES")
+        assert len(self.captions) == len(self.caplens) == len(self.capmasks) == len(self.entity_features)
+
+    def __len__(self):
+        return len(self.captions)
+
+    def __getitem__(self, i):
+        if self.precomputed:
+            img = torch.from_numpy(np.asarray(self.imgs[i], dtype=np.float32))
+        else:
+            img = torch.as_tensor(np.asarray(self.imgs[i]) / 255.0, dtype=torch.float32)
+            if self.transform is not None:
+                img = self.transform(img)
+        item = (img, torch.tensor(self.captions[i], dtype=torch.long), torch.tensor([self.caplens[i]], dtype=torch.long),
+                torch.tensor(self.capmasks[i], dtype=torch.long),
+                torch.tensor(np.asarray(self.entity_features[i]), dtype=torch.float32),
+                torch.tensor(np.asarray(self.entity_names[i]), dtype=torch.long))
+        if self.has_facts:
+            item += (torch.tensor(np.asarray(self.facts[i]), dtype=torch.long),
+                     torch.tensor(np.asarray(self.fact_names[i]), dtype=torch.long))
+        return item

@@ -1,0 +1,56 @@
+"""Greedy caption generation over a test split, mirroring evaluate() of the reference's eval.py
+(geo-aware/eval.py:46-125; knowledge-aware/eval.py:46-200 for the fact tokens): encoder -> decoder.predict ->
+token ids -> text (vocabulary words, entity names and fact objects decoded from their integer encodings) ->
+generated_captions.csv.  The domain metrics that follow in the reference (Jensen-Shannon, fact accuracy, BLEU...)
+are CPU text statistics outside this path."""
+import os
+
+import pandas as pd
+import torch
+
+from . import utils as ut
+
+
+def detokenize(seq, word_map, rev_word_map, entity_names, fact_names=None):
+    """seq: iterable of token ids of ONE caption; entity_names (K, 2+50) / fact_names (F, 2+50) integer-encoded
+    names [idx, length, chars...] as produced by the reference's preprocessing."""
+    V = len(word_map)
+    K = entity_names.shape[0]
+    special = {word_map["<start>"], word_map["<end>"], word_map["<pad>"]}
+    words = []
+    for tok in seq:
+        tok = int(tok)
+        if tok < V:
+            if tok not in special:
+                words.append(rev_word_map[tok])
+        elif tok < V + K or fact_names is None:
+            k = tok - V
+            words.append("<unk_ent>" if k >= K else ut.int_to_str(entity_names[k][2:].tolist(), int(entity_names[k][1])))
+        else:
+            j = tok - V - K
+            words.append("<unk_fact>" if j >= fact_names.shape[0]
+                         else ut.int_to_str(fact_names[j][2:].tolist(), int(fact_names[j][1])))
+    text = " ".join(words)
+    if not text.endswith(".") and text.count(".") > 1:       # drop a trailing unfinished sentence
+        text = ".".join(text.split(".")[:-1]) + "."
+    return text
+
+
+@torch.no_grad()
+def evaluate(encoder, decoder, loader, word_map, max_caption_len=30, out_csv="generated_captions.csv", device="cuda"):
+    decoder.eval()
+    encoder.eval()
+    rev = {v: k for k, v in word_map.items()}
+    captions, sequences = [], []
+    for batch in loader:                                      # any batch size: captions decode independently
+        image, ent, names = batch[0].to(device), batch[4], batch[5]
+        has_facts = len(batch) > 6
+        extra = (batch[6].to(device),) if has_facts else ()
+        seq = decoder.predict(encoder(image), max_caption_len, ent, *extra)   # (max_len, B)
+        for b in range(seq.shape[1]):
+            ids = seq[:, b].tolist()
+            sequences.append(ids)
+            captions.append(detokenize(ids, word_map, rev, names[b], batch[7][b] if has_facts else None))
+    if out_csv:
+        pd.DataFrame({"generated_caption": captions}).to_csv(out_csv, index=False)
+    return captions, sequences

@@ -207,3 +207,45 @@ CONFIGS = {
     "cfg4": dict(variant="knowledge", B=64, L=20, K=20, V=50000, F=51),
     "cfg5": dict(variant="geo", B=32, L=20, K=20, V=10000, F=0),
 }
+
+
+def write_dataset(data_dir, data_name, variant, n_train=24, n_val=8, n_test=4, L=12, K=6, V=60, F=5, seed=0):
+    """Write a small synthetic dataset in the reference's on-disk formats (datasets.CaptionDataset): JSON
+    captions / lengths / masks, pickled entity (and fact) features and integer-encoded names, a WORDMAP, and
+    precomputed feature maps as <SPLIT>_FEATURES_<name>.npy."""
+    import json
+    import os
+    import pickle
+
+    import numpy as np
+
+    from .utils import str_to_int
+    os.makedirs(data_dir, exist_ok=True)
+    wm = make_word_map(V)
+    with open(os.path.join(data_dir, "WORDMAP_%s.json" % data_name), "w") as f:
+        json.dump(wm, f)
+    for split, n, sd in (("TRAIN", n_train, seed), ("VAL", n_val, seed + 1), ("TEST", n_test, seed + 2)):
+        b = make_batch(variant, n, L, K, V, F, sd)
+
+        def out(kind, ext):
+            return os.path.join(data_dir, "%s_%s_%s.%s" % (split, kind, data_name, ext))
+
+        with open(out("CAPTIONS", "json"), "w") as f:
+            json.dump(b["captions"].tolist(), f)
+        with open(out("CAPLENS", "json"), "w") as f:
+            json.dump(b["caption_lengths"].view(-1).tolist(), f)
+        with open(out("CAPMASKS", "json"), "w") as f:
+            json.dump(b["caption_masks"].tolist(), f)
+        with open(out("ENT_FEATURES", "pkl"), "wb") as f:
+            pickle.dump(b["entities"].tolist(), f)
+        names = [[[k, len("ent%d" % k)] + str_to_int("ent%d" % k) for k in range(K)] for _ in range(n)]
+        with open(out("ENT_NAMES", "pkl"), "wb") as f:
+            pickle.dump(names, f)
+        if variant != "geo":
+            with open(out("FACTS", "pkl"), "wb") as f:
+                pickle.dump(b["facts"].tolist(), f)
+            fn = [[[j, len("obj%d" % j)] + str_to_int("obj%d" % j) for j in range(F)] for _ in range(n)]
+            with open(out("FACT_NAMES", "pkl"), "wb") as f:
+                pickle.dump(fn, f)
+        np.save(out("FEATURES", "npy"), make_feats(n, sd).numpy().astype(np.float16))
+    return wm

@@ -1,0 +1,176 @@
+"""Training / validation loop with the reference's structure (geo-aware/train.py:57-386; the knowledge and
+news variants differ only in the extra `facts` tensors) on top of the MI355X path.
+
+    python -m ick_amd.train  (after editing CONFIG below, like the reference's module-level globals), or
+    from ick_amd import train; train.main(train.Config(variant="knowledge", data_dir=..., data_name=...))
+
+Differences from the reference, all deliberate: images are precomputed 14x14x2048 feature maps
+(datasets.CaptionDataset); `fused=True` (default) replaces Adam + clip_gradient + loss.backward() by
+training.TrainStep (same update, one flat bucket, one all-reduce per step under torchrun); `fused=False` keeps the
+reference's exact statement sequence (CrossEntropyLoss on pack_padded_sequence, loss.backward() through the HIP
+autograd bridge, utils.clip_gradient, torch Adam).  Checkpoints use the reference's layout (utils.save_checkpoint)."""
+import json
+import os
+import time
+from dataclasses import dataclass
+
+import torch
+from torch import nn
+from torch.nn.utils.rnn import pack_padded_sequence
+
+from . import dp, load_models, ops
+from . import utils as ut
+from .datasets import CaptionDataset
+from .training import TrainStep
+
+
+@dataclass
+class Config:
+    variant: str = "geo"
+    data_dir: str = "img_caption_data/input_dataset_files/"
+    data_name: str = "geo_aware_georic2"
+    pretrained_word_embeddings_file: str = ""          # GloVe text file; empty = keep the random init
+    emb_dim: int = 300
+    decoder_dim: int = 512
+    encoder_dim: int = 512
+    num_heads: int = 10
+    num_layers: int = 3
+    start_epoch: int = 0
+    epochs: int = 120
+    max_epochs_since_improvement: int = 20
+    batch_size: int = 4                                # reference: 4 / 4 / 3 (geo / knowledge / news)
+    workers: int = 1
+    decoder_lr: float = 4e-4
+    grad_clip: float = 5.0
+    print_freq: int = 100
+    checkpoint: str = ""
+    zero_out_epochs_since_improvement: bool = False
+    fused: bool = True
+    out_dir: str = "."
+    max_batches: int = 0                               # >0: stop an epoch early (smoke runs)
+
+
+def _batch_to_device(batch, device, has_facts):
+    imgs, caps, caplens, capmasks, ent = batch[0], batch[1], batch[2], batch[3], batch[4]
+    facts = batch[6].to(device) if has_facts else None
+    # entity features stay on the host exactly as in geo-aware/train.py:263-266; the decoder moves them
+    return imgs.to(device), caps.to(device), caplens.to(device), capmasks.to(device), ent, facts
+
+
+def packed_loss(criterion, scores, caps_sorted, decode_lengths):
+    targets = caps_sorted[:, 1:]
+    s = pack_padded_sequence(scores, decode_lengths, batch_first=True).data
+    t = pack_padded_sequence(targets, decode_lengths, batch_first=True).data
+    return criterion(s, t)
+
+
+def train(loader, encoder, decoder, criterion, decoder_optimizer, step, epoch, cfg, device):
+    decoder.train()
+    encoder.train()
+    batch_time, losses = ut.AverageMeter(), ut.AverageMeter()
+    has_facts = decoder.has_facts
+    start = time.time()
+    for i, batch in enumerate(loader):
+        imgs, caps, caplens, capmasks, ent, facts = _batch_to_device(batch, device, has_facts)
+        extra = (facts,) if has_facts else ()
+        with torch.no_grad():
+            enc = encoder(imgs)
+        n_tok = int((caplens - 1).sum())
+        if step is not None:                                             # fused HIP step
+            loss = step(caps, enc, capmasks, caplens, ent, *extra).item()
+        else:                                                            # the reference's statement sequence
+            scores, caps_sorted, dl = decoder(caps, enc, capmasks, caplens, ent, *extra)
+            loss_t = packed_loss(criterion, scores, caps_sorted, dl)
+            decoder_optimizer.zero_grad()
+            loss_t.backward()
+            if cfg.grad_clip is not None:
+                ut.clip_gradient(decoder_optimizer, cfg.grad_clip)
+            decoder_optimizer.step()
+            loss = loss_t.item()
+        losses.update(loss, n_tok)
+        batch_time.update(time.time() - start)
+        start = time.time()
+        if i % cfg.print_freq == 0:
+            print("Epoch: [%d][%d/%d]\tBatch Time %.3f (%.3f)\tLoss %.4f (%.4f)" %
+                  (epoch, i, len(loader), batch_time.val, batch_time.avg, losses.val, losses.avg))
+        if cfg.max_batches and i + 1 >= cfg.max_batches:
+            break
+    return losses.avg
+
+
+def validate(loader, encoder, decoder, criterion, cfg, device):
+    decoder.eval()
+    encoder.eval()
+    losses = ut.AverageMeter()
+    has_facts = decoder.has_facts
+    with torch.no_grad():
+        for i, batch in enumerate(loader):
+            imgs, caps, caplens, capmasks, ent, facts = _batch_to_device(batch, device, has_facts)
+            extra = (facts,) if has_facts else ()
+            scores, caps_sorted, dl = decoder(caps, encoder(imgs), capmasks, caplens, ent, *extra)
+            losses.update(packed_loss(criterion, scores, caps_sorted, dl).item(), sum(dl))
+            if cfg.max_batches and i + 1 >= cfg.max_batches:
+                break
+    return losses.avg
+
+
+def main(cfg=None):
+    cfg = cfg or Config()
+    dp.init_from_env()
+    rank = int(os.environ.get("RANK", "0"))
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(device)
+    models = load_models(cfg.variant)
+    with open(os.path.join(cfg.data_dir, "WORDMAP_" + cfg.data_name + ".json")) as f:
+        word_map = json.load(f)
+    best_loss, epochs_since_improvement, start_epoch = 1e5, 0, cfg.start_epoch
+    if not cfg.checkpoint:
+        decoder = models.DecoderTransformer(word_map=word_map, emb_dim=cfg.emb_dim, decoder_dim=cfg.decoder_dim,
+                                            encoder_dim=cfg.encoder_dim, num_heads=cfg.num_heads,
+                                            num_layers=cfg.num_layers)
+        if cfg.pretrained_word_embeddings_file:
+            decoder.load_pretrained_embeddings(ut.load_embeddings(cfg.pretrained_word_embeddings_file, word_map))
+        decoder.fine_tune_embeddings(True)
+        encoder = models.Encoder(emb_dim=cfg.emb_dim)
+        decoder_optimizer = None
+    else:
+        ck = ut.load_checkpoint(cfg.checkpoint, map_location=device)
+        decoder, encoder = ck["decoder"], ck["encoder"]
+        decoder_optimizer = None if cfg.zero_out_epochs_since_improvement else ck["decoder_optimizer"]
+        if not cfg.zero_out_epochs_since_improvement:
+            start_epoch, epochs_since_improvement, best_loss = ck["epoch"] + 1, ck["epochs_since_improvement"], ck["loss"]
+    decoder.to(device)
+    encoder.to(device)
+    step = None
+    if cfg.fused:
+        step = TrainStep(decoder, lr=cfg.decoder_lr, grad_clip=cfg.grad_clip, seed=rank)
+    elif decoder_optimizer is None:
+        decoder_optimizer = torch.optim.Adam([p for p in decoder.parameters() if p.requires_grad], lr=cfg.decoder_lr)
+    criterion = nn.CrossEntropyLoss(ignore_index=word_map["<pad>"]).to(device)
+    loaders = {s: torch.utils.data.DataLoader(CaptionDataset(cfg.data_dir, cfg.data_name, s), batch_size=cfg.batch_size,
+                                               shuffle=True, num_workers=cfg.workers, pin_memory=True)
+               for s in ("TRAIN", "VAL")}
+    history = []
+    for epoch in range(start_epoch, cfg.epochs):
+        if epochs_since_improvement == cfg.max_epochs_since_improvement:
+            break
+        if epochs_since_improvement > 0 and epochs_since_improvement % 8 == 0:
+            if step is not None:
+                step.lr *= 0.8
+                step._graphs.clear()          # the learning rate is baked into the captured optimizer graph
+            else:
+                ut.adjust_learning_rate(decoder_optimizer, 0.8)
+        tr = train(loaders["TRAIN"], encoder, decoder, criterion, decoder_optimizer, step, epoch, cfg, device)
+        last_loss = validate(loaders["VAL"], encoder, decoder, criterion, cfg, device)
+        is_best = last_loss < best_loss
+        best_loss = min(last_loss, best_loss)
+        epochs_since_improvement = 0 if is_best else epochs_since_improvement + 1
+        history.append((tr, last_loss))
+        if rank == 0:
+            ut.save_checkpoint(cfg.data_name, epoch, epochs_since_improvement, encoder, decoder, None,
+                               decoder_optimizer, last_loss, is_best, out_dir=cfg.out_dir)
+    return history
+
+
+if __name__ == "__main__":
+    main()
