@@ -134,7 +134,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("ICK_BENCH_BACKEND", "nccl")   # "gloo" lets several ranks share one GPU (tests)
         kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
-        dist.init_process_group(backend=backend, **kw)
+        try:
+            dist.init_process_group(backend=backend, **kw)
+            probe = torch.ones(1, device="cuda")
+            dist.all_reduce(probe)          # first collective builds the RCCL communicators: fail here, not mid-run
+        except Exception as e:              # noqa: BLE001 -- keep the scaling run alive on a broken RCCL setup
+            sys.stderr.write("bench.py: backend %s failed (%s); falling back to gloo\n" % (backend, e))
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            dist.init_process_group(backend="gloo")
 
     import ick_amd
     import ick_amd.ops as ops
