@@ -15,8 +15,10 @@ constexpr int kMaxPerLane = 16;
 // LayerNorm backward for y = LN(z) * gamma + beta with z = x + res (recomputed here):
 //   zh = (z - mean) * rstd;  g = dy * gamma
 //   dz = rstd * (g - mean_d(g) - zh * mean_d(g * zh));   dgamma += sum_rows dy * zh;  dbeta += sum_rows dy
-// One wave per row; per-workgroup partial dgamma/dbeta go through LDS, then one float atomic per
-// column per workgroup.
+// One wave per row; per-workgroup partial dgamma/dbeta are combined in LDS and then either written to
+// row blockIdx.x of `partials` (nblocks x 2d; the caller column-sums it off the critical path -- 160
+// workgroups hammering the same 600 addresses with float atomics cost more than the rest of the kernel)
+// or, without a workspace, added to dgamma/dbeta with one float atomic per column per workgroup.
 // ---------------------------------------------------------------------------------------------
 template <int NJ>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -26,7 +28,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ rstd, float* __restrict__ dz,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int64_t rows, int d, int rows_per_block,
-                                                            float* __restrict__ dx_drop, DropArg darg) {
+                                                            float* __restrict__ dx_drop, DropArg darg,
+                                                            float* __restrict__ partials) {
     extern __shared__ float sm[];  // 2 * d partial sums
     const Dropout drop = darg.get();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             if (c < d) {
                 const float v = rs * (g[j] - s1 - zh[j] * s2);
                 dz[row * d + c] = v;
-                if (dx_drop) dx_drop[row * d + c] = v * drop.mask((uint32_t)row * (uint32_t)d + (uint32_t)c);
+                if (dx_drop) dx_drop[row * d + c] = drop.on() ? v * drop.mask((uint32_t)row * (uint32_t)d + (uint32_t)c) : v;
             }
         }
     }
@@ -84,6 +87,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         }
     }
     __syncthreads();
+    if (partials) {
+        float* pr = partials + (int64_t)blockIdx.x * 2 * d;
+        for (int i = threadIdx.x; i < 2 * d; i += 256) pr[i] = sm[i];
+        return;
+    }
     for (int i = threadIdx.x; i < d; i += 256) {
         atomicAdd(dgamma + i, sm[i]);
         atomicAdd(dbeta + i, sm[d + i]);
@@ -324,14 +332,16 @@ __global__ __launch_bounds__(256) void context_gate_bwd_kernel(const int64_t* __
 // ---------------------------------------------------------------------------------------------
 // clip_gradient (geo-aware/utils.py:75-85) + torch.optim.Adam.step (default betas/eps, no weight
 // decay, no amsgrad) over one flat fp32 parameter bucket:
-//   g = clamp(g * gscale, -clip, clip);  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2
+//   g = clamp(g * gscale [/ *gscale_den], -clip, clip);  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2
 //   p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_clamp_kernel(float* __restrict__ p, float* __restrict__ g,
                                                          float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                          float gscale, float clip, float lr, float b1, float b2,
-                                                         float eps, int step0, const uint32_t* step_ptr) {
+                                                         float eps, int step0, const uint32_t* step_ptr,
+                                                         const float* __restrict__ gscale_den) {
     const int64_t stride = (int64_t)gridDim.x * 256;
+    if (gscale_den) gscale = gscale / gscale_den[0];
     const float t = (float)(step0 + (step_ptr ? (int)*step_ptr : 0));
     const float bc1 = 1.f - powf(b1, t);
     const float bc2_sqrt = sqrtf(1.f - powf(b2, t));
@@ -362,27 +372,30 @@ __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, int64
 
 using namespace ick;
 
+extern "C" int ick_layernorm_bwd_rows_per_block(void) { return 8; }
+
 extern "C" int ick_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma,
                                  const float* mean, const float* rstd, float* dz, float* dgamma, float* dbeta,
                                  int64_t rows, int32_t d, float* dx_drop, float drop_p, uint32_t drop_seed,
-                                 uint32_t drop_site, const uint32_t* drop_epoch, void* stream) {
-    ICK_CHECK_ARG(dy && x && gamma && mean && rstd && dz && dgamma && dbeta && rows > 0 && d > 0 && d <= 1024);
+                                 uint32_t drop_site, const uint32_t* drop_epoch, float* partials, void* stream) {
+    ICK_CHECK_ARG(dy && x && gamma && mean && rstd && dz && rows > 0 && d > 0 && d <= 1024);
+    ICK_CHECK_ARG(partials || (dgamma && dbeta));
     ICK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || dx_drop != nullptr));
-    const int rpb = 8;   // two rows per wave: 160 workgroups for the 1280 rows of a layer
+    const int rpb = ick_layernorm_bwd_rows_per_block();   // two rows per wave: 160 workgroups for the 1280 rows of a layer
     const DropArg dr{drop_p, drop_seed, drop_site, drop_epoch};
-    float* dxd = drop_p > 0.f ? dx_drop : nullptr;
+    float* dxd = dx_drop;   // written whenever given: dz * mask, or a plain copy of dz without dropout
     const dim3 grid(ceil_div(rows, rpb));
     const size_t sm = 2 * d * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     if (d <= 320)
         hipLaunchKernelGGL(layernorm_bwd_kernel<5>, grid, dim3(256), sm, s, dy, x, res, gamma, mean, rstd, dz, dgamma,
-                           dbeta, rows, d, rpb, dxd, dr);
+                           dbeta, rows, d, rpb, dxd, dr, partials);
     else if (d <= 512)
         hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, dim3(256), sm, s, dy, x, res, gamma, mean, rstd, dz, dgamma,
-                           dbeta, rows, d, rpb, dxd, dr);
+                           dbeta, rows, d, rpb, dxd, dr, partials);
     else
         hipLaunchKernelGGL(layernorm_bwd_kernel<16>, grid, dim3(256), sm, s, dy, x, res, gamma, mean, rstd, dz, dgamma,
-                           dbeta, rows, d, rpb, dxd, dr);
+                           dbeta, rows, d, rpb, dxd, dr, partials);
     ICK_LAUNCH_RET();
 }
 
@@ -455,10 +468,10 @@ extern "C" int ick_context_gate_bwd(const int64_t* captions, const int64_t* fact
 
 extern "C" int ick_adam_clamp(float* p, float* g, float* m, float* v, int64_t n, float gscale, float clip, float lr,
                               float beta1, float beta2, float eps, int32_t step, const uint32_t* step_ptr,
-                              void* stream) {
+                              const float* gscale_den, void* stream) {
     ICK_CHECK_ARG(p && g && m && v && n > 0 && (step >= 1 || step_ptr != nullptr));
     hipLaunchKernelGGL(adam_clamp_kernel, dim3((int)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0,
-                       (hipStream_t)stream, p, g, m, v, n, gscale, clip, lr, beta1, beta2, eps, step, step_ptr);
+                       (hipStream_t)stream, p, g, m, v, n, gscale, clip, lr, beta1, beta2, eps, step, step_ptr, gscale_den);
     ICK_LAUNCH_RET();
 }
 

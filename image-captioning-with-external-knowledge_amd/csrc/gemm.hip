@@ -27,8 +27,6 @@
 namespace ick {
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDK = BK + 4;  // floats per LDS row of a k-contiguous tile
 
 struct RowMap {  // offset of logical row r:  goff(r / grp) + (r % grp) * rs
     int grp;
@@ -65,7 +63,7 @@ __device__ __forceinline__ int64_t col_offset(const ick_gemm_args& p, int col) {
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 constexpr uint32_t kOobOffset = 0x80000000u;   // >= any extent the vector path accepts (< 2 GiB)
 
-template <int R, bool KM, bool VEC, int BKT = BK>
+template <int R, bool KM, bool VEC, int BKT>
 struct Stager {
     static constexpr int NP = R * BKT / 1024;        // float4 per thread (256 threads)
     static constexpr int CH = KM ? R / 4 : BKT / 4;  // float4 chunks along the contiguous dim
@@ -182,7 +180,7 @@ struct Stager {
 };
 
 // One 16-row fragment for the four MFMA steps of k-chunk t.
-template <int R, bool KM, int BKT = BK>
+template <int R, bool KM, int BKT>
 __device__ __forceinline__ void read_frag(const float* lds, int row0, int t, int i, int q, float (&f)[4]) {
     if constexpr (KM) {
         constexpr int LD = R + 4;
@@ -195,11 +193,12 @@ __device__ __forceinline__ void read_frag(const float* lds, int row0, int t, int
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC>
+template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT>
 __global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m, int tiles_n, int kchunk) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-    using SA = Stager<BM, AKM, VEC>;
-    using SB = Stager<BN, BKM, VEC>;
+    constexpr int BK = BKT;
+    using SA = Stager<BM, AKM, VEC, BKT>;
+    using SB = Stager<BN, BKM, VEC, BKT>;
     constexpr int STAGE = SA::FLOATS + SB::FLOATS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -249,13 +248,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m,
         const float* Bs = As + SA::FLOATS;
         const int k0 = kbeg + it * BK;
         if (it + 2 < nk) { sa.template load<CUR>(k0 + 2 * BK, kend); sb.template load<CUR>(k0 + 2 * BK, kend); }
-        const int nchunk = (kend - k0 > 16) ? 2 : 1;
+        const int nchunk = min(BK / 16, (kend - k0 + 15) >> 4);
         for (int t = 0; t < nchunk; ++t) {
             float af[TM][4], bf[TN][4];
 #pragma unroll
-            for (int a = 0; a < TM; ++a) read_frag<BM, AKM>(As, (wm * TM + a) * 16, t, fi, fq, af[a]);
+            for (int a = 0; a < TM; ++a) read_frag<BM, AKM, BKT>(As, (wm * TM + a) * 16, t, fi, fq, af[a]);
 #pragma unroll
-            for (int b = 0; b < TN; ++b) read_frag<BN, BKM>(Bs, (wn * TN + b) * 16, t, fi, fq, bf[b]);
+            for (int b = 0; b < TN; ++b) read_frag<BN, BKM, BKT>(Bs, (wn * TN + b) * 16, t, fi, fq, bf[b]);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -332,16 +331,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m,
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC>
+template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT = 32>
 int launch(const ick_gemm_args& a, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-    constexpr int STAGE = Stager<BM, AKM, VEC>::FLOATS + Stager<BN, BKM, VEC>::FLOATS;
+    constexpr int BK = BKT;
+    constexpr int STAGE = Stager<BM, AKM, VEC, BKT>::FLOATS + Stager<BN, BKM, VEC, BKT>::FLOATS;
     constexpr size_t smem = 2 * STAGE * sizeof(float);
     const int tiles_m = ceil_div(a.M, BM), tiles_n = ceil_div(a.N, BN);
     int split = a.split_k > 1 ? a.split_k : 1;
     int kchunk = ceil_div(ceil_div(a.K, split), BK) * BK;
     split = ceil_div(a.K, kchunk);
-    auto kern = gemm_kernel<WM, WN, TM, TN, AKM, BKM, VEC>;
+    auto kern = gemm_kernel<WM, WN, TM, TN, AKM, BKM, VEC, BKT>;
     static bool attr_set = false;
     if (!attr_set && smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -412,12 +412,12 @@ extern "C" int ick_gemm(const ick_gemm_args* in, void* stream) {
     // that enough workgroups exist to cover the 256 CUs.
     const int64_t tiles_big = (int64_t)ceil_div(a.M, 128) * ceil_div(a.N, 128);
     const int64_t work = (int64_t)a.M * a.N;
-#define ICK_DISPATCH(WM, WN, TM, TN)                                                  \
-    do {                                                                              \
-        if (!akm && !bkm) return launch<WM, WN, TM, TN, false, false, true>(a, s);    \
-        if (akm && !bkm) return launch<WM, WN, TM, TN, true, false, true>(a, s);      \
-        if (!akm && bkm) return launch<WM, WN, TM, TN, false, true, true>(a, s);      \
-        return launch<WM, WN, TM, TN, true, true, true>(a, s);                        \
+#define ICK_DISPATCH(WM, WN, TM, TN, BKT)                                                  \
+    do {                                                                                   \
+        if (!akm && !bkm) return launch<WM, WN, TM, TN, false, false, true, BKT>(a, s);    \
+        if (akm && !bkm) return launch<WM, WN, TM, TN, true, false, true, BKT>(a, s);      \
+        if (!akm && bkm) return launch<WM, WN, TM, TN, false, true, true, BKT>(a, s);      \
+        return launch<WM, WN, TM, TN, true, true, true, BKT>(a, s);                        \
     } while (0)
     if (!vec) {  // ragged / unaligned operands: element-wise staging, one medium tile shape
         if (!akm && !bkm) return launch<2, 2, 2, 2, false, false, false>(a, s);
@@ -425,14 +425,14 @@ extern "C" int ick_gemm(const ick_gemm_args* in, void* stream) {
         if (!akm && bkm) return launch<2, 2, 2, 2, false, true, false>(a, s);
         return launch<2, 2, 2, 2, true, true, false>(a, s);
     }
-    {   // experiment hook: ICK_GEMM_TILE=<id> forces a tile shape (0: 256x64, 1: 128x128, 2: 64x64, 3: 32x32, 4: 128x64)
+    {   // experiment hook: ICK_GEMM_TILE=<id> forces a tile shape (2: 64x64, 3: 32x32, 5: 32x32 BK64, 6: 32x32 BK128, 7: 64x64 BK64)
         static int forced = -2;
         if (forced == -2) { const char* e = getenv("ICK_GEMM_TILE"); forced = e ? atoi(e) : -1; }
-        if (forced == 0) ICK_DISPATCH(4, 1, 4, 4);
-        if (forced == 1) ICK_DISPATCH(2, 2, 4, 4);
-        if (forced == 2) ICK_DISPATCH(2, 2, 2, 2);
-        if (forced == 3) ICK_DISPATCH(2, 2, 1, 1);
-        if (forced == 4) ICK_DISPATCH(2, 2, 4, 2);
+        if (forced == 2) ICK_DISPATCH(2, 2, 2, 2, 32);
+        if (forced == 3) ICK_DISPATCH(2, 2, 1, 1, 32);
+        if (forced == 5) ICK_DISPATCH(2, 2, 1, 1, 64);
+        if (forced == 6) ICK_DISPATCH(2, 2, 1, 1, 128);
+        if (forced == 7) ICK_DISPATCH(2, 2, 2, 2, 64);
     }
     // Measured on MI355X (tools/probes/probe_ops, profiles/r01_*): with exact-fp32 MFMA a 64x64 wave tile
     // alone needs ~18 us for K = 300, so latency and occupancy favour 64x64 workgroup tiles (32x32 per
@@ -442,7 +442,7 @@ extern "C" int ick_gemm(const ick_gemm_args* in, void* stream) {
     // ~500 64x64 tiles on (cross K/V, vocabulary, feature projection) the larger tile wins (175 vs 212 us).
     (void)tiles_big; (void)work;
     const int64_t wgs64 = (int64_t)ceil_div(a.M, 64) * ceil_div(a.N, 64) * (a.split_k > 1 ? a.split_k : 1);
-    if (wgs64 >= 512) ICK_DISPATCH(2, 2, 2, 2);   // 64 x 64 tiles
-    ICK_DISPATCH(2, 2, 1, 1);                     // 32 x 32 tiles
+    if (wgs64 >= 512) ICK_DISPATCH(2, 2, 2, 2, 32);   // 64 x 64 tiles
+    ICK_DISPATCH(2, 2, 1, 1, 32);                     // 32 x 32 tiles
 #undef ICK_DISPATCH
 }

@@ -153,6 +153,51 @@ __global__ __launch_bounds__(256) void packed_ce_rows_kernel(const float* __rest
             for (int i = tid; i < Vx; i += 256) dr[i] = 0.f;
         return;
     }
+    // Rows of up to 256 * 4 * kCeVec floats (16-byte aligned) stay in registers between the passes: one read
+    // of the logits and one write of the gradient instead of three reads; longer / unaligned rows re-read.
+    constexpr int kCeVec = 10;
+    const bool in_regs = (Vx & 3) == 0 && (ld & 3) == 0 && Vx <= 256 * 4 * kCeVec &&
+                         (reinterpret_cast<uintptr_t>(scores) & 15) == 0 &&
+                         (dr == nullptr || (reinterpret_cast<uintptr_t>(dscores) & 15) == 0);
+    if (in_regs) {
+        const float4* r4 = reinterpret_cast<const float4*>(r);
+        const int n4 = Vx >> 2;
+        float4 x[kCeVec];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < kCeVec; ++j) {
+            const int i = tid + 256 * j;
+            x[j] = i < n4 ? r4[i] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            m = fmaxf(m, fmaxf(fmaxf(x[j].x, x[j].y), fmaxf(x[j].z, x[j].w)));
+        }
+        m = block_max<4>(m, red);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < kCeVec; ++j) {
+            x[j].x = __expf(x[j].x - m); x[j].y = __expf(x[j].y - m);
+            x[j].z = __expf(x[j].z - m); x[j].w = __expf(x[j].w - m);
+            s += (x[j].x + x[j].y) + (x[j].z + x[j].w);
+        }
+        s = block_sum<4>(s, red);
+        if (tid == 0) row_loss[row] = m + __logf(s) - r[target];
+        if (dr) {
+            const float inv = 1.f / s;
+            float4* d4 = reinterpret_cast<float4*>(dr);
+            const int tq = (int)(target >> 2), tr = (int)(target & 3);
+#pragma unroll
+            for (int j = 0; j < kCeVec; ++j) {
+                const int i = tid + 256 * j;
+                if (i < n4) {
+                    float4 g = make_float4(x[j].x * inv, x[j].y * inv, x[j].z * inv, x[j].w * inv);
+                    if (i == tq) {
+                        if (tr == 0) g.x -= 1.f; else if (tr == 1) g.y -= 1.f; else if (tr == 2) g.z -= 1.f; else g.w -= 1.f;
+                    }
+                    d4[i] = g;
+                }
+            }
+        }
+        return;
+    }
     float m = -INFINITY;
     for (int i = tid; i < Vx; i += 256) m = fmaxf(m, r[i]);
     m = block_max<4>(m, red);

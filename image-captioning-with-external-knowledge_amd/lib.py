@@ -76,7 +76,8 @@ SIGNATURES = {
     "ick_greedy_update": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "ick_packed_ce": [vp, i64, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "ick_attention_bwd": [C.POINTER(AttnBwdArgs), vp],
-    "ick_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, f32, u32, u32, vp, vp],
+    "ick_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, f32, u32, u32, vp, vp, vp],
+    "ick_layernorm_bwd_rows_per_block": [],
     "ick_relu_bwd": [vp, vp, vp, i64, f32, vp],
     "ick_colsum": [vp, i64, i32, i64, vp, vp],
     "ick_caption_embed_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, u32, u32, vp, vp],
@@ -84,7 +85,7 @@ SIGNATURES = {
     "ick_entity_encode_bwd": [i32, vp, vp, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, vp],
     "ick_fact_encode_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "ick_context_gate_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
-    "ick_adam_clamp": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, i32, vp, vp],
+    "ick_adam_clamp": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, i32, vp, vp, vp],
     "ick_counter_add": [vp, u32, vp],
     "ick_scale_by_ratio": [vp, i64, vp, vp, vp],
 }

@@ -307,15 +307,27 @@ def attention_heads_bwd(q, kv, O, dO, lse, dQ, dK, dV, H, dh, T, S, q_seg=0, k_s
 
 def layernorm_bwd(dy, x, res, gamma, mean, rstd, dgamma, dbeta, drop=None):
     """Returns (dz, dx): dz = gradient of the residual operand (and of z), dx = gradient of the operand the
-    forward applied dropout to (the same tensor as dz when there was no dropout)."""
+    forward applied dropout to.  dx is always its own tensor (a copy of dz without dropout): dz is accumulated
+    into in place by the next data-gradient GEMM while dx is still being read by weight-gradient kernels on the
+    side stream.  The per-workgroup dgamma / dbeta partial sums are reduced by two column sums (side stream)."""
     d = x.shape[-1]
     rows = x.numel() // d
     dz = torch.empty_like(x)
-    on = drop is not None and drop[0] > 0.0
-    dxd = torch.empty_like(x) if on else None
-    L.check(L.load().ick_layernorm_bwd(_p(dy), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(dgamma),
-                                       _p(dbeta), rows, d, _p(dxd), *_dargs(drop), _stream()), "ick_layernorm_bwd")
-    return dz, (dxd if on else dz)
+    dxd = torch.empty_like(x)
+    rpb = L.load().ick_layernorm_bwd_rows_per_block()
+    part = torch.empty((rows + rpb - 1) // rpb, 2 * d, device=x.device, dtype=torch.float32)
+    L.check(L.load().ick_layernorm_bwd(_p(dy), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), _p(dz), None, None,
+                                       rows, d, _p(dxd), *_dargs(drop), _p(part), _stream()), "ick_layernorm_bwd")
+
+    def reduce_partials():
+        colsum(part[:, :d], dgamma)
+        colsum(part[:, d:], dbeta)
+
+    if SIDE is not None:
+        SIDE.submit(reduce_partials, part)
+    else:
+        reduce_partials()
+    return dz, dxd
 
 
 def relu_bwd(dy, act, out=None, scale=1.0):
@@ -340,27 +352,47 @@ def colsum(a2d, out):
 
 
 class SideStream:
-    """Second HIP stream for work that is off the critical path of the backward pass: the weight and bias
+    """Second HIP stream for work that is off the critical path: in the backward pass the weight and bias
     gradients of a Linear only feed the optimizer, while the data gradient feeds the next layer's backward.
-    fork(): the side stream waits for everything enqueued so far on the main stream; join(): the main stream
-    waits for the side stream (before the all-reduce / optimizer, or before a tensor the side stream reads is
-    overwritten)."""
+
+    fork(): the side stream waits for everything enqueued so far on the main stream (or for an earlier mark());
+    join(): the main stream waits for the side stream (before the all-reduce / optimizer).
+    submit()/flush(): deferred form -- the dependency point is marked now, the side work is enqueued at the next
+    flush().  Callers flush right *after* enqueuing the next main-stream kernel, so that in a captured graph the
+    main chain is the first child of every node: hipGraph keeps a node's first child on the parent's queue,
+    and a hop to another queue costs ~15 us of idle time on the critical path."""
 
     def __init__(self):
         self.stream = torch.cuda.Stream()
         self.pending = False
         self.keep = []   # tensors the side stream reads stay referenced until the pass ends, so the caching
                          # allocator cannot hand their memory to the main stream meanwhile (also under capture)
+        self.deferred = []
 
-    def fork(self, *tensors):
+    def mark(self):
+        """Event at the current point of the main stream, for a later fork(..., after=event)."""
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
+        return ev
+
+    def fork(self, *tensors, after=None):
+        ev = after if after is not None else self.mark()
         self.stream.wait_event(ev)
         self.keep.extend(t for t in tensors if t is not None)
         self.pending = True
         return torch.cuda.stream(self.stream)
 
+    def submit(self, fn, *tensors):
+        self.deferred.append((self.mark(), fn, tensors))
+
+    def flush(self):
+        work, self.deferred = self.deferred, []
+        for ev, fn, tensors in work:
+            with self.fork(*tensors, after=ev):
+                fn()
+
     def join(self):
+        self.flush()
         if self.pending:
             torch.cuda.current_stream().wait_stream(self.stream)
             self.pending = False
@@ -383,13 +415,11 @@ def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False):
         if db is not None:
             colsum(dy, db)
 
-    if SIDE is not None and (dw is not None or db is not None):
-        if accumulate_dx:
-            SIDE.join()          # dx may alias a tensor an earlier parameter-gradient kernel still reads
-        with SIDE.fork(dy, x):
-            param_grads()
-    else:
-        param_grads()
+    # The parameter gradients depend on the point *before* the data gradient but are enqueued after it
+    # (SideStream.submit / flush), and the main stream never waits for the side stream until the pass ends.
+    overlap = SIDE is not None and (dw is not None or db is not None)
+    if overlap:
+        SIDE.submit(param_grads, dy, x)
     if need_dx:
         # a long reduction (the vocabulary: N = 10k..50k) over few output tiles is split over workgroups
         split = max(1, min(16, N // 1024)) if (M * K) <= 1280 * 512 else 1
@@ -403,6 +433,10 @@ def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False):
             if dx is None:
                 dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
             gemm_raw(dy, w, dx, M, K, N, dy.stride(0), 1, 1, w.stride(0), dx.stride(0), accumulate=accumulate_dx)
+    if overlap:
+        SIDE.flush()
+    else:
+        param_grads()
     return dx
 
 
@@ -446,10 +480,12 @@ def context_gate_bwd(captions, facts, dgate, dw, dbias, K, V, mode=0):
                                           dw.shape[1], d, mode, _stream()), "ick_context_gate_bwd")
 
 
-def adam_clamp(p, g, m, v, step, lr, clip=5.0, gscale=1.0, beta1=0.9, beta2=0.999, eps=1e-8, step_tensor=None):
-    """step (+ the uint32 device counter step_tensor, if given) is Adam's 1-based step count."""
+def adam_clamp(p, g, m, v, step, lr, clip=5.0, gscale=1.0, beta1=0.9, beta2=0.999, eps=1e-8, step_tensor=None,
+               gscale_den=None):
+    """step (+ the uint32 device counter step_tensor, if given) is Adam's 1-based step count; the gradient is
+    scaled by gscale (/ the device scalar gscale_den, if given) before the clamp."""
     L.check(L.load().ick_adam_clamp(_p(p), _p(g), _p(m), _p(v), p.numel(), gscale, clip, lr, beta1, beta2, eps, step,
-                                    _p(step_tensor), _stream()), "ick_adam_clamp")
+                                    _p(step_tensor), _p(gscale_den), _stream()), "ick_adam_clamp")
 
 
 def counter_add(counter, inc=1):

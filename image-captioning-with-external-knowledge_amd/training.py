@@ -77,7 +77,7 @@ def _context_encoder_fwd(dec, stack, x, tape_list, ds):
     return x
 
 
-def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds):
+def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds, side=None):
     H, d = dec.num_heads, dec.emb_dim
     dh = d // H
     B, T, _ = x.shape
@@ -96,6 +96,8 @@ def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds):
     t["qc"] = ops.project_heads(t["x1"], ca_w[:d], ca_b[:d], 1, H, T)
     t["ca"] = torch.empty_like(x)
     t["lse_c"] = torch.empty(B * H * T, device=x.device, dtype=torch.float32)
+    if side is not None:
+        side.join()    # the context rows of kv (and of the saved memory) come from the side stream
     ops.attention_heads(t["qc"], kv, t["ca"], H, dh, T, S, 0, 2 * li, 2 * li + 1, lse=t["lse_c"], drop=t["d_ca"])
     t["o2"] = ops.linear(t["ca"], _p(layer.multihead_attn.out_proj.weight), _p(layer.multihead_attn.out_proj.bias))
     t["x2"], t["m2"], t["r2"] = ops.add_layernorm(t["o2"], t["x1"], _p(layer.norm2.weight), _p(layer.norm2.bias),
@@ -109,17 +111,21 @@ def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds):
 
 
 def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gmap, seed=0, epoch=None,
-                      fresh_pack=False):
+                      fresh_pack=False, overlap=False):
     """Teacher-forced forward on already length-sorted inputs; returns (scores, tape).  Dropout is
     active iff the module is in train() mode (masks derive from `seed` + the device counter `epoch`).
     fresh_pack: rebuild the packed cross-K/V / transposed predicate weights from the live parameters
-    (needed when they are updated behind torch's version counters, and inside captured graphs)."""
+    (needed when they are updated behind torch's version counters, and inside captured graphs).
+    overlap: run the context-encoder chain (small, latency-bound kernels) on a second stream beside the
+    image-row K/V projection and the first self-attention block (for captured graphs; eager launches are
+    host-bound and gain nothing)."""
     tape = Tape()
     m = tape.misc
     ds = DropSites(seed, dec.training, epoch)
     d, V, H = dec.emb_dim, dec.vocab_size, dec.num_heads
     B, L = captions.shape
     P, K = enc_tok.shape[1], entities.shape[1]
+    dev = enc_tok.device
     ee = ops.entity_encode(dec.variant, entities, _p(dec.entity_encoder.type_embedding.weight), d,
                            facts=facts if dec.has_facts else None,
                            word_emb=_p(dec.word_embedding.weight) if dec.variant == "news" else None)
@@ -127,16 +133,6 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     if dec.has_facts:
         Fn = facts.shape[1]
         fe = ops.fact_encode(facts, ee, _p(dec.predicate_embedding.weight))
-    tape.enc_layers["entities"] = []
-    ctx_e = _context_encoder_fwd(dec, dec.transformer_encoder_entities, ee, tape.enc_layers["entities"], ds)
-    ctx_f = None
-    if dec.has_facts:
-        tape.enc_layers["facts"] = []
-        ctx_f = _context_encoder_fwd(dec, dec.transformer_encoder_facts, fe, tape.enc_layers["facts"], ds)
-    # contiguous memory (B, S, d): the K/V projection and its weight gradient are then plain GEMMs
-    img = enc_tok.index_select(0, gmap.long()) if gmap is not None else enc_tok
-    mem = torch.cat([img, ctx_e] + ([ctx_f] if dec.has_facts else []), dim=1)
-    S = mem.shape[1]
     if fresh_pack:
         layers_ = dec.transformer_decoder.layers
         wkv = torch.cat([_p(l.multihead_attn.in_proj_weight)[d:] for l in layers_])
@@ -144,13 +140,42 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     else:
         wkv, bkv = dec._packed_cross_kv()
     nseg = wkv.shape[0] // d
-    kv = ops.project_heads(mem, wkv, bkv, nseg, H, S)
+    S = P + K + Fn
+    # memory rows [image ; entities ; facts], kept contiguous (B, S, d) for the weight gradient of the K/V
+    # projection; its three row groups are projected separately (disjoint rows of the head-major kv buffer)
+    mem = torch.empty(B, S, d, device=dev, dtype=torch.float32)
+    kv = torch.empty(B, nseg, H, S, ops.DHP, device=dev, dtype=torch.float32)
+    tape.enc_layers["entities"] = []
+    if dec.has_facts:
+        tape.enc_layers["facts"] = []
+
+    def context_chain():
+        ctx_e = _context_encoder_fwd(dec, dec.transformer_encoder_entities, ee, tape.enc_layers["entities"], ds)
+        mem[:, P:P + K].copy_(ctx_e)
+        ops.project_heads(ctx_e, wkv, bkv, nseg, H, S, out=kv, s0=P, grp=K)
+        if dec.has_facts:
+            ctx_f = _context_encoder_fwd(dec, dec.transformer_encoder_facts, fe, tape.enc_layers["facts"], ds)
+            mem[:, P + K:].copy_(ctx_f)
+            ops.project_heads(ctx_f, wkv, bkv, nseg, H, S, out=kv, s0=P + K, grp=Fn)
+
+    side = ops.SideStream() if overlap else None
+    if side is not None:
+        side.submit(context_chain, ee, fe, mem, kv, wkv, bkv)
+    else:
+        context_chain()
+    img = enc_tok.index_select(0, gmap.long()) if gmap is not None else enc_tok
+    mem[:, :P].copy_(img)
+    if side is not None:
+        side.flush()     # enqueued after the main stream's next kernel (see SideStream)
+    ops.project_heads(img, wkv, bkv, nseg, H, S, out=kv, s0=0, grp=P)
     pe = dec.pos_encoder.pe.view(-1, d)
     m["d_pos"] = ds.site(dec.pos_encoder.dropout.p)
     x = ops.caption_embed(captions, caption_masks, _p(dec.word_embedding.weight), ee, fe, pe, V,
                           dec.word_map["<pad>"], math.sqrt(d), drop=m["d_pos"])
     for li, layer in enumerate(dec.transformer_decoder.layers):
-        x = _decoder_layer_fwd(dec, li, layer, x, kv, S, tape.dec_layers, ds)
+        x = _decoder_layer_fwd(dec, li, layer, x, kv, S, tape.dec_layers, ds, side=side if li == 0 else None)
+    if side is not None:
+        side.join()
     eib = gate = hv = None
     if dec.has_facts:
         pred_wt = _p(dec.fc_predicate.weight).t().contiguous() if fresh_pack else dec._pred_wt()
@@ -312,14 +337,23 @@ def _backward_from_tape(dec, tape, dscores, grads):
     for li, layer in enumerate(layers):
         gw, gb = _g(grads, layer.multihead_attn.in_proj_weight), _g(grads, layer.multihead_attn.in_proj_bias)
         sl = dkv2[:, 2 * li * d:(2 * li + 2) * d]
-        if gw is not None:
-            ops.gemm_raw(sl, mem2, gw[d:], 2 * d, d, B * S, 1, sl.stride(0), 1, d, d, atomic=True, split_k=16)
-        if gb is not None:
-            ops.colsum(sl, gb[d:])
+
+        def kv_param_grads(sl=sl, gw=gw, gb=gb):
+            if gw is not None:
+                ops.gemm_raw(sl, mem2, gw[d:], 2 * d, d, B * S, 1, sl.stride(0), 1, d, d, atomic=True, split_k=16)
+            if gb is not None:
+                ops.colsum(sl, gb[d:])
+
+        if ops.SIDE is not None:
+            ops.SIDE.submit(kv_param_grads, dkv_rows, mem2)
+        else:
+            kv_param_grads()
     nctx = K + Fn
     dctx = torch.empty(B, nctx, d, device=dev, dtype=torch.float32)
     ops.gemm_raw(dkv_rows[:, P:], m["wkv"], dctx, B * nctx, d, nseg * d, nseg * d, 1, 1, d, d, a_grp=nctx,
                  a_gs=S * nseg * d)
+    if ops.SIDE is not None:
+        ops.SIDE.flush()
     # ---- context encoders
     dee_enc = _context_encoder_bwd(dec, dec.transformer_encoder_entities, tape.enc_layers["entities"],
                                    dctx[:, :K].contiguous(), grads)
@@ -423,7 +457,8 @@ class TrainStep:
         dec = self.dec
         self.flat_g.zero_()
         scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gmap,
-                                         seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True)
+                                         seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
+                                         overlap=self.use_graph)
         loss_sum, count, dscores = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True)
         backward_from_tape(dec, tape, dscores, self.grads, overlap=self.use_graph)
         self.flat_g[self.n:self.n + 1].copy_(loss_sum)
@@ -432,14 +467,14 @@ class TrainStep:
 
     def _part_b(self):
         # divide by the global token count (device-resident), clamp, Adam with the device step counter
-        ops.scale_by_ratio(self.flat_g[:self.n], self.one, self.flat_g[self.n + 1:])
         ops.adam_clamp(self.flat_p, self.flat_g, self.flat_m, self.flat_v, 1, self.lr, self.clip, 1.0,
-                       self.betas[0], self.betas[1], self.eps, step_tensor=self.counter)
+                       self.betas[0], self.betas[1], self.eps, step_tensor=self.counter,
+                       gscale_den=self.flat_g[self.n + 1:])
         ops.counter_add(self.counter, 1)
         return self.flat_g
 
     def _capture(self, fn, inputs):
-        static = [None if t is None else t.clone() for t in inputs]
+        static = [None if t is None else t.contiguous().clone() for t in inputs]
         # warm-up off the capture (lazy kernel attributes); the warm-up steps touch the gradient bucket only
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -456,16 +491,14 @@ class TrainStep:
         dec = self.dec
         encoder_out, entities, facts = dec._prepare_inputs(encoder_out, entities, facts)
         dev = encoder_out.device
-        lengths, sort_ind = caption_lengths.detach().squeeze(1).cpu().sort(dim=0, descending=True)
-        sort_dev = sort_ind.to(dev)
-        captions = captions.to(dev)[sort_dev].contiguous()
-        caption_masks = caption_masks.to(dev)[sort_dev].contiguous()
-        entities = entities[sort_dev].contiguous()
-        if dec.has_facts:
-            facts = facts[sort_dev].contiguous()
-        enc_tok = dec._token_major(encoder_out).contiguous()
-        decode_len = (lengths - 1).to(torch.int32).to(dev)
-        inputs = [captions, caption_masks, entities, facts, enc_tok, sort_dev.to(torch.int32), decode_len]
+        # No length sort and no host round trip here: the loss is a sum over tokens, so the batch order does
+        # not matter, and the lengths are only read on the device (packed cross entropy).  The reference sorts
+        # because pack_padded_sequence wants it (geo-aware/models.py:330-336); forward() keeps doing so.
+        captions = captions.to(dev, non_blocking=True)
+        caption_masks = caption_masks.to(dev, non_blocking=True)
+        enc_tok = dec._token_major(encoder_out)
+        decode_len = (caption_lengths.to(dev, non_blocking=True).reshape(-1) - 1).to(torch.int32)
+        inputs = [captions, caption_masks, entities, facts, enc_tok, None, decode_len]
         key = tuple(None if t is None else tuple(t.shape) for t in inputs)
         if self.use_graph and key not in self._graphs:
             if len(self._graphs) >= 4:

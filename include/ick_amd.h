@@ -213,11 +213,15 @@ typedef struct {
 } ick_attn_bwd_args;
 int ick_attention_bwd(const ick_attn_bwd_args* args, void* stream);
 
-/* dz = dLN/d(x+res) ; dgamma += ..., dbeta += ... (accumulated with float atomics). */
+/* dz = dLN/d(x+res).  Parameter gradients: with `partials` == NULL, dgamma += ..., dbeta += ... (float atomics);
+ * otherwise workgroup i writes its partial [dgamma | dbeta] sums to partials[i*2d .. i*2d+2d) for
+ * i < ceil(rows / ick_layernorm_bwd_rows_per_block()) and the caller reduces them (ick_colsum), off the critical path. */
+int ick_layernorm_bwd_rows_per_block(void);
 int ick_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma, const float* mean,
                       const float* rstd, float* dz, float* dgamma, float* dbeta, int64_t rows, int32_t d,
-                      float* dx_drop /* dz * mask: gradient of the dropped operand x (drop_p > 0) */,
-                      float drop_p, uint32_t drop_seed, uint32_t drop_site, const uint32_t* drop_epoch, void* stream);
+                      float* dx_drop /* optional: dz * mask = gradient of the dropped operand x (required when drop_p > 0; a copy of dz when drop_p == 0) */,
+                      float drop_p, uint32_t drop_seed, uint32_t drop_site, const uint32_t* drop_epoch, float* partials,
+                      void* stream);
 /* dx = dy where the forward ReLU output `act` was positive, else 0. */
 int ick_relu_bwd(const float* dy, const float* act, float* dx, int64_t n, float scale /* 1/(1-p) of the FFN dropout */,
                  void* stream);
@@ -247,9 +251,12 @@ int ick_context_gate_bwd(const int64_t* captions, const int64_t* facts, const fl
                          int32_t num_pred, int32_t d, int32_t mode, void* stream);
 /* g = clamp(g*gscale, +-clip) (clip <= 0: no clamp) followed by torch.optim.Adam's update, one flat
  * fp32 bucket; the 1-based step count is step + *step_ptr (step_ptr may be NULL; a device-resident counter
- * lets a captured graph advance the bias correction on every replay). */
+ * lets a captured graph advance the bias correction on every replay).  With gscale_den (device scalar, may be
+ * NULL) the gradient scale is gscale / *gscale_den: the token-mean normalisation by the all-reduced token
+ * count without a host round trip or a separate pass over the bucket. */
 int ick_adam_clamp(float* p, float* g, float* m, float* v, int64_t n, float gscale, float clip, float lr,
-                   float beta1, float beta2, float eps, int32_t step, const uint32_t* step_ptr, void* stream);
+                   float beta1, float beta2, float eps, int32_t step, const uint32_t* step_ptr,
+                   const float* gscale_den, void* stream);
 /* *counter += inc on the stream (step / dropout-epoch counter of captured training graphs). */
 int ick_counter_add(uint32_t* counter, uint32_t inc, void* stream);
 /* x *= num[0] / den[0] with device-resident scalars (token-mean normalisation without a host sync). */

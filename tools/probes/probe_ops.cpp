@@ -55,6 +55,13 @@ int main(int argc, char** argv) {
     gemm("out-proj", 1280, 300, 300, false, 0);
     gemm("ffn1", 1280, 512, 300, false, 0);
     gemm("ffn2", 1280, 300, 512, false, 0);
+    gemm("latency: 1 tile", 32, 32, 300, false, 0);
+    gemm("latency: K=32", 1280, 300, 32, false, 0);
+    gemm("latency: K=64", 1280, 300, 64, false, 0);
+    gemm("latency: K=128", 1280, 300, 128, false, 0);
+    gemm("latency: K=1200", 1280, 300, 1200, false, 0);
+    gemm("latency: 256 tiles", 512, 512, 300, false, 0);
+    gemm("latency: 1024 tiles", 1024, 1024, 300, false, 0);
     gemm("decode-step qkv B=64", 64, 900, 300, false, 0);
     gemm("decode-step vocab B=64", 64, 10000, 300, false, 0);
     gemm("square 4096", 4096, 4096, 2048, false, 0);
@@ -102,8 +109,10 @@ int main(int argc, char** argv) {
     printf("%-28s rows=1280               : %8.2f us\n", "add_layernorm", us);
     // backward probes
     float *mean = bias + 4096, *rstd = bias + 8192;
-    us = timeit([&] { ick_layernorm_bwd(A, B, C, bias, mean, rstd, C + 4000000, bias + 1024, bias + 2048, 1280, 300, nullptr, 0.f, 0, 0, nullptr, st); }, iters);
+    us = timeit([&] { ick_layernorm_bwd(A, B, C, bias, mean, rstd, C + 4000000, bias + 1024, bias + 2048, 1280, 300, nullptr, 0.f, 0, 0, nullptr, nullptr, st); }, iters);
     printf("%-28s rows=1280               : %8.2f us\n", "layernorm_bwd", us);
+    us = timeit([&] { ick_layernorm_bwd(A, B, C, bias, mean, rstd, C + 4000000, bias + 1024, bias + 2048, 1280, 300, nullptr, 0.f, 0, 0, nullptr, C + 8000000, st); }, iters);
+    printf("%-28s rows=1280               : %8.2f us\n", "layernorm_bwd (partials)", us);
     us = timeit([&] { ick_colsum(A, 1280, 900, 900, bias + 1024, st); }, iters);
     printf("%-28s 1280x900                : %8.2f us\n", "colsum", us);
     auto attn_bwd = [&](const char* name, int Bn, int T, int S, int causal) {
