@@ -13,6 +13,9 @@
 //            broadcast from LDS as float4; scores go to LDS as Ps[query][key]
 //   phase 2  softmax per query row: one wave per row, wave-shuffle max / sum
 //   phase 3  lane <-> (query, 4 output columns): P broadcast + one float4 of V per key
+#include <cstdlib>
+
+#include "attention_mfma.h"
 #include "common.h"
 
 namespace ick {
@@ -340,15 +343,25 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(ick_attn_bwd_args p, int 
     }
 }
 
+// queries per workgroup of the general backward kernel (all of them when they fit in LDS, else chunks whose
+// dK / dV contributions are combined with float atomics)
+inline int attn_bwd_chunk(int T, int S, int DHP) {
+    const int VLD = DHP + 4, SLD = S | 1;
+    const size_t fixed = (size_t)S * VLD, budget = 150 * 1024 / sizeof(float), stage = (size_t)256 * DHP + 4;
+    int TQ = T;
+    while (TQ > 1 && fixed + stage + (size_t)TQ * (2 * DHP + SLD + 2) > budget) TQ = (TQ + 1) / 2;
+    return TQ;
+}
+inline bool attn_bwd_single_chunk(int T, int S, int DHP) { return attn_bwd_chunk(T, S, DHP) >= T; }
+
 template <int DHP>
 int launch_attn_bwd(const ick_attn_bwd_args& a, hipStream_t s) {
     constexpr int VLD = DHP + 4;
     const int SLD = a.S | 1;
     const size_t fixed = (size_t)a.S * VLD;
-    int TQ = a.T;
     const size_t budget = 150 * 1024 / sizeof(float);
     const size_t stage = (size_t)256 * DHP + 4;
-    while (TQ > 1 && fixed + stage + (size_t)TQ * (2 * DHP + SLD + 2) > budget) TQ = (TQ + 1) / 2;
+    const int TQ = attn_bwd_chunk(a.T, a.S, DHP);
     const size_t fl = fixed + stage + (size_t)TQ * (2 * DHP + SLD + 2);
     if (fl > budget) return ICK_EINVAL;
     auto kern = attn_bwd_kernel<DHP>;
@@ -373,6 +386,11 @@ extern "C" int ick_attention(const ick_attn_args* in, void* stream) {
     ICK_CHECK_ARG(a.B > 0 && a.H > 0 && a.T > 0 && a.S > 0 && a.dh > 0 && a.dh <= 64);
     ICK_CHECK_ARG(a.B <= 65535);
     hipStream_t s = (hipStream_t)stream;
+    static const bool no_mfma = getenv("ICK_ATTN_NO_MFMA") != nullptr;   // experiment hook: force the general kernels
+    if (!no_mfma) {
+        const int rc = launch_attn_mfma(a, s);
+        if (rc != kAttnMfmaUnsupported) return rc;
+    }
     if (a.dh <= 32) return launch_attn<32>(a, s);
     return launch_attn<64>(a, s);
 }
@@ -391,6 +409,17 @@ extern "C" int ick_attention_bwd(const ick_attn_bwd_args* in, void* stream) {
     ICK_CHECK_ARG(a.q_bs % 4 == 0 && a.q_hs % 4 == 0 && a.k_bs % 4 == 0 && a.k_hs % 4 == 0 && a.v_bs % 4 == 0 &&
                   a.v_hs % 4 == 0);
     hipStream_t s = (hipStream_t)stream;
+    static const bool no_mfma = getenv("ICK_ATTN_NO_MFMA") != nullptr;
+    if (DHP == 32 && !no_mfma) {
+        const int rc = launch_attn_bwd_mfma(a, s);
+        if (rc != kAttnMfmaUnsupported) return rc;
+    }
     if (DHP == 32) return launch_attn_bwd<32>(a, s);
     return launch_attn_bwd<64>(a, s);
+}
+
+extern "C" int ick_attention_bwd_overwrites(int32_t T, int32_t S, int32_t dh) {
+    using namespace ick;
+    if (dh <= 32 && attn_mfma_shape_ok(T, S, dh) && getenv("ICK_ATTN_NO_MFMA") == nullptr) return 1;
+    return attn_bwd_single_chunk(T, S, dh <= 32 ? 32 : 64) ? 1 : 0;
 }

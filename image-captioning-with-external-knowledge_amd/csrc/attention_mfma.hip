@@ -1,0 +1,417 @@
+// Matrix-core attention for the teacher-forced shapes of the caption decoder (T <= 64 queries,
+// S <= 512 keys, dh <= 32, head-major padded operands): forward and backward of
+//   O = softmax(Q K^T * scale [+ causal mask]) V            (see include/ick_amd.h: ick_attention)
+// on v_mfma_f32_16x16x4_f32 (exact fp32).  One workgroup of four waves per (sample, head); the key
+// tiles (16 keys) are dealt round-robin to the waves and nothing is transposed through memory:
+// the MFMA output layout (lane <-> column, 4 registers <-> 4 consecutive rows) of one product is
+// exactly the k-major operand layout of the next one.
+//
+//   operand fragments (lane l: i = l & 15, q = l >> 4; chunk t covers columns 16t .. 16t+15):
+//     a row-major matrix X[row][col] serves as A (row = i) or as B (column n = i) of the MFMA with
+//     one 16-byte read X[row0 + i][16t + 4q .. +3]; step u of the chunk consumes element u, both
+//     operands use the same column order so the sum is the same set of products.
+//   result C: lane holds column n = l & 15, rows 4q + r (r = 0..3)  ==  the B operand of a product
+//     whose reduction index is that row index (element u <-> row 4q + u).
+//
+// forward   S^T = K Q^T      (A = K rows from global, B = Q rows from LDS)  -> lane <-> query, regs <-> keys
+//           softmax over keys: registers, two lane shuffles, one LDS exchange between the waves
+//           O^T = V^T P^T    (A = V^T from LDS [col][key], B = the P registers) -> lane <-> query, regs <-> 4 cols
+// backward  S = Q K^T, dP = dO V^T   (A = Q / dO rows from LDS, B = K / V rows from global) -> lane <-> key
+//           dV^T = dO^T P, dK^T = Q^T dS (A = dO^T / Q^T from LDS, B = the P / dS registers)
+//           dS goes to LDS once ([query][key]); dQ = dS K with A = dS rows, B = K^T rows from LDS.
+#include "attention_mfma.h"
+
+namespace ick {
+namespace {
+
+constexpr int DHP = 32;          // padded head dimension of the head-major layout
+constexpr int QLD = DHP + 4;     // LDS row stride of the row-major Q / dO tiles
+
+__device__ __forceinline__ float4 mask_cols(float4 x, int c0, int dh) {
+    x.x = c0 + 0 < dh ? x.x : 0.f; x.y = c0 + 1 < dh ? x.y : 0.f;
+    x.z = c0 + 2 < dh ? x.z : 0.f; x.w = c0 + 3 < dh ? x.w : 0.f;
+    return x;
+}
+
+__device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+    return c;
+}
+
+// Stage rows [0, rows) of a head-major matrix (row stride DHP) as X^T in LDS: dst[col][row], row stride SP,
+// columns >= dh and rows in [rows, rows_pad) zeroed.  8 lanes read one 128-byte row (coalesced).
+__device__ __forceinline__ void stage_transposed(const float* __restrict__ src, float* __restrict__ dst, int rows,
+                                                 int rows_pad, int SP, int dh) {
+    for (int f = threadIdx.x; f < rows_pad * 8; f += 256) {
+        const int s = f >> 3, c = f & 7;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < rows) x = mask_cols(*reinterpret_cast<const float4*>(src + (int64_t)s * DHP + 4 * c), 4 * c, dh);
+        dst[(4 * c + 0) * SP + s] = x.x; dst[(4 * c + 1) * SP + s] = x.y;
+        dst[(4 * c + 2) * SP + s] = x.z; dst[(4 * c + 3) * SP + s] = x.w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+template <int NQT, int MAXT>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ick_attn_args p, int SP) {
+    constexpr int NQ = NQT * 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Vt = smem;                    // DHP * SP      V^T: [col][key]
+    float* Qs = Vt + DHP * SP;           // NQ * QLD      Q rows (zero padded)
+    float* Ored = Qs + NQ * QLD;         // 4 waves * NQT * 2 tiles * 256
+    float* red = Ored + 4 * NQT * 2 * 256;   // 4 * NQ   per-wave row statistics
+    float* stat = red + 4 * NQ;          // 2 * NQ       final max / 1/sum
+
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int T = p.T, S = p.S, dh = p.dh;
+    int slen = S;
+    if (p.kv_len) slen = min(S, p.kv_len[b]);
+    const int nkt = (S + 15) >> 4;       // key tiles
+    const Dropout drop = make_dropout(p.drop_p, p.drop_epoch ? p.drop_seed + *p.drop_epoch : p.drop_seed, p.drop_site);
+    const float* qb = p.Q + (int64_t)b * p.q_bs + (int64_t)h * p.q_hs;
+    const float* kb = p.K + (int64_t)b * p.k_bs + (int64_t)h * p.k_hs;
+    const float* vb = p.V + (int64_t)b * p.v_bs + (int64_t)h * p.v_hs;
+
+    // this wave's K fragments straight from global memory (requested first: they land during the staging)
+    float4 kf[MAXT][2];
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        const int key = 16 * (wave + 4 * i) + li;
+        const bool ok = key < slen;
+        const float* kr = kb + (int64_t)(ok ? key : 0) * DHP + 4 * lq;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float4 x = *reinterpret_cast<const float4*>(kr + 16 * t);
+            x = mask_cols(x, 16 * t + 4 * lq, ok ? dh : 0);
+            kf[i][t] = x;
+        }
+    }
+    for (int f = tid; f < NQ * 8; f += 256) {
+        const int t = f >> 3, c = f & 7;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < T) x = mask_cols(*reinterpret_cast<const float4*>(qb + (int64_t)t * DHP + 4 * c), 4 * c, dh);
+        *reinterpret_cast<float4*>(Qs + t * QLD + 4 * c) = x;
+    }
+    stage_transposed(vb, Vt, slen, nkt * 16, SP, dh);
+    __syncthreads();
+
+    // S^T tiles: lane <-> query (16 qt + li), registers <-> keys 16 kt + 4 lq + r
+    f32x4 sc[MAXT][NQT];
+    float mx[NQT];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        mx[qt] = -INFINITY;
+        const float4 q0 = *reinterpret_cast<const float4*>(Qs + (16 * qt + li) * QLD + 4 * lq);
+        const float4 q1 = *reinterpret_cast<const float4*>(Qs + (16 * qt + li) * QLD + 16 + 4 * lq);
+        const int query = 16 * qt + li;
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (wave + 4 * i < nkt) {   // wave-uniform
+                acc = mfma4(kf[i][0], q0, acc);
+                acc = mfma4(kf[i][1], q1, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * (wave + 4 * i) + 4 * lq + r;
+                float v = acc[r] * p.scale;
+                if (key >= slen || (p.causal && key > p.q_pos0 + query)) v = -INFINITY;
+                acc[r] = v;
+                mx[qt] = fmaxf(mx[qt], v);
+            }
+            sc[i][qt] = acc;
+        }
+        mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 16, 64));
+        mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 32, 64));
+        if (lq == 0) red[wave * NQ + query] = mx[qt];
+    }
+    __syncthreads();
+    if (tid < NQ) stat[tid] = fmaxf(fmaxf(red[tid], red[NQ + tid]), fmaxf(red[2 * NQ + tid], red[3 * NQ + tid]));
+    __syncthreads();
+
+    // P = exp(s - max) (the normaliser keeps every key; attention dropout only thins the numerator)
+    float sum[NQT];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        const int query = 16 * qt + li;
+        const float m = stat[query];
+        const uint32_t rowbase = (uint32_t)((b * p.H + h) * T + query) * (uint32_t)S;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * (wave + 4 * i) + 4 * lq + r;
+                const float e = (m == -INFINITY) ? 0.f : __expf(sc[i][qt][r] - m);
+                s += e;
+                sc[i][qt][r] = drop.on() ? e * drop.mask(rowbase + (uint32_t)key) : e;
+            }
+        }
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        sum[qt] = s;
+    }
+    // O^T partial sums over this wave's keys: lane <-> query, registers <-> columns 16 jt + 4 lq + r
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < MAXT; ++i) {
+                if (wave + 4 * i < nkt) {
+                    const float4 vt = *reinterpret_cast<const float4*>(Vt + (16 * jt + li) * SP + 16 * (wave + 4 * i) + 4 * lq);
+                    const float4 pf = make_float4(sc[i][qt][0], sc[i][qt][1], sc[i][qt][2], sc[i][qt][3]);
+                    acc = mfma4(vt, pf, acc);
+                }
+            }
+            *reinterpret_cast<f32x4*>(Ored + ((wave * NQT + qt) * 2 + jt) * 256 + lane * 4) = acc;
+        }
+        if (lq == 0) red[wave * NQ + 16 * qt + li] = sum[qt];
+    }
+    __syncthreads();
+    if (tid < NQ) {
+        const float s = (red[tid] + red[NQ + tid]) + (red[2 * NQ + tid] + red[3 * NQ + tid]);
+        stat[NQ + tid] = s > 0.f ? 1.f / s : 0.f;
+        if (p.lse && tid < T) p.lse[((int64_t)b * p.H + h) * T + tid] = stat[tid] + __logf(s);
+    }
+    __syncthreads();
+    // combine the four partial tiles and store: tile tt = (qt, jt), lane <-> query, 4 consecutive columns
+    for (int tt = wave; tt < NQT * 2; tt += 4) {
+        const int qt = tt >> 1, jt = tt & 1;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) o += *reinterpret_cast<const f32x4*>(Ored + ((w * NQT + qt) * 2 + jt) * 256 + lane * 4);
+        const int query = 16 * qt + li;
+        if (query < T) {
+            const float inv = stat[NQ + query];
+            float* orow = p.O + (int64_t)b * p.o_bs + (int64_t)query * p.o_ts + h * dh;
+            const int j0 = 16 * jt + 4 * lq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (j0 + r < dh) orow[j0 + r] = o[r] * inv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+template <int NQT>
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p, int SP) {
+    constexpr int NQ = NQT * 16;
+    constexpr int TLD = NQ + 4;          // row stride of the transposed Q / dO tiles ([col][query])
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Kt = smem;                    // DHP * SP     K^T: [col][key]
+    float* dSs = Kt + DHP * SP;          // NQ * SP      dS: [query][key]
+    float* Qs = dSs + NQ * SP;           // NQ * QLD
+    float* Gs = Qs + NQ * QLD;           // NQ * QLD     dO rows
+    float* Qt = Gs + NQ * QLD;           // DHP * TLD
+    float* Gt = Qt + DHP * TLD;          // DHP * TLD
+    float* Ls = Gt + DHP * TLD;          // NQ  lse
+    float* Dl = Ls + NQ;                 // NQ  rowsum(dO * O)
+
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int T = p.T, S = p.S, dh = p.dh;
+    const int nkt = (S + 15) >> 4;
+    const Dropout drop = make_dropout(p.drop_p, p.drop_epoch ? p.drop_seed + *p.drop_epoch : p.drop_seed, p.drop_site);
+    const float* qb = p.Q + (int64_t)b * p.q_bs + (int64_t)h * p.q_hs;
+    const float* kb = p.K + (int64_t)b * p.k_bs + (int64_t)h * p.k_hs;
+    const float* vb = p.V + (int64_t)b * p.v_bs + (int64_t)h * p.v_hs;
+    const float* ob = p.O + (int64_t)b * p.o_bs + h * dh;
+    const float* gb = p.dO + (int64_t)b * p.o_bs + h * dh;
+
+    // ---- staging: Q (row-major and transposed), dO (both), K^T, lse, D
+    for (int f = tid; f < NQ * 8; f += 256) {
+        const int t = f >> 3, c = f & 7;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < T) x = mask_cols(*reinterpret_cast<const float4*>(qb + (int64_t)t * DHP + 4 * c), 4 * c, dh);
+        *reinterpret_cast<float4*>(Qs + t * QLD + 4 * c) = x;
+        Qt[(4 * c + 0) * TLD + t] = x.x; Qt[(4 * c + 1) * TLD + t] = x.y;
+        Qt[(4 * c + 2) * TLD + t] = x.z; Qt[(4 * c + 3) * TLD + t] = x.w;
+    }
+    for (int f = tid; f < NQ * DHP; f += 256) {
+        const int t = f >> 5, j = f & 31;
+        const bool ok = t < T && j < dh;
+        const float g = ok ? gb[(int64_t)t * p.o_ts + j] : 0.f;
+        const float o = ok ? ob[(int64_t)t * p.o_ts + j] : 0.f;
+        Gs[t * QLD + j] = g;
+        Gt[j * TLD + t] = g;
+        // D[t] = sum_j dO[t][j] O[t][j]: the 32 lanes of a row are one half wave
+        float d = g * o;
+        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+        d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 16, 64);
+        if (j == 0) {
+            Dl[t] = d;
+            Ls[t] = t < T ? p.lse[((int64_t)b * p.H + h) * T + t] : 0.f;
+        }
+    }
+    stage_transposed(kb, Kt, S, nkt * 16, SP, dh);
+    __syncthreads();
+
+    // ---- per key tile: S, dP (lane <-> key 16 kt + li, registers <-> queries 16 qt + 4 lq + r), dV^T, dK^T
+    for (int kt = wave; kt < nkt; kt += 4) {
+        const int key = 16 * kt + li;
+        const bool kok = key < S;
+        float4 kf[2], vf[2];
+        {
+            const float* kr = kb + (int64_t)(kok ? key : 0) * DHP + 4 * lq;
+            const float* vr = vb + (int64_t)(kok ? key : 0) * DHP + 4 * lq;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                kf[t] = mask_cols(*reinterpret_cast<const float4*>(kr + 16 * t), 16 * t + 4 * lq, kok ? dh : 0);
+                vf[t] = mask_cols(*reinterpret_cast<const float4*>(vr + 16 * t), 16 * t + 4 * lq, kok ? dh : 0);
+            }
+        }
+        f32x4 dvt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x4 dkt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float4 qa = *reinterpret_cast<const float4*>(Qs + (16 * qt + li) * QLD + 16 * t + 4 * lq);
+                const float4 ga = *reinterpret_cast<const float4*>(Gs + (16 * qt + li) * QLD + 16 * t + 4 * lq);
+                s = mfma4(qa, kf[t], s);
+                dp = mfma4(ga, vf[t], dp);
+            }
+            const float4 l4 = *reinterpret_cast<const float4*>(Ls + 16 * qt + 4 * lq);
+            const float4 d4 = *reinterpret_cast<const float4*>(Dl + 16 * qt + 4 * lq);
+            const float lr[4] = {l4.x, l4.y, l4.z, l4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
+            float pd[4], ds[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int query = 16 * qt + 4 * lq + r;
+                float pr = __expf(s[r] * p.scale - lr[r]);
+                if (!kok || query >= T || (p.causal && key > p.q_pos0 + query)) pr = 0.f;
+                float mk = 1.f;
+                if (drop.on()) mk = drop.mask((uint32_t)((b * p.H + h) * T + query) * (uint32_t)S + (uint32_t)key);
+                ds[r] = pr * (dp[r] * mk - dr[r]) * p.scale;
+                pd[r] = pr * mk;
+                dSs[query * SP + key] = ds[r];
+            }
+            const float4 pf = make_float4(pd[0], pd[1], pd[2], pd[3]);
+            const float4 df = make_float4(ds[0], ds[1], ds[2], ds[3]);
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const float4 gt = *reinterpret_cast<const float4*>(Gt + (16 * jt + li) * TLD + 16 * qt + 4 * lq);
+                const float4 qt4 = *reinterpret_cast<const float4*>(Qt + (16 * jt + li) * TLD + 16 * qt + 4 * lq);
+                dvt[jt] = mfma4(gt, pf, dvt[jt]);
+                dkt[jt] = mfma4(qt4, df, dkt[jt]);
+            }
+        }
+        // dV^T / dK^T tiles: lane <-> key, registers <-> columns 16 jt + 4 lq + r (4 consecutive floats of a row)
+        if (kok) {
+            float* dvr = p.dV + (int64_t)b * p.dv_bs + (int64_t)key * p.dv_ss + h * dh;
+            float* dkr = p.dK + (int64_t)b * p.dk_bs + (int64_t)key * p.dk_ss + h * dh;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const int j0 = 16 * jt + 4 * lq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (j0 + r < dh) { dvr[j0 + r] = dvt[jt][r]; dkr[j0 + r] = dkt[jt][r]; }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- dQ = dS K: output tile (qt, jt) per wave, reduction over all keys; lane <-> column 16 jt + li
+    for (int tt = wave; tt < NQT * 2; tt += 4) {
+        const int qt = tt >> 1, jt = tt & 1;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nkt; ++kt) {
+            const float4 da = *reinterpret_cast<const float4*>(dSs + (16 * qt + li) * SP + 16 * kt + 4 * lq);
+            const float4 kb4 = *reinterpret_cast<const float4*>(Kt + (16 * jt + li) * SP + 16 * kt + 4 * lq);
+            acc = mfma4(da, kb4, acc);
+        }
+        const int j = 16 * jt + li;
+        if (j < dh) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int query = 16 * qt + 4 * lq + r;
+                if (query < T) p.dQ[(int64_t)b * p.dq_bs + (int64_t)query * p.dq_ts + h * dh + j] = acc[r];
+            }
+        }
+    }
+}
+
+inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+template <typename K>
+int set_lds(K kern, size_t bytes) {
+    if (bytes <= 64 * 1024) return 0;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+template <int NQT, int MAXT>
+int launch_fwd(const ick_attn_args& a, int SP, hipStream_t s) {
+    const size_t fl = (size_t)DHP * SP + (size_t)NQT * 16 * QLD + 4 * NQT * 2 * 256 + 6 * NQT * 16;
+    if (fl * sizeof(float) > 150 * 1024) return kAttnMfmaUnsupported;
+    auto kern = attn_fwd_mfma_kernel<NQT, MAXT>;
+    static bool attr = false;
+    if (!attr) { if (int e = set_lds(kern, 160 * 1024)) return e; attr = true; }
+    hipLaunchKernelGGL(kern, dim3(a.H, a.B), dim3(256), fl * sizeof(float), s, a, SP);
+    ICK_LAUNCH_RET();
+}
+
+template <int NQT>
+int launch_bwd(const ick_attn_bwd_args& a, int SP, hipStream_t s) {
+    constexpr int NQ = NQT * 16;
+    const size_t fl = (size_t)DHP * SP + (size_t)NQ * SP + 2 * (size_t)NQ * QLD + 2 * (size_t)DHP * (NQ + 4) + 2 * NQ;
+    if (fl * sizeof(float) > 150 * 1024) return kAttnMfmaUnsupported;
+    auto kern = attn_bwd_mfma_kernel<NQT>;
+    static bool attr = false;
+    if (!attr) { if (int e = set_lds(kern, 160 * 1024)) return e; attr = true; }
+    hipLaunchKernelGGL(kern, dim3(a.H, a.B), dim3(256), fl * sizeof(float), s, a, SP);
+    ICK_LAUNCH_RET();
+}
+
+}  // namespace
+
+bool attn_mfma_shape_ok(int T, int S, int dh) {
+    if (!(T >= 2 && T <= 64 && S >= 1 && S <= 512 && dh <= DHP)) return false;
+    // the backward keeps K^T and dS ([query][key]) in LDS
+    const size_t nq = (size_t)((T + 15) / 16) * 16, sp = (size_t)((S + 15) / 16) * 16 + 4;
+    return (DHP * sp + nq * sp + 2 * nq * QLD + 2 * DHP * (nq + 4) + 2 * nq) * sizeof(float) <= 150 * 1024;
+}
+
+int launch_attn_mfma(const ick_attn_args& a, hipStream_t s) {
+    if (!attn_mfma_shape_ok(a.T, a.S, a.dh)) return kAttnMfmaUnsupported;
+    if (!(a.q_ts == DHP && a.k_ss == DHP && a.v_ss == DHP && aligned16(a.Q) && aligned16(a.K) && aligned16(a.V) &&
+          a.q_bs % 4 == 0 && a.q_hs % 4 == 0 && a.k_bs % 4 == 0 && a.k_hs % 4 == 0 && a.v_bs % 4 == 0 && a.v_hs % 4 == 0))
+        return kAttnMfmaUnsupported;
+    const int SP = ((a.S + 15) / 16) * 16 + 4;
+    const int nqt = (a.T + 15) / 16;
+    const bool small = a.S <= 256;
+#define ICK_FWD(N)                                                    \
+    case N: return small ? launch_fwd<N, 4>(a, SP, s) : launch_fwd<N, 8>(a, SP, s)
+    switch (nqt) {
+        ICK_FWD(1); ICK_FWD(2); ICK_FWD(3); ICK_FWD(4);
+    }
+#undef ICK_FWD
+    return kAttnMfmaUnsupported;
+}
+
+int launch_attn_bwd_mfma(const ick_attn_bwd_args& a, hipStream_t s) {
+    if (!attn_mfma_shape_ok(a.T, a.S, a.dh)) return kAttnMfmaUnsupported;
+    const int SP = ((a.S + 15) / 16) * 16 + 4;
+    switch ((a.T + 15) / 16) {
+        case 1: return launch_bwd<1>(a, SP, s);
+        case 2: return launch_bwd<2>(a, SP, s);
+        case 3: return launch_bwd<3>(a, SP, s);
+        case 4: return launch_bwd<4>(a, SP, s);
+    }
+    return kAttnMfmaUnsupported;
+}
+
+}  // namespace ick

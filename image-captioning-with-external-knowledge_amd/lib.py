@@ -78,6 +78,7 @@ SIGNATURES = {
     "ick_attention_bwd": [C.POINTER(AttnBwdArgs), vp],
     "ick_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, f32, u32, u32, vp, vp, vp],
     "ick_layernorm_bwd_rows_per_block": [],
+    "ick_attention_bwd_overwrites": [i32, i32, i32],
     "ick_relu_bwd": [vp, vp, vp, i64, f32, vp],
     "ick_colsum": [vp, i64, i32, i64, vp, vp],
     "ick_caption_embed_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, u32, u32, vp, vp],

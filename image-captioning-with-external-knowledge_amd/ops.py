@@ -278,6 +278,14 @@ def packed_ce(scores, captions_sorted, decode_len, pad_token, want_grad=False):
 # ------------------------------------------------------------------------------------------------
 # Backward / training-step wrappers
 # ------------------------------------------------------------------------------------------------
+def attention_bwd_buffer(shape, T, S, dh, device):
+    """Gradient buffer for attention_heads_bwd: uninitialised when the kernel chosen for (T, S, dh) writes every
+    element, zeroed when it accumulates query chunks with atomics."""
+    if L.load().ick_attention_bwd_overwrites(T, S, dh):
+        return torch.empty(shape, device=device, dtype=torch.float32)
+    return torch.zeros(shape, device=device, dtype=torch.float32)
+
+
 def attention_heads_bwd(q, kv, O, dO, lse, dQ, dK, dV, H, dh, T, S, q_seg=0, k_seg=0, v_seg=1, causal=False,
                         drop=None):
     """Backward of attention_heads.  q (B,nq,H,Tq,DHP), kv (B,nkv,H,Sa,DHP); O/dO (B,T,d) row-major;

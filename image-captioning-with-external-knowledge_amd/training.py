@@ -231,7 +231,7 @@ def _context_encoder_bwd(dec, stack, tapes, dx, grads):
                                     _g(grads, layer.norm1.weight), _g(grads, layer.norm1.bias), drop=t["d1"])
         dsa = _lin_bwd(grads, do1.view(M, d), t["sa"].view(M, d), layer.self_attn.out_proj.weight,
                        layer.self_attn.out_proj.bias)
-        dqkv = torch.zeros(B, T, 3 * d, device=dx.device, dtype=torch.float32)
+        dqkv = ops.attention_bwd_buffer((B, T, 3 * d), T, T, d // H, dx.device)
         ops.attention_heads_bwd(t["qkv"], t["qkv"], t["sa"], dsa.view(B, T, d), t["lse"], dqkv[:, :, :d],
                                 dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:], H, d // H, T, T, 0, 1, 2, drop=t["d_att"])
         dx = _lin_bwd(grads, dqkv.view(M, 3 * d), t["x"].view(M, d), layer.self_attn.in_proj_weight,
@@ -264,7 +264,7 @@ def _decoder_layer_bwd(dec, li, layer, t, dx, dkv_rows, kv, S, grads):
                                 _g(grads, layer.norm1.weight), _g(grads, layer.norm1.bias), drop=t["d1"])
     dsa = _lin_bwd(grads, do1.view(M, d), t["sa"].view(M, d), layer.self_attn.out_proj.weight,
                    layer.self_attn.out_proj.bias)
-    dqkv = torch.zeros(B, T, 3 * d, device=dx.device, dtype=torch.float32)
+    dqkv = ops.attention_bwd_buffer((B, T, 3 * d), T, T, dh, dx.device)
     ops.attention_heads_bwd(t["qkv"], t["qkv"], t["sa"], dsa.view(B, T, d), t["lse_s"], dqkv[:, :, :d],
                             dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:], H, dh, T, T, 0, 1, 2, causal=True,
                             drop=t["d_sa"])
@@ -327,7 +327,7 @@ def _backward_from_tape(dec, tape, dscores, grads):
     # ---- decoder stack
     layers = list(dec.transformer_decoder.layers)
     nseg = 2 * len(layers)
-    dkv_rows = torch.zeros(B, S, nseg * d, device=dev, dtype=torch.float32)
+    dkv_rows = ops.attention_bwd_buffer((B, S, nseg * d), L, S, d // H, dev)
     dx = dh
     for li in reversed(range(len(layers))):
         dx = _decoder_layer_bwd(dec, li, layers[li], tape.dec_layers[li], dx, dkv_rows, m["kv"], S, grads)

@@ -212,6 +212,9 @@ typedef struct {
     const uint32_t* drop_epoch;
 } ick_attn_bwd_args;
 int ick_attention_bwd(const ick_attn_bwd_args* args, void* stream);
+/* 1 when ick_attention_bwd writes every element of dQ / dK / dV for this shape (no pre-zeroing needed), 0 when it
+ * accumulates query chunks with float atomics into buffers the caller must have zeroed. */
+int ick_attention_bwd_overwrites(int32_t T, int32_t S, int32_t dh);
 
 /* dz = dLN/d(x+res).  Parameter gradients: with `partials` == NULL, dgamma += ..., dbeta += ... (float atomics);
  * otherwise workgroup i writes its partial [dgamma | dbeta] sums to partials[i*2d .. i*2d+2d) for

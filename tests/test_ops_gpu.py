@@ -163,6 +163,48 @@ def test_attention(ops, B, T, S, causal):
     close(got, ref_attention(q, k, v, H, causal), 3e-6, "attention")
 
 
+@pytest.mark.parametrize("B,T,S,causal,q_pos0,use_len", [
+    (3, 20, 216, False, 0, False),     # decoder cross-attention (cfg2)
+    (3, 20, 20, True, 0, False),       # decoder self-attention
+    (2, 7, 6, False, 0, True),         # one partial tile each way, ragged keys
+    (2, 40, 300, False, 0, True),      # three query tiles, five key tiles per wave (MAXT = 8 instantiation)
+    (2, 64, 512, True, 448, False),    # the largest shape of the matrix-core path, causal with an offset
+    (2, 33, 257, False, 0, True),      # just past the tile boundaries
+    (2, 2, 1, False, 0, False),        # smallest
+])
+def test_attention_matrix_core_path(ops, B, T, S, causal, q_pos0, use_len):
+    """Head-major padded operands with T >= 2 take the MFMA kernels (attention_mfma.hip): outputs and the
+    log-sum-exp against float64 math, with NaN in the pad columns and in the rows beyond kv_len."""
+    H, d = 10, 300
+    dh = d // H
+    x, mem = rnd(B, T, d, seed=11), rnd(B, S, d, seed=12)
+    q = torch.full((B, 1, H, T, ops.DHP), float("nan"), device="cuda")
+    kv = torch.full((B, 2, H, S, ops.DHP), float("nan"), device="cuda")
+    q[..., :dh] = dev(x).view(B, T, 1, H, dh).permute(0, 2, 3, 1, 4)
+    kv[:, 0, :, :, :dh] = dev(mem).view(B, S, H, dh).permute(0, 2, 1, 3)
+    kv[:, 1, :, :, :dh] = dev(mem.flip(1)).view(B, S, H, dh).permute(0, 2, 1, 3)
+    kv_len = None
+    if use_len:
+        kv_len = torch.tensor([S, max(1, S // 3)] + [max(1, S - 1)] * (B - 2), dtype=torch.int32)[:B]
+        for b in range(B):
+            kv[b, :, :, int(kv_len[b]):, :] = float("nan")
+    out = torch.full((B, T, d), float("nan"), device="cuda")
+    lse = torch.empty(B * H * T, device="cuda")
+    ops.attention_heads(q, kv, out, H, dh, T, S, 0, 0, 1, causal=causal, q_pos0=q_pos0,
+                        kv_len=None if kv_len is None else dev(kv_len), lse=lse)
+    ref = ref_attention(x, mem, mem.flip(1), H, causal, None if kv_len is None else kv_len.long(), q_pos0)
+    close(out, ref, 5e-6, "mfma attention")
+    qq = x.double().view(B, T, H, dh).transpose(1, 2)
+    kk = mem.double().view(B, S, H, dh).transpose(1, 2)
+    att = qq @ kk.transpose(-1, -2) / math.sqrt(dh)
+    if kv_len is not None:
+        att = att.masked_fill(torch.arange(S).view(1, 1, 1, S) >= kv_len.long().view(B, 1, 1, 1), float("-inf"))
+    if causal:
+        att = att.masked_fill(torch.arange(S).view(1, 1, 1, S) > q_pos0 + torch.arange(T).view(1, 1, T, 1),
+                              float("-inf"))
+    close(lse.view(B, H, T), att.logsumexp(-1), 5e-6, "mfma lse")
+
+
 def test_attention_packed_kv_len_and_lse(ops):
     # q/k/v live in one packed (B, T, 3d) projection; per-sample key length; causal offset
     B, T, S, H, d = 3, 1, 12, 10, 300

@@ -42,8 +42,11 @@ def test_layernorm_bwd(ops):
     close(db, br.grad, 2e-5, "ln dbeta")
 
 
-@pytest.mark.parametrize("B,T,S,causal", [(3, 20, 216, False), (3, 20, 20, True), (2, 7, 6, False), (2, 40, 300, False)])
+@pytest.mark.parametrize("B,T,S,causal", [(3, 20, 216, False), (3, 20, 20, True), (2, 7, 6, False), (2, 40, 300, False),
+                                          (2, 64, 340, False), (2, 33, 257, True), (2, 80, 300, False),
+                                          (2, 20, 600, False)])
 def test_attention_bwd(ops, B, T, S, causal):
+    """Matrix-core backward (T <= 64, S <= 512, LDS permitting) and the general kernel behind it (last two)."""
     H, d = 10, 300
     dh = d // H
     x, mem, do = rnd(B, T, d, seed=1), rnd(B, S, d, seed=2), rnd(B, T, d, seed=3)
@@ -58,8 +61,12 @@ def test_attention_bwd(ops, B, T, S, causal):
     kr, vr = kvr[..., :d].clone().requires_grad_(True), kvr[..., d:].clone().requires_grad_(True)
     ref = ref_attention_f64(qr, kr, vr, H, causal)
     ref.backward(do.double())
-    dq = torch.zeros(B, T, d, device="cuda")
-    dkv = torch.zeros(B, S, 2 * d, device="cuda")
+    # buffers as the training step allocates them; where the kernel claims to write everything, prove it with NaN
+    dq = ops.attention_bwd_buffer((B, T, d), T, S, dh, "cuda")
+    dkv = ops.attention_bwd_buffer((B, S, 2 * d), T, S, dh, "cuda")
+    if ops.L.load().ick_attention_bwd_overwrites(T, S, dh):
+        dq.fill_(float("nan"))
+        dkv.fill_(float("nan"))
     ops.attention_heads_bwd(q, kv, out, dev(do), lse, dq, dkv[:, :, :d], dkv[:, :, d:], H, dh, T, S, 0, 0, 1,
                             causal=causal)
     close(out, ref.detach(), 5e-6, "fwd")
