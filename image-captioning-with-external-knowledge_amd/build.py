@@ -29,7 +29,8 @@ def _stale(out, deps):
 def build(force=False, verbose=False):
     # a change of compiler flags invalidates every object
     stamp = os.path.join(CSRC, ".flags")
-    cur = " ".join([HIPCC] + FLAGS)
+    cur = " ".join([HIPCC] + [f for f in FLAGS if not os.path.isabs(f)])   # location independent: objects may be
+                                                                            # built in another checkout of the tree
     if not os.path.exists(stamp) or open(stamp).read() != cur:
         force = True
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "ick_amd.h")]

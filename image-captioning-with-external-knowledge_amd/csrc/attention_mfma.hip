@@ -18,7 +18,7 @@
 //           O^T = V^T P^T    (A = V^T from LDS [col][key], B = the P registers) -> lane <-> query, regs <-> 4 cols
 // backward  S = Q K^T, dP = dO V^T   (A = Q / dO rows from LDS, B = K / V rows from global) -> lane <-> key
 //           dV^T = dO^T P, dK^T = Q^T dS (A = dO^T / Q^T from LDS, B = the P / dS registers)
-//           dS goes to LDS once ([query][key]); dQ = dS K with A = dS rows, B = K^T rows from LDS.
+//           dS goes to LDS once ([query][key]); dQ = dS K with A = dS rows from LDS, B = K columns from global (L2).
 #include "attention_mfma.h"
 
 namespace ick {
@@ -42,15 +42,29 @@ __device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& b, f32x4 c
 }
 
 // Stage rows [0, rows) of a head-major matrix (row stride DHP) as X^T in LDS: dst[col][row], row stride SP,
-// columns >= dh and rows in [rows, rows_pad) zeroed.  8 lanes read one 128-byte row (coalesced).
+// columns >= dh and rows in [rows, rows_pad) zeroed.  8 lanes read one 128-byte row (coalesced).  All global
+// loads of the thread are issued before the first LDS write (IT = 256-thread passes, compile time), so the
+// passes share one memory round trip instead of paying one each.
+template <int IT>
 __device__ __forceinline__ void stage_transposed(const float* __restrict__ src, float* __restrict__ dst, int rows,
                                                  int rows_pad, int SP, int dh) {
-    for (int f = threadIdx.x; f < rows_pad * 8; f += 256) {
+    float4 x[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int f = threadIdx.x + 256 * it;
         const int s = f >> 3, c = f & 7;
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s < rows) x = mask_cols(*reinterpret_cast<const float4*>(src + (int64_t)s * DHP + 4 * c), 4 * c, dh);
-        dst[(4 * c + 0) * SP + s] = x.x; dst[(4 * c + 1) * SP + s] = x.y;
-        dst[(4 * c + 2) * SP + s] = x.z; dst[(4 * c + 3) * SP + s] = x.w;
+        x[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < rows) x[it] = *reinterpret_cast<const float4*>(src + (int64_t)s * DHP + 4 * c);
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int f = threadIdx.x + 256 * it;
+        const int s = f >> 3, c = f & 7;
+        if (s < rows_pad) {
+            const float4 v = mask_cols(x[it], 4 * c, s < rows ? dh : 0);
+            dst[(4 * c + 0) * SP + s] = v.x; dst[(4 * c + 1) * SP + s] = v.y;
+            dst[(4 * c + 2) * SP + s] = v.z; dst[(4 * c + 3) * SP + s] = v.w;
+        }
     }
 }
 
@@ -99,7 +113,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ick_attn_args p, int
         if (t < T) x = mask_cols(*reinterpret_cast<const float4*>(qb + (int64_t)t * DHP + 4 * c), 4 * c, dh);
         *reinterpret_cast<float4*>(Qs + t * QLD + 4 * c) = x;
     }
-    stage_transposed(vb, Vt, slen, nkt * 16, SP, dh);
+    stage_transposed<2 * MAXT>(vb, Vt, slen, nkt * 16, SP, dh);
     __syncthreads();
 
     // S^T tiles: lane <-> query (16 qt + li), registers <-> keys 16 kt + 4 lq + r
@@ -204,13 +218,12 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ick_attn_args p, int
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
-template <int NQT>
+template <int NQT, int MAXT>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p, int SP) {
     constexpr int NQ = NQT * 16;
     constexpr int TLD = NQ + 4;          // row stride of the transposed Q / dO tiles ([col][query])
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Kt = smem;                    // DHP * SP     K^T: [col][key]
-    float* dSs = Kt + DHP * SP;          // NQ * SP      dS: [query][key]
+    float* dSs = smem;                   // NQ * SP      dS: [query][key]
     float* Qs = dSs + NQ * SP;           // NQ * QLD
     float* Gs = Qs + NQ * QLD;           // NQ * QLD     dO rows
     float* Qt = Gs + NQ * QLD;           // DHP * TLD
@@ -230,6 +243,21 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p,
     const float* ob = p.O + (int64_t)b * p.o_bs + h * dh;
     const float* gb = p.dO + (int64_t)b * p.o_bs + h * dh;
 
+    // this wave's K / V fragments straight from global memory, requested before the staging so that they land
+    // while it runs (key tile 16 (wave + 4 i), lane <-> key li, columns 16 t + 4 lq .. +3)
+    float4 kf[MAXT][2], vf[MAXT][2];
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        const int key = 16 * (wave + 4 * i) + li;
+        const bool kok = key < S;
+        const float* kr = kb + (int64_t)(kok ? key : 0) * DHP + 4 * lq;
+        const float* vr = vb + (int64_t)(kok ? key : 0) * DHP + 4 * lq;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            kf[i][t] = mask_cols(*reinterpret_cast<const float4*>(kr + 16 * t), 16 * t + 4 * lq, kok ? dh : 0);
+            vf[i][t] = mask_cols(*reinterpret_cast<const float4*>(vr + 16 * t), 16 * t + 4 * lq, kok ? dh : 0);
+        }
+    }
     // ---- staging: Q (row-major and transposed), dO (both), K^T, lse, D
     for (int f = tid; f < NQ * 8; f += 256) {
         const int t = f >> 3, c = f & 7;
@@ -239,39 +267,39 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p,
         Qt[(4 * c + 0) * TLD + t] = x.x; Qt[(4 * c + 1) * TLD + t] = x.y;
         Qt[(4 * c + 2) * TLD + t] = x.z; Qt[(4 * c + 3) * TLD + t] = x.w;
     }
-    for (int f = tid; f < NQ * DHP; f += 256) {
+    const float lse_v = tid < T ? p.lse[((int64_t)b * p.H + h) * T + tid] : 0.f;
+    float gv[NQT * 2], ov[NQT * 2];
+#pragma unroll
+    for (int it = 0; it < NQT * 2; ++it) {   // all loads first: one memory round trip
+        const int f = tid + 256 * it;
         const int t = f >> 5, j = f & 31;
         const bool ok = t < T && j < dh;
-        const float g = ok ? gb[(int64_t)t * p.o_ts + j] : 0.f;
-        const float o = ok ? ob[(int64_t)t * p.o_ts + j] : 0.f;
+        gv[it] = ok ? gb[(int64_t)t * p.o_ts + j] : 0.f;
+        ov[it] = ok ? ob[(int64_t)t * p.o_ts + j] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NQT * 2; ++it) {
+        const int f = tid + 256 * it;
+        const int t = f >> 5, j = f & 31;
+        const float g = gv[it], o = ov[it];
         Gs[t * QLD + j] = g;
         Gt[j * TLD + t] = g;
         // D[t] = sum_j dO[t][j] O[t][j]: the 32 lanes of a row are one half wave
         float d = g * o;
         d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
         d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 16, 64);
-        if (j == 0) {
-            Dl[t] = d;
-            Ls[t] = t < T ? p.lse[((int64_t)b * p.H + h) * T + t] : 0.f;
-        }
+        if (j == 0) Dl[t] = d;
     }
-    stage_transposed(kb, Kt, S, nkt * 16, SP, dh);
+    if (tid < NQ) Ls[tid] = lse_v;
     __syncthreads();
 
     // ---- per key tile: S, dP (lane <-> key 16 kt + li, registers <-> queries 16 qt + 4 lq + r), dV^T, dK^T
-    for (int kt = wave; kt < nkt; kt += 4) {
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        const int kt = wave + 4 * i;
+        if (kt >= nkt) continue;         // wave-uniform
         const int key = 16 * kt + li;
         const bool kok = key < S;
-        float4 kf[2], vf[2];
-        {
-            const float* kr = kb + (int64_t)(kok ? key : 0) * DHP + 4 * lq;
-            const float* vr = vb + (int64_t)(kok ? key : 0) * DHP + 4 * lq;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                kf[t] = mask_cols(*reinterpret_cast<const float4*>(kr + 16 * t), 16 * t + 4 * lq, kok ? dh : 0);
-                vf[t] = mask_cols(*reinterpret_cast<const float4*>(vr + 16 * t), 16 * t + 4 * lq, kok ? dh : 0);
-            }
-        }
         f32x4 dvt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         f32x4 dkt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -281,8 +309,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p,
             for (int t = 0; t < 2; ++t) {
                 const float4 qa = *reinterpret_cast<const float4*>(Qs + (16 * qt + li) * QLD + 16 * t + 4 * lq);
                 const float4 ga = *reinterpret_cast<const float4*>(Gs + (16 * qt + li) * QLD + 16 * t + 4 * lq);
-                s = mfma4(qa, kf[t], s);
-                dp = mfma4(ga, vf[t], dp);
+                s = mfma4(qa, kf[i][t], s);
+                dp = mfma4(ga, vf[i][t], dp);
             }
             const float4 l4 = *reinterpret_cast<const float4*>(Ls + 16 * qt + 4 * lq);
             const float4 d4 = *reinterpret_cast<const float4*>(Dl + 16 * qt + 4 * lq);
@@ -324,17 +352,28 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p,
     }
     __syncthreads();
 
-    // ---- dQ = dS K: output tile (qt, jt) per wave, reduction over all keys; lane <-> column 16 jt + li
+    // ---- dQ = dS K: output tile (qt, jt) per wave, reduction over all keys; lane <-> column 16 jt + li.
+    // A = dS rows from LDS (16-byte reads); B[k = key][n = column] comes straight from global memory (K was
+    // read a moment ago: L2 hits; 16 lanes cover 64 contiguous bytes of a key row) -- keeping a K^T copy in LDS
+    // instead would cost 29 KB and the third workgroup per CU.
     for (int tt = wave; tt < NQT * 2; tt += 4) {
         const int qt = tt >> 1, jt = tt & 1;
+        const int j = 16 * jt + li;
+        const bool jok = j < dh;
+        const float* kc = kb + (jok ? j : 0);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
         for (int kt = 0; kt < nkt; ++kt) {
             const float4 da = *reinterpret_cast<const float4*>(dSs + (16 * qt + li) * SP + 16 * kt + 4 * lq);
-            const float4 kb4 = *reinterpret_cast<const float4*>(Kt + (16 * jt + li) * SP + 16 * kt + 4 * lq);
+            const int k0 = 16 * kt + 4 * lq;
+            float4 kb4;
+            kb4.x = (jok && k0 + 0 < S) ? kc[(int64_t)(k0 + 0) * DHP] : 0.f;
+            kb4.y = (jok && k0 + 1 < S) ? kc[(int64_t)(k0 + 1) * DHP] : 0.f;
+            kb4.z = (jok && k0 + 2 < S) ? kc[(int64_t)(k0 + 2) * DHP] : 0.f;
+            kb4.w = (jok && k0 + 3 < S) ? kc[(int64_t)(k0 + 3) * DHP] : 0.f;
             acc = mfma4(da, kb4, acc);
         }
-        const int j = 16 * jt + li;
-        if (j < dh) {
+        if (jok) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int query = 16 * qt + 4 * lq + r;
@@ -364,12 +403,12 @@ int launch_fwd(const ick_attn_args& a, int SP, hipStream_t s) {
     ICK_LAUNCH_RET();
 }
 
-template <int NQT>
+template <int NQT, int MAXT>
 int launch_bwd(const ick_attn_bwd_args& a, int SP, hipStream_t s) {
     constexpr int NQ = NQT * 16;
-    const size_t fl = (size_t)DHP * SP + (size_t)NQ * SP + 2 * (size_t)NQ * QLD + 2 * (size_t)DHP * (NQ + 4) + 2 * NQ;
+    const size_t fl = (size_t)NQ * SP + 2 * (size_t)NQ * QLD + 2 * (size_t)DHP * (NQ + 4) + 2 * NQ;
     if (fl * sizeof(float) > 150 * 1024) return kAttnMfmaUnsupported;
-    auto kern = attn_bwd_mfma_kernel<NQT>;
+    auto kern = attn_bwd_mfma_kernel<NQT, MAXT>;
     static bool attr = false;
     if (!attr) { if (int e = set_lds(kern, 160 * 1024)) return e; attr = true; }
     hipLaunchKernelGGL(kern, dim3(a.H, a.B), dim3(256), fl * sizeof(float), s, a, SP);
@@ -380,9 +419,9 @@ int launch_bwd(const ick_attn_bwd_args& a, int SP, hipStream_t s) {
 
 bool attn_mfma_shape_ok(int T, int S, int dh) {
     if (!(T >= 2 && T <= 64 && S >= 1 && S <= 512 && dh <= DHP)) return false;
-    // the backward keeps K^T and dS ([query][key]) in LDS
+    // the backward keeps dS ([query][key]) in LDS
     const size_t nq = (size_t)((T + 15) / 16) * 16, sp = (size_t)((S + 15) / 16) * 16 + 4;
-    return (DHP * sp + nq * sp + 2 * nq * QLD + 2 * DHP * (nq + 4) + 2 * nq) * sizeof(float) <= 150 * 1024;
+    return (nq * sp + 2 * nq * QLD + 2 * DHP * (nq + 4) + 2 * nq) * sizeof(float) <= 150 * 1024;
 }
 
 int launch_attn_mfma(const ick_attn_args& a, hipStream_t s) {
@@ -405,11 +444,12 @@ int launch_attn_mfma(const ick_attn_args& a, hipStream_t s) {
 int launch_attn_bwd_mfma(const ick_attn_bwd_args& a, hipStream_t s) {
     if (!attn_mfma_shape_ok(a.T, a.S, a.dh)) return kAttnMfmaUnsupported;
     const int SP = ((a.S + 15) / 16) * 16 + 4;
+    const bool small = a.S <= 256;
     switch ((a.T + 15) / 16) {
-        case 1: return launch_bwd<1>(a, SP, s);
-        case 2: return launch_bwd<2>(a, SP, s);
-        case 3: return launch_bwd<3>(a, SP, s);
-        case 4: return launch_bwd<4>(a, SP, s);
+        case 1: return small ? launch_bwd<1, 4>(a, SP, s) : launch_bwd<1, 8>(a, SP, s);
+        case 2: return small ? launch_bwd<2, 4>(a, SP, s) : launch_bwd<2, 8>(a, SP, s);
+        case 3: return small ? launch_bwd<3, 4>(a, SP, s) : launch_bwd<3, 8>(a, SP, s);
+        case 4: return small ? launch_bwd<4, 4>(a, SP, s) : launch_bwd<4, 8>(a, SP, s);
     }
     return kAttnMfmaUnsupported;
 }
