@@ -193,18 +193,18 @@ __device__ __forceinline__ void read_frag(const float* lds, int row0, int t, int
     }
 }
 
+// One output tile: workgroup `bid` of the tiles_m x tiles_n grid of problem p, K slice `zid`.
 template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT>
-__global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m, int tiles_n, int kchunk) {
+__device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, int tiles_n, int kchunk, int bid,
+                                          int zid, float* smem) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     constexpr int BK = BKT;
     using SA = Stager<BM, AKM, VEC, BKT>;
     using SB = Stager<BN, BKM, VEC, BKT>;
     constexpr int STAGE = SA::FLOATS + SB::FLOATS;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
 
     // XCD-aware tile order (blocks b, b+8, ... share an XCD).
     const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
     {
         const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
         bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m,
     if (tiles_m <= tiles_n) { tm = bid % tiles_m; tn = bid / tiles_m; }
     else { tn = bid % tiles_n; tm = bid / tiles_n; }
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = blockIdx.z * kchunk;
+    const int kbeg = zid * kchunk;
     const int kend = min(p.K, kbeg + kchunk);
 
     const RowMap amap{p.a_grp, p.a_gs, p.a_gmap, p.a_rs};
@@ -233,6 +233,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m,
         for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (kend - kbeg + BK - 1) / BK;
+    const bool colsum = AKM && p.colsum_a != nullptr && tn == 0;   // uniform
+    float csum = 0.f;
     // Software pipeline, two slices deep: slice i is in LDS buffer i&1, slice i+1 is in flight (or landed)
     // in register set (i+1)&1 and is written to the other LDS buffer after the MFMAs of slice i, slice i+2
     // is requested into register set i&1 before them -- every global load has two MFMA phases to land.
@@ -263,6 +265,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m,
                     for (int b = 0; b < TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][u], bf[b][u], acc[a][b], 0, 0, 0);
         }
+        if constexpr (AKM) {
+            // bias-gradient fusion: column sums of the k-major A operand (dY of a weight-gradient GEMM), taken
+            // from the tile already in LDS by the workgroups of the first tile column
+            if (colsum && threadIdx.x < BM) {
+#pragma unroll 8
+                for (int k = 0; k < BK; ++k) csum += As[k * SA::LD + threadIdx.x];
+            }
+        }
         if (it + 1 < nk) {
             float* An = smem + NXT * STAGE;
             sa.template store<NXT>(An, k0 + BK, kend); sb.template store<NXT>(An + SA::FLOATS, k0 + BK, kend);
@@ -273,6 +283,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m,
         phase(it, std::integral_constant<int, 0>{});
         if (it + 1 < nk) phase(it + 1, std::integral_constant<int, 1>{});
     }
+
+    if (colsum && threadIdx.x < BM && m0 + (int)threadIdx.x < p.M) atomicAdd(p.colsum_a + m0 + threadIdx.x, csum);
 
     // Epilogue.  C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.
     const bool hs = p.hs_dh > 0;
@@ -287,7 +299,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m,
     for (int b = 0; b < TN; ++b) {
         cols[b] = n0 + (wn * TN + b) * 16 + fi;
         co[b] = col_offset(p, cols[b]);
-        bv[b] = (p.bias != nullptr && blockIdx.z == 0 && cols[b] < p.N) ? p.bias[cols[b]] : 0.f;
+        bv[b] = (p.bias != nullptr && zid == 0 && cols[b] < p.N) ? p.bias[cols[b]] : 0.f;
     }
     const float alpha = p.alpha;
     int64_t coff[TM][4];
@@ -331,42 +343,85 @@ __global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m,
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT = 32>
-int launch(const ick_gemm_args& a, hipStream_t s) {
-    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-    constexpr int BK = BKT;
-    constexpr int STAGE = Stager<BM, AKM, VEC, BKT>::FLOATS + Stager<BN, BKM, VEC, BKT>::FLOATS;
+template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT>
+__global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m, int tiles_n, int kchunk) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_tile<WM, WN, TM, TN, AKM, BKM, VEC, BKT>(p, tiles_m, tiles_n, kchunk, blockIdx.x, blockIdx.z, smem);
+}
+
+// Several independent problems of the same kernel configuration in one launch (the weight-gradient GEMMs of a
+// layer: each alone is a ~15 us latency-bound launch of a few hundred workgroups).
+constexpr int kGroupMax = 8;
+struct GroupArgs {
+    int count;
+    int wg_end[kGroupMax];      // exclusive prefix sums of workgroups (tiles * K splits)
+    int tiles_m[kGroupMax], tiles_n[kGroupMax], kchunk[kGroupMax];
+    ick_gemm_args g[kGroupMax];
+};
+
+template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT>
+__global__ __launch_bounds__(256) void gemm_group_kernel(GroupArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int gi = 0;
+    while (gi + 1 < ga.count && (int)blockIdx.x >= ga.wg_end[gi]) ++gi;
+    const int local = blockIdx.x - (gi > 0 ? ga.wg_end[gi - 1] : 0);
+    const int nt = ga.tiles_m[gi] * ga.tiles_n[gi];
+    gemm_tile<WM, WN, TM, TN, AKM, BKM, VEC, BKT>(ga.g[gi], ga.tiles_m[gi], ga.tiles_n[gi], ga.kchunk[gi], local % nt,
+                                                  local / nt, smem);
+}
+
+// Host-side plan of one problem: validated arguments + kernel configuration.
+struct Plan {
+    ick_gemm_args a;
+    bool akm, bkm, vec;
+    bool big;                    // 64 x 64 tiles (else 32 x 32)
+    int tiles_m, tiles_n, kchunk, split;
+};
+
+template <int TM, int TN, bool AKM, bool BKM, bool VEC>
+int launch_one(const Plan& pl, hipStream_t s) {
+    constexpr int BM = 2 * TM * 16, BN = 2 * TN * 16;
+    constexpr int STAGE = Stager<BM, AKM, VEC, 32>::FLOATS + Stager<BN, BKM, VEC, 32>::FLOATS;
     constexpr size_t smem = 2 * STAGE * sizeof(float);
-    const int tiles_m = ceil_div(a.M, BM), tiles_n = ceil_div(a.N, BN);
-    int split = a.split_k > 1 ? a.split_k : 1;
-    int kchunk = ceil_div(ceil_div(a.K, split), BK) * BK;
-    split = ceil_div(a.K, kchunk);
-    auto kern = gemm_kernel<WM, WN, TM, TN, AKM, BKM, VEC, BKT>;
-    static bool attr_set = false;
-    if (!attr_set && smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    static_assert(smem <= 64 * 1024, "tile needs the large-LDS attribute");
+    hipLaunchKernelGGL((gemm_kernel<2, 2, TM, TN, AKM, BKM, VEC, 32>), dim3(pl.tiles_m * pl.tiles_n, 1, pl.split),
+                       dim3(256), smem, s, pl.a, pl.tiles_m, pl.tiles_n, pl.kchunk);
+    ICK_LAUNCH_RET();
+}
+
+template <int TM, int TN, bool AKM, bool BKM>
+int launch_group(const Plan* const* pls, int n, hipStream_t s) {
+    constexpr int BM = 2 * TM * 16, BN = 2 * TN * 16;
+    constexpr int STAGE = Stager<BM, AKM, true, 32>::FLOATS + Stager<BN, BKM, true, 32>::FLOATS;
+    constexpr size_t smem = 2 * STAGE * sizeof(float);
+    GroupArgs ga;
+    ga.count = n;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        total += pls[i]->tiles_m * pls[i]->tiles_n * pls[i]->split;
+        ga.wg_end[i] = total;
+        ga.tiles_m[i] = pls[i]->tiles_m; ga.tiles_n[i] = pls[i]->tiles_n; ga.kchunk[i] = pls[i]->kchunk;
+        ga.g[i] = pls[i]->a;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, 1, split), dim3(256), smem, s, a, tiles_m, tiles_n, kchunk);
+    for (int i = n; i < kGroupMax; ++i) { ga.wg_end[i] = total; ga.tiles_m[i] = ga.tiles_n[i] = 1; ga.kchunk[i] = 32; ga.g[i] = pls[0]->a; }
+    hipLaunchKernelGGL((gemm_group_kernel<2, 2, TM, TN, AKM, BKM, true, 32>), dim3(total), dim3(256), smem, s, ga);
     ICK_LAUNCH_RET();
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-}  // namespace
-}  // namespace ick
-
-extern "C" int ick_gemm(const ick_gemm_args* in, void* stream) {
-    using namespace ick;
+// Validation + kernel selection for one problem (shared by ick_gemm and ick_gemm_grouped).
+int make_plan(const ick_gemm_args* in, Plan& pl) {
     if (!in) return ICK_EINVAL;
-    ick_gemm_args a = *in;
+    ick_gemm_args& a = pl.a;
+    a = *in;
     ICK_CHECK_ARG(a.A && a.B && a.C);
     ICK_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0);
     const bool akm = a.a_rs == 1 && a.a_ks != 1, bkm = a.b_rs == 1 && a.b_ks != 1;
     ICK_CHECK_ARG((a.a_rs == 1) || (a.a_ks == 1));
     ICK_CHECK_ARG((a.b_rs == 1) || (a.b_ks == 1));
     if (a.split_k > 1) ICK_CHECK_ARG(a.flags & ICK_GEMM_ATOMIC);
+    if (a.colsum_a) ICK_CHECK_ARG(akm);       // column sums come from the k-major A tile
     if (a.hs_dh > 0) {
         ICK_CHECK_ARG(a.hs_dhp >= a.hs_dh && a.hs_H > 0 && a.hs_S > 0 && a.hs_s0 >= 0);
         ICK_CHECK_ARG(a.N % (a.hs_H * a.hs_dh) == 0);
@@ -402,47 +457,89 @@ extern "C" int ick_gemm(const ick_gemm_args* in, void* stream) {
     a.b_extent = std::min(a.b_extent & ~(int64_t)3, kMaxExtent - 4);
     const int64_t a_need = extent_of(a.M, a.a_rs, a.K, a.a_ks, a.a_grp, a.a_gs, a.a_gmap != nullptr);
     const int64_t b_need = extent_of(a.N, a.b_rs, a.K, a.b_ks, 0, 0, false);
-    const bool vec = avec && bvec && a.a_extent >= 4 && a.b_extent >= 4 && a_need <= a.a_extent + 3 &&
-                     b_need <= a.b_extent + 3;
+    pl.vec = avec && bvec && a.a_extent >= 4 && a.b_extent >= 4 && a_need <= a.a_extent + 3 && b_need <= a.b_extent + 3;
+    pl.akm = akm; pl.bkm = bkm;
     a.flags &= 0xff;
-    hipStream_t s = (hipStream_t)stream;
-
-    // Tile selection: 64x64 per wave on large problems; N<=320 keeps 4 waves stacked along M so a
-    // 300-wide output costs 5 x 64 columns instead of 3 x 128; small problems use small tiles so
-    // that enough workgroups exist to cover the 256 CUs.
-    const int64_t tiles_big = (int64_t)ceil_div(a.M, 128) * ceil_div(a.N, 128);
-    const int64_t work = (int64_t)a.M * a.N;
-#define ICK_DISPATCH(WM, WN, TM, TN, BKT)                                                  \
-    do {                                                                                   \
-        if (!akm && !bkm) return launch<WM, WN, TM, TN, false, false, true, BKT>(a, s);    \
-        if (akm && !bkm) return launch<WM, WN, TM, TN, true, false, true, BKT>(a, s);      \
-        if (!akm && bkm) return launch<WM, WN, TM, TN, false, true, true, BKT>(a, s);      \
-        return launch<WM, WN, TM, TN, true, true, true, BKT>(a, s);                        \
-    } while (0)
-    if (!vec) {  // ragged / unaligned operands: element-wise staging, one medium tile shape
-        if (!akm && !bkm) return launch<2, 2, 2, 2, false, false, false>(a, s);
-        if (akm && !bkm) return launch<2, 2, 2, 2, true, false, false>(a, s);
-        if (!akm && bkm) return launch<2, 2, 2, 2, false, true, false>(a, s);
-        return launch<2, 2, 2, 2, true, true, false>(a, s);
-    }
-    {   // experiment hook: ICK_GEMM_TILE=<id> forces a tile shape (2: 64x64, 3: 32x32, 5: 32x32 BK64, 6: 32x32 BK128, 7: 64x64 BK64)
+    // Tile selection, measured on MI355X (tools/probes/probe_ops, profiles/r01_*): with exact-fp32 MFMA a 64x64
+    // wave tile alone needs ~18 us for K = 300, so latency and occupancy favour 64x64 workgroup tiles (32x32 per
+    // wave, 4+ waves per SIMD) on every large shape of this path (128x128 / 256x64 tiles were 5-15 % slower, BK =
+    // 64 / 128 no faster than 32).  Small outputs (the chain GEMMs of the layers and their data/weight gradients)
+    // take 32x32 tiles so that ~1000 workgroups exist: 7.7 vs 11.7 us for 1280x300x300, 18.5 vs 30.6 us for K = 900;
+    // from ~500 64x64 tiles on (cross K/V, vocabulary, feature projection) the larger tile wins (175 vs 212 us).
+    // Ragged / unaligned operands (element-wise staging) always use the 64x64 shape.
+    const int split_req = a.split_k > 1 ? a.split_k : 1;
+    const int64_t wgs64 = (int64_t)ceil_div(a.M, 64) * ceil_div(a.N, 64) * split_req;
+    pl.big = !pl.vec || wgs64 >= 512;
+    {   // experiment hook: ICK_GEMM_TILE=2 forces 64x64 tiles, 3 forces 32x32
         static int forced = -2;
         if (forced == -2) { const char* e = getenv("ICK_GEMM_TILE"); forced = e ? atoi(e) : -1; }
-        if (forced == 2) ICK_DISPATCH(2, 2, 2, 2, 32);
-        if (forced == 3) ICK_DISPATCH(2, 2, 1, 1, 32);
-        if (forced == 5) ICK_DISPATCH(2, 2, 1, 1, 64);
-        if (forced == 6) ICK_DISPATCH(2, 2, 1, 1, 128);
-        if (forced == 7) ICK_DISPATCH(2, 2, 2, 2, 64);
+        if (forced == 2) pl.big = true;
+        if (forced == 3 && pl.vec) pl.big = false;
     }
-    // Measured on MI355X (tools/probes/probe_ops, profiles/r01_*): with exact-fp32 MFMA a 64x64 wave tile
-    // alone needs ~18 us for K = 300, so latency and occupancy favour 64x64 workgroup tiles (32x32 per
-    // wave, 4+ waves per SIMD) on every shape of this path; larger tiles stay available for experiments.
-    // Small outputs (the chain GEMMs of the layers and their data/weight gradients) take 32x32 tiles so
-    // that ~1000 workgroups exist: 7.7 vs 11.7 us for 1280x300x300, 18.5 vs 30.6 us for K = 900; from
-    // ~500 64x64 tiles on (cross K/V, vocabulary, feature projection) the larger tile wins (175 vs 212 us).
-    (void)tiles_big; (void)work;
-    const int64_t wgs64 = (int64_t)ceil_div(a.M, 64) * ceil_div(a.N, 64) * (a.split_k > 1 ? a.split_k : 1);
-    if (wgs64 >= 512) ICK_DISPATCH(2, 2, 2, 2, 32);   // 64 x 64 tiles
-    ICK_DISPATCH(2, 2, 1, 1, 32);                     // 32 x 32 tiles
-#undef ICK_DISPATCH
+    const int BMN = pl.big ? 64 : 32;
+    pl.tiles_m = ceil_div(a.M, BMN); pl.tiles_n = ceil_div(a.N, BMN);
+    pl.kchunk = ceil_div(ceil_div(a.K, split_req), 32) * 32;
+    pl.split = ceil_div(a.K, pl.kchunk);
+    return ICK_OK;
+}
+
+#define ICK_BY_LAYOUT(FN, TM, TN, VECARGS, ...)                                         \
+    do {                                                                                \
+        if (!pl.akm && !pl.bkm) return FN<TM, TN, false, false VECARGS>(__VA_ARGS__);   \
+        if (pl.akm && !pl.bkm) return FN<TM, TN, true, false VECARGS>(__VA_ARGS__);     \
+        if (!pl.akm && pl.bkm) return FN<TM, TN, false, true VECARGS>(__VA_ARGS__);     \
+        return FN<TM, TN, true, true VECARGS>(__VA_ARGS__);                             \
+    } while (0)
+#define ICK_COMMA_TRUE , true
+#define ICK_COMMA_FALSE , false
+
+int launch_plan(const Plan& pl, hipStream_t s) {
+    if (!pl.vec) ICK_BY_LAYOUT(launch_one, 2, 2, ICK_COMMA_FALSE, pl, s);
+    if (pl.big) ICK_BY_LAYOUT(launch_one, 2, 2, ICK_COMMA_TRUE, pl, s);
+    ICK_BY_LAYOUT(launch_one, 1, 1, ICK_COMMA_TRUE, pl, s);
+}
+
+int launch_plans_grouped(const Plan* const* pls, int n, hipStream_t s) {
+    const Plan& pl = *pls[0];
+    if (pl.big) ICK_BY_LAYOUT(launch_group, 2, 2, , pls, n, s);
+    ICK_BY_LAYOUT(launch_group, 1, 1, , pls, n, s);
+}
+
+}  // namespace
+}  // namespace ick
+
+extern "C" int ick_gemm(const ick_gemm_args* in, void* stream) {
+    using namespace ick;
+    Plan pl;
+    if (int rc = make_plan(in, pl)) return rc;
+    return launch_plan(pl, (hipStream_t)stream);
+}
+
+extern "C" int ick_gemm_grouped(const ick_gemm_args* problems, int32_t count, void* stream) {
+    using namespace ick;
+    if (!problems || count <= 0 || count > 64) return ICK_EINVAL;
+    Plan plans[64];
+    for (int i = 0; i < count; ++i)
+        if (int rc = make_plan(problems + i, plans[i])) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    bool done[64] = {false};
+    for (int i = 0; i < count; ++i) {
+        if (done[i]) continue;
+        if (!plans[i].vec) {          // element-wise staging: no grouped instantiation, launch alone
+            done[i] = true;
+            if (int rc = launch_plan(plans[i], s)) return rc;
+            continue;
+        }
+        const Plan* grp[kGroupMax];
+        int n = 0;
+        for (int j = i; j < count && n < kGroupMax; ++j) {
+            if (done[j] || !plans[j].vec || plans[j].akm != plans[i].akm || plans[j].bkm != plans[i].bkm ||
+                plans[j].big != plans[i].big) continue;
+            grp[n++] = &plans[j];
+            done[j] = true;
+        }
+        const int rc = n == 1 ? launch_plan(*grp[0], s) : launch_plans_grouped(grp, n, s);
+        if (rc) return rc;
+    }
+    return ICK_OK;
 }

@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
         ("flags", i32), ("split_k", i32), ("alpha", f32),
         ("hs_dh", i32), ("hs_dhp", i32), ("hs_H", i32), ("hs_S", i32), ("hs_s0", i32),
         ("drop_p", f32), ("drop_seed", u32), ("drop_site", u32), ("drop_epoch", vp),
-        ("a_extent", i64), ("b_extent", i64),
+        ("a_extent", i64), ("b_extent", i64), ("colsum_a", vp),
     ]
 
 
@@ -78,6 +78,7 @@ SIGNATURES = {
     "ick_attention_bwd": [C.POINTER(AttnBwdArgs), vp],
     "ick_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, f32, u32, u32, vp, vp, vp],
     "ick_layernorm_bwd_rows_per_block": [],
+    "ick_gemm_grouped": [vp, i32, vp],
     "ick_attention_bwd_overwrites": [i32, i32, i32],
     "ick_relu_bwd": [vp, vp, vp, i64, f32, vp],
     "ick_colsum": [vp, i64, i32, i64, vp, vp],

@@ -46,11 +46,12 @@ def _dargs(drop):
     return 0.0, 0, 0, None
 
 
-def gemm_raw(A, B, Cout, M, N, K, a_rs, a_ks, b_rs, b_ks, c_rs, bias=None, a_grp=0, a_gs=0, a_gmap=None,
-             c_grp=0, c_gs=0, c_gmap=None, relu=False, accumulate=False, atomic=False, split_k=1, alpha=1.0,
-             drop=None):
-    """C[m,n] = act(alpha * sum_k A(m,k) B(n,k) + bias[n]) with explicit element strides; A/B/Cout are
-    tensors (only their data pointers are used -- the caller guarantees the strides stay in bounds)."""
+def gemm_args(A, B, Cout, M, N, K, a_rs, a_ks, b_rs, b_ks, c_rs, bias=None, a_grp=0, a_gs=0, a_gmap=None,
+              c_grp=0, c_gs=0, c_gmap=None, relu=False, accumulate=False, atomic=False, split_k=1, alpha=1.0,
+              drop=None, colsum_a=None):
+    """ick_gemm_args for C[m,n] = act(alpha * sum_k A(m,k) B(n,k) + bias[n]) with explicit element strides; A/B/Cout
+    are tensors (only their data pointers are used -- the caller guarantees the strides stay in bounds).
+    colsum_a (k-major A only): colsum_a[m] += sum_k A(m,k)."""
     a = L.GemmArgs()
     a.A, a.B, a.C, a.bias = _p(A), _p(B), _p(Cout), _p(bias)
     a.M, a.N, a.K = M, N, K
@@ -61,7 +62,14 @@ def gemm_raw(A, B, Cout, M, N, K, a_rs, a_ks, b_rs, b_ks, c_rs, bias=None, a_grp
     a.split_k = split_k
     a.alpha = alpha
     a.a_extent, a.b_extent = _extent(A), _extent(B)
+    a.colsum_a = _p(colsum_a)
     _drop(a, drop)
+    return a
+
+
+def gemm_raw(A, B, Cout, M, N, K, *args, **kwargs):
+    """Launch one GEMM (see gemm_args)."""
+    a = gemm_args(A, B, Cout, M, N, K, *args, **kwargs)
     timed = TIMED is not None and TIMED["shape"] == (M, N, K)
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -71,6 +79,14 @@ def gemm_raw(A, B, Cout, M, N, K, a_rs, a_ks, b_rs, b_ks, c_rs, bias=None, a_grp
         e1.record()
         TIMED["events"].append((e0, e1))
     return Cout
+
+
+def gemm_grouped(problems):
+    """Launch a list of ick_gemm_args; problems of one kernel configuration share a launch."""
+    for i in range(0, len(problems), 64):
+        chunk = problems[i:i + 64]
+        arr = (L.GemmArgs * len(chunk))(*chunk)
+        L.check(L.load().ick_gemm_grouped(arr, len(chunk), _stream()), "ick_gemm_grouped")
 
 
 def linear(x, w, bias=None, out=None, relu=False, drop=None):
@@ -328,10 +344,14 @@ def layernorm_bwd(dy, x, res, gamma, mean, rstd, dgamma, dbeta, drop=None):
                                        rows, d, _p(dxd), *_dargs(drop), _p(part), _stream()), "ick_layernorm_bwd")
 
     def reduce_partials():
-        colsum(part[:, :d], dgamma)
-        colsum(part[:, d:], dbeta)
+        if dbeta.data_ptr() == dgamma.data_ptr() + 4 * d:     # adjacent in a flat gradient bucket: one launch
+            colsum(part, dgamma, n_out=2 * d)
+        else:
+            colsum(part[:, :d], dgamma)
+            colsum(part[:, d:], dbeta)
 
     if SIDE is not None:
+        SIDE.flush()     # side work marked earlier goes out now that the main chain has its next kernel
         SIDE.submit(reduce_partials, part)
     else:
         reduce_partials()
@@ -352,9 +372,11 @@ def dropout_mask(rows, cols, p, seed, site, device="cuda"):
     return out
 
 
-def colsum(a2d, out):
-    """out[n] += sum_m a2d[m, n] for a row-major 2-D view."""
+def colsum(a2d, out, n_out=None):
+    """out[n] += sum_m a2d[m, n] for a row-major 2-D view (n_out: out really has that many elements from its
+    data pointer on, e.g. two adjacent gradient buffers)."""
     M, N = a2d.shape
+    assert (n_out or out.numel()) >= N
     L.check(L.load().ick_colsum(_p(a2d), M, N, a2d.stride(0), _p(out), _stream()), "ick_colsum")
     return out
 
@@ -376,6 +398,19 @@ class SideStream:
         self.keep = []   # tensors the side stream reads stay referenced until the pass ends, so the caching
                          # allocator cannot hand their memory to the main stream meanwhile (also under capture)
         self.deferred = []
+        self.group = []  # weight-gradient problems (ick_gemm_args) waiting for the next flush_group()
+
+    def add_problem(self, args, *tensors):
+        """Queue a GEMM whose operands are complete on the main stream by the next flush_group()."""
+        self.group.append(args)
+        self.keep.extend(t for t in tensors if t is not None)
+
+    def flush_group(self):
+        """One grouped launch (ick_gemm_grouped) of the queued problems on the side stream, ordered after
+        everything enqueued so far on the main stream; like submit() it is enqueued at the next flush()."""
+        if self.group:
+            problems, self.group = self.group, []
+            self.deferred.append((self.mark(), lambda: gemm_grouped(problems), ()))
 
     def mark(self):
         """Event at the current point of the main stream, for a later fork(..., after=event)."""
@@ -400,6 +435,7 @@ class SideStream:
                 fn()
 
     def join(self):
+        self.flush_group()
         self.flush()
         if self.pending:
             torch.cuda.current_stream().wait_stream(self.stream)
@@ -409,25 +445,37 @@ class SideStream:
 SIDE = None   # set by training.TrainStep / backward_from_tape for the duration of a backward pass
 
 
-def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False):
+def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False, group_now=False):
     """Backward of y = x @ w.T + b for row-major 2-D views dy (M,N), x (M,K), w (N,K):
     dw += dy.T @ x (split-K over M, float atomics), db += colsum(dy), dx = dy @ w.
     With a SideStream installed the two parameter gradients run beside the data gradient."""
     M, N = dy.shape
     K = x.shape[1]
 
+    # dw += dy.T @ x with db += colsum(dy) riding on the first tile column of the same kernel
+    wg = None
+    if dw is not None:
+        wg = gemm_args(dy, x, dw, N, K, M, 1, dy.stride(0), 1, x.stride(0), dw.stride(0), atomic=True,
+                       split_k=max(1, min(16, M // 256)), colsum_a=db)
+
     def param_grads():
-        if dw is not None:
-            gemm_raw(dy, x, dw, N, K, M, 1, dy.stride(0), 1, x.stride(0), dw.stride(0), atomic=True,
-                     split_k=max(1, min(16, M // 256)))
-        if db is not None:
+        if wg is not None:
+            L.check(L.load().ick_gemm(C.byref(wg), _stream()), "ick_gemm(wgrad)")
+        elif db is not None:
             colsum(dy, db)
 
-    # The parameter gradients depend on the point *before* the data gradient but are enqueued after it
-    # (SideStream.submit / flush), and the main stream never waits for the side stream until the pass ends.
+    # With a SideStream the weight gradients of a whole layer are queued and go out as one grouped launch at the
+    # layer's end (SideStream.flush_group): each alone is a ~15 us latency-bound kernel, and every fork point of
+    # the captured graph costs the main chain ~4 us.  The main stream never waits for the side stream until the
+    # pass ends.
     overlap = SIDE is not None and (dw is not None or db is not None)
     if overlap:
-        SIDE.submit(param_grads, dy, x)
+        if wg is not None:
+            SIDE.add_problem(wg, dy, x)
+            if group_now:      # a large problem of its own (the vocabulary): runs beside its data gradient
+                SIDE.flush_group()
+        else:
+            SIDE.submit(param_grads, dy, x)
     if need_dx:
         # a long reduction (the vocabulary: N = 10k..50k) over few output tiles is split over workgroups
         split = max(1, min(16, N // 1024)) if (M * K) <= 1280 * 512 else 1
@@ -441,9 +489,7 @@ def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False):
             if dx is None:
                 dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
             gemm_raw(dy, w, dx, M, K, N, dy.stride(0), 1, 1, w.stride(0), dx.stride(0), accumulate=accumulate_dx)
-    if overlap:
-        SIDE.flush()
-    else:
+    if not overlap:
         param_grads()
     return dx
 

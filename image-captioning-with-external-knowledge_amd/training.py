@@ -205,7 +205,7 @@ def _g(grads, param):
     return grads.get(id(param))
 
 
-def _lin_bwd(grads, dy2, x2, lin_w, lin_b, w_rows=None, need_dx=True, dx=None, acc=False):
+def _lin_bwd(grads, dy2, x2, lin_w, lin_b, w_rows=None, need_dx=True, dx=None, acc=False, group_now=False):
     """Backward of a Linear whose weight is `lin_w` (optionally the row slice w_rows of it)."""
     gw, gb = _g(grads, lin_w), _g(grads, lin_b)
     w = _p(lin_w)
@@ -213,7 +213,7 @@ def _lin_bwd(grads, dy2, x2, lin_w, lin_b, w_rows=None, need_dx=True, dx=None, a
         w = w[w_rows]
         gw = gw[w_rows] if gw is not None else None
         gb = gb[w_rows] if gb is not None else None
-    return ops.linear_bwd(dy2, x2, w, gw, gb, need_dx=need_dx, dx=dx, accumulate_dx=acc)
+    return ops.linear_bwd(dy2, x2, w, gw, gb, need_dx=need_dx, dx=dx, accumulate_dx=acc, group_now=group_now)
 
 
 def _context_encoder_bwd(dec, stack, tapes, dx, grads):
@@ -236,6 +236,8 @@ def _context_encoder_bwd(dec, stack, tapes, dx, grads):
                                 dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:], H, d // H, T, T, 0, 1, 2, drop=t["d_att"])
         dx = _lin_bwd(grads, dqkv.view(M, 3 * d), t["x"].view(M, d), layer.self_attn.in_proj_weight,
                       layer.self_attn.in_proj_bias, dx=dz.view(M, d), acc=True).view(B, T, d)
+        if ops.SIDE is not None:
+            ops.SIDE.flush_group()      # this layer's weight gradients: one grouped launch
     return dx
 
 
@@ -268,8 +270,11 @@ def _decoder_layer_bwd(dec, li, layer, t, dx, dkv_rows, kv, S, grads):
     ops.attention_heads_bwd(t["qkv"], t["qkv"], t["sa"], dsa.view(B, T, d), t["lse_s"], dqkv[:, :, :d],
                             dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:], H, dh, T, T, 0, 1, 2, causal=True,
                             drop=t["d_sa"])
-    return _lin_bwd(grads, dqkv.view(M, 3 * d), t["x"].view(M, d), layer.self_attn.in_proj_weight,
-                    layer.self_attn.in_proj_bias, dx=dz.view(M, d), acc=True).view(B, T, d)
+    dx0 = _lin_bwd(grads, dqkv.view(M, 3 * d), t["x"].view(M, d), layer.self_attn.in_proj_weight,
+                   layer.self_attn.in_proj_bias, dx=dz.view(M, d), acc=True).view(B, T, d)
+    if ops.SIDE is not None:
+        ops.SIDE.flush_group()          # this layer's weight gradients: one grouped launch
+    return dx0
 
 
 def backward_from_tape(dec, tape, dscores, grads, overlap=True):
@@ -306,7 +311,9 @@ def _backward_from_tape(dec, tape, dscores, grads):
     dfe = torch.zeros_like(fe) if fe is not None else None
     # ---- score head
     hv = m["hv"] if dec.has_facts else h
-    dhv = _lin_bwd(grads, dsc2[:, :V], hv.view(M, d), dec.fc_vocab.weight, dec.fc_vocab.bias).view(B, L, d)
+    # the vocabulary weight gradient is a large problem of its own: it starts beside its data gradient
+    dhv = _lin_bwd(grads, dsc2[:, :V], hv.view(M, d), dec.fc_vocab.weight, dec.fc_vocab.bias,
+                   group_now=True).view(B, L, d)
     if dec.has_facts:
         dh = ops.mul(dhv, m["gate"])
         dgate = ops.mul(dhv, h)
@@ -338,13 +345,20 @@ def _backward_from_tape(dec, tape, dscores, grads):
         gw, gb = _g(grads, layer.multihead_attn.in_proj_weight), _g(grads, layer.multihead_attn.in_proj_bias)
         sl = dkv2[:, 2 * li * d:(2 * li + 2) * d]
 
-        def kv_param_grads(sl=sl, gw=gw, gb=gb):
-            if gw is not None:
-                ops.gemm_raw(sl, mem2, gw[d:], 2 * d, d, B * S, 1, sl.stride(0), 1, d, d, atomic=True, split_k=16)
-            if gb is not None:
+        wg = None
+        if gw is not None:
+            wg = ops.gemm_args(sl, mem2, gw[d:], 2 * d, d, B * S, 1, sl.stride(0), 1, d, d, atomic=True, split_k=16,
+                               colsum_a=None if gb is None else gb[d:])
+
+        def kv_param_grads(sl=sl, gb=gb, wg=wg):
+            if wg is not None:
+                ops.gemm_grouped([wg])
+            elif gb is not None:
                 ops.colsum(sl, gb[d:])
 
-        if ops.SIDE is not None:
+        if ops.SIDE is not None and wg is not None:
+            ops.SIDE.add_problem(wg, dkv_rows, mem2)
+        elif ops.SIDE is not None:
             ops.SIDE.submit(kv_param_grads, dkv_rows, mem2)
         else:
             kv_param_grads()
@@ -353,7 +367,7 @@ def _backward_from_tape(dec, tape, dscores, grads):
     ops.gemm_raw(dkv_rows[:, P:], m["wkv"], dctx, B * nctx, d, nseg * d, nseg * d, 1, 1, d, d, a_grp=nctx,
                  a_gs=S * nseg * d)
     if ops.SIDE is not None:
-        ops.SIDE.flush()
+        ops.SIDE.flush_group()          # the three K/V-projection weight gradients share a launch
     # ---- context encoders
     dee_enc = _context_encoder_bwd(dec, dec.transformer_encoder_entities, tape.enc_layers["entities"],
                                    dctx[:, :K].contiguous(), grads)

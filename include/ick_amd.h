@@ -67,6 +67,8 @@ typedef struct {
     const uint32_t* drop_epoch;                  /* optional device counter added to drop_seed (graph replays) */
     int64_t a_extent, b_extent;   /* floats addressable from A / B (bounds of the buffer descriptors); 0 = derive from
                                      the strides -- required when a_gmap is given, otherwise the slow path is taken */
+    float* colsum_a;              /* optional, k-major A only: colsum_a[m] += sum_k A(m,k) (float atomics) -- the bias
+                                     gradient of a Linear rides on its weight-gradient GEMM (A = dY^T) */
 } ick_gemm_args;
 
 #define ICK_GEMM_RELU 1
@@ -74,6 +76,10 @@ typedef struct {
 #define ICK_GEMM_ATOMIC 4
 
 int ick_gemm(const ick_gemm_args* args, void* stream);
+/* `count` (<= 64) independent problems; those that select the same kernel configuration share one launch (up to 8
+ * per launch).  Used for the weight-gradient GEMMs of a layer (geo-aware/train.py:284 `loss.backward()`), each of
+ * which alone is a latency-bound launch of a few hundred workgroups. */
+int ick_gemm_grouped(const ick_gemm_args* problems, int32_t count, void* stream);
 
 /* y[r,:] = LayerNorm(x[r,:] + res[r,:]) * gamma + beta   (res may be NULL), d <= 1024.
  * Replaces norm1/norm2/norm3 + the residual adds of Transformer{En,De}coderLayer

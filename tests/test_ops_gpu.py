@@ -108,6 +108,30 @@ def test_gemm_kmajor_operands_and_splitk(ops):
     close(dw2, 1.0 + 0.5 * (dy.double().t() @ x.double()), 1e-5 * math.sqrt(M), "wgrad accumulate")
 
 
+def test_gemm_grouped_and_colsum_fusion(ops):
+    """ick_gemm_grouped: weight-gradient problems of different shapes in one launch (plus one that needs another
+    kernel configuration), each with the bias gradient (column sums of the k-major A operand) fused in."""
+    shapes = [(1280, 300, 300), (1280, 512, 300), (1280, 300, 512), (1280, 900, 300), (260, 7, 300), (1280, 300, 300),
+              (13824, 600, 300), (1284, 10, 6), (1280, 304, 300), (1280, 300, 300)]
+    problems, keep, refs = [], [], []
+    for i, (M, N, K) in enumerate(shapes):
+        dy, x = rnd(M, N, seed=100 + i), rnd(M, K, seed=200 + i)
+        dw0, db0 = rnd(N, K, seed=300 + i), rnd(N, seed=400 + i)
+        ddy, dx_, dw, db = dev(dy), dev(x), dev(dw0), dev(db0)
+        keep += [ddy, dx_, dw, db]
+        problems.append(ops.gemm_args(ddy, dx_, dw, N, K, M, 1, N, 1, K, K, atomic=True,
+                                      split_k=max(1, min(16, M // 256)), colsum_a=db))
+        refs.append((dw, db, dw0.double() + dy.double().t() @ x.double(), db0.double() + dy.double().sum(0)))
+    ops.gemm_grouped(problems)
+    for i, (dw, db, rw, rb) in enumerate(refs):
+        close(dw, rw, 2e-4, "grouped dw %d" % i)
+        close(db, rb, 2e-4, "grouped db %d" % i)
+    # colsum_a needs a k-major A operand
+    bad = ops.gemm_args(keep[0], keep[1], keep[2], 1280, 300, 300, 300, 1, 300, 1, 300, colsum_a=keep[3])
+    with pytest.raises(Exception):
+        ops.gemm_grouped([bad])
+
+
 def test_gemm_argument_errors(ops):
     x = torch.zeros(4, 4, device="cuda")
     import ick_amd.lib as L
