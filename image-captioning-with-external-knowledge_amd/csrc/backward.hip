@@ -43,38 +43,56 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         gm[j] = c < d ? gamma[c] : 0.f;
     }
     const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
-    for (int r = wave; r < rows_per_block; r += 4) {
-        const int64_t row = row0 + r;
-        if (row >= rows) break;
-        const float mu = mean[row], rs = rstd[row];
-        float zh[NJ], g[NJ];
-        float s1 = 0.f, s2 = 0.f;
+    // two rows per wave and iteration: all loads of both rows are in flight before either is reduced (the
+    // kernel is bound by memory latency: 160 workgroups x 4 waves, ~15 small loads per row)
+    for (int r = wave; r < rows_per_block; r += 8) {
+        int64_t rows2[2] = {row0 + r, row0 + r + 4};
+        bool live[2] = {rows2[0] < rows, r + 4 < rows_per_block && rows2[1] < rows};
+        float zv[2][NJ], dyv[2][NJ], mu[2], rs[2];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int c = lane + 64 * j;
-            float z = 0.f, dyv = 0.f;
-            if (c < d) {
-                z = x[row * d + c];
+        for (int q = 0; q < 2; ++q) {
+            const int64_t row = live[q] ? rows2[q] : row0;   // row0 < rows: a valid address for dead slots
+            mu[q] = mean[row]; rs[q] = rstd[row];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int c = lane + 64 * j;
+                float z = 0.f, dv = 0.f, rv = 0.f;
+                if (c < d) {
+                    z = x[row * d + c];
+                    if (res) rv = res[row * d + c];
+                    dv = dy[row * d + c];
+                }
                 if (drop.on()) z *= drop.mask((uint32_t)row * (uint32_t)d + (uint32_t)c);
-                if (res) z += res[row * d + c];
-                dyv = dy[row * d + c];
+                zv[q][j] = z + rv;
+                dyv[q][j] = dv;
             }
-            zh[j] = c < d ? (z - mu) * rs : 0.f;
-            g[j] = dyv * gm[j];
-            s1 += g[j];
-            s2 += g[j] * zh[j];
-            ag[j] += dyv * zh[j];
-            ab[j] += dyv;
         }
-        s1 = wave_sum(s1) / (float)d;
-        s2 = wave_sum(s2) / (float)d;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int c = lane + 64 * j;
-            if (c < d) {
-                const float v = rs * (g[j] - s1 - zh[j] * s2);
-                dz[row * d + c] = v;
-                if (dx_drop) dx_drop[row * d + c] = drop.on() ? v * drop.mask((uint32_t)row * (uint32_t)d + (uint32_t)c) : v;
+        for (int q = 0; q < 2; ++q) {
+            if (!live[q]) continue;     // wave-uniform
+            const int64_t row = rows2[q];
+            float zh[NJ], g[NJ];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int c = lane + 64 * j;
+                zh[j] = c < d ? (zv[q][j] - mu[q]) * rs[q] : 0.f;
+                g[j] = dyv[q][j] * gm[j];
+                s1 += g[j];
+                s2 += g[j] * zh[j];
+                ag[j] += dyv[q][j] * zh[j];
+                ab[j] += dyv[q][j];
+            }
+            s1 = wave_sum(s1) / (float)d;
+            s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int c = lane + 64 * j;
+                if (c < d) {
+                    const float v = rs[q] * (g[j] - s1 - zh[j] * s2);
+                    dz[row * d + c] = v;
+                    if (dx_drop) dx_drop[row * d + c] = drop.on() ? v * drop.mask((uint32_t)row * (uint32_t)d + (uint32_t)c) : v;
+                }
             }
         }
     }
@@ -187,28 +205,45 @@ __global__ __launch_bounds__(256) void pointer_bwd_dh_kernel(const float* __rest
     }
 }
 
+// One workgroup per (sample, 64 columns): the (T x Kc) score gradients of the sample sit in LDS, lane <-> column,
+// the four waves share the Kc context rows.  d w and d bias leave the workgroup as one float atomic per column /
+// one per sample (a workgroup per (sample, row) made 1280 workgroups fight over the same 300 addresses: 59 us).
 __global__ __launch_bounds__(256) void pointer_bwd_dctx_kernel(const float* __restrict__ ds, int64_t ds_ld, int col0,
                                                                const float* __restrict__ h, const float* __restrict__ ctx,
                                                                const float* __restrict__ w, const float* __restrict__ ind,
                                                                float* __restrict__ dctx, float* __restrict__ dw,
                                                                float* __restrict__ dbias, int T, int Kc, int d) {
-    __shared__ float red[4];
-    const int b = blockIdx.y, k = blockIdx.x;
+    extern __shared__ float gs[];   // T * Kc gradients (indicator applied), 4 floats of scratch, 4 x 64 partial d w
+    float* red = gs + T * Kc;
+    float* dwp = red + 4;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float bsum = 0.f;
-    for (int c = threadIdx.x; c < d; c += 256) {
-        float acc = 0.f;
-        for (int t = 0; t < T; ++t) {
-            float g = ds[((int64_t)b * T + t) * ds_ld + col0 + k];
-            if (ind) g *= ind[((int64_t)b * T + t) * Kc + k];
-            acc = fmaf(g, h[((int64_t)b * T + t) * d + c], acc);
-        }
-        dctx[((int64_t)b * Kc + k) * d + c] += acc * w[c];
-        atomicAdd(dw + c, acc * ctx[((int64_t)b * Kc + k) * d + c]);
+    for (int idx = threadIdx.x; idx < T * Kc; idx += 256) {
+        const int t = idx / Kc, k = idx - t * Kc;
+        float g = ds[((int64_t)b * T + t) * ds_ld + col0 + k];
+        bsum += g;
+        if (ind) g *= ind[((int64_t)b * T + t) * Kc + k];
+        gs[idx] = g;
     }
-    if (threadIdx.x < T) bsum = ds[((int64_t)b * T + threadIdx.x) * ds_ld + col0 + k];
-    for (int t = threadIdx.x + 256; t < T; t += 256) bsum += ds[((int64_t)b * T + t) * ds_ld + col0 + k];
-    bsum = block_sum<4>(bsum, red);
-    if (threadIdx.x == 0) atomicAdd(dbias, bsum);
+    bsum = block_sum<4>(bsum, red);   // contains the barriers that publish gs
+    if (threadIdx.x == 0 && blockIdx.y == 0) atomicAdd(dbias, bsum);
+    const int c = blockIdx.y * 64 + lane;
+    const bool ok = c < d;
+    const float* hb = h + (int64_t)b * T * d + (ok ? c : 0);
+    const float wc = ok ? w[c] : 0.f;
+    float dwl = 0.f;
+    for (int k = wave; k < Kc; k += 4) {
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t) acc = fmaf(gs[t * Kc + k], hb[(int64_t)t * d], acc);
+        if (ok) {
+            const int64_t o = ((int64_t)b * Kc + k) * d + c;
+            dctx[o] += acc * wc;
+            dwl = fmaf(acc, ctx[o], dwl);
+        }
+    }
+    dwp[wave * 64 + lane] = dwl;
+    __syncthreads();
+    if (wave == 0 && ok) atomicAdd(dw + c, (dwp[lane] + dwp[64 + lane]) + (dwp[128 + lane] + dwp[192 + lane]));
 }
 
 // EntityEncoder backward: only the type embedding is trainable (feature slots are inputs).  News:
@@ -432,8 +467,10 @@ extern "C" int ick_pointer_scores_bwd(const float* ds, int64_t ds_ld, int32_t co
     ICK_CHECK_ARG(ds && h && ctx && w && dh && dctx && dw && dbias && B > 0 && B <= 65535 && T > 0 && Kc > 0 && d > 0);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(pointer_bwd_dh_kernel, dim3(T, B), dim3(256), 0, s, ds, ds_ld, col0, ctx, w, ind, dh, T, Kc, d);
-    hipLaunchKernelGGL(pointer_bwd_dctx_kernel, dim3(Kc, B), dim3(256), 0, s, ds, ds_ld, col0, h, ctx, w, ind, dctx, dw,
-                       dbias, T, Kc, d);
+    const size_t smem = ((size_t)T * Kc + 4 + 256) * sizeof(float);
+    ICK_CHECK_ARG(smem <= 64 * 1024);
+    hipLaunchKernelGGL(pointer_bwd_dctx_kernel, dim3(B, ceil_div(d, 64)), dim3(256), smem, s, ds, ds_ld, col0, h, ctx, w,
+                       ind, dctx, dw, dbias, T, Kc, d);
     ICK_LAUNCH_RET();
 }
 

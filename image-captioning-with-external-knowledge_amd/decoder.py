@@ -289,7 +289,7 @@ class DecoderTransformer(nn.Module):
         # The context-encoder chain (small, latency-bound kernels) runs on a second stream beside the
         # large image-row projection; both write disjoint key/value rows of `kv`.  The caller joins the
         # side stream before the first cross-attention (`side.join()`).
-        side = ops.SideStream()
+        side = ops.SideStream(priority=-1)
         with side.fork(ee, fe, kv, wkv, bkv):
             ctx_e = self._context_encoder(self.transformer_encoder_entities, ee)
             ops.project_heads(ctx_e, wkv, bkv, nseg, H, S, out=kv, s0=P, grp=K)

@@ -352,7 +352,7 @@ def layernorm_bwd(dy, x, res, gamma, mean, rstd, dgamma, dbeta, drop=None):
 
     if SIDE is not None:
         SIDE.flush()     # side work marked earlier goes out now that the main chain has its next kernel
-        SIDE.submit(reduce_partials, part)
+        SIDE.submit_with_group(reduce_partials, part)
     else:
         reduce_partials()
     return dz, dxd
@@ -392,13 +392,16 @@ class SideStream:
     main chain is the first child of every node: hipGraph keeps a node's first child on the parent's queue,
     and a hop to another queue costs ~15 us of idle time on the critical path."""
 
-    def __init__(self):
-        self.stream = torch.cuda.Stream()
+    def __init__(self, priority=0):
+        # priority -1: the chain of small kernels on the side stream competes with a large GEMM on the main stream
+        # for workgroup slots; a high-priority queue gets its workgroups dispatched first
+        self.stream = torch.cuda.Stream(priority=priority)
         self.pending = False
         self.keep = []   # tensors the side stream reads stay referenced until the pass ends, so the caching
                          # allocator cannot hand their memory to the main stream meanwhile (also under capture)
         self.deferred = []
         self.group = []  # weight-gradient problems (ick_gemm_args) waiting for the next flush_group()
+        self.late = []   # (fn, tensors) enqueued with the next grouped launch
 
     def add_problem(self, args, *tensors):
         """Queue a GEMM whose operands are complete on the main stream by the next flush_group()."""
@@ -408,9 +411,17 @@ class SideStream:
     def flush_group(self):
         """One grouped launch (ick_gemm_grouped) of the queued problems on the side stream, ordered after
         everything enqueued so far on the main stream; like submit() it is enqueued at the next flush()."""
-        if self.group:
+        if self.group or self.late:
             problems, self.group = self.group, []
-            self.deferred.append((self.mark(), lambda: gemm_grouped(problems), ()))
+            late, self.late = self.late, []
+
+            def launch():
+                if problems:
+                    gemm_grouped(problems)
+                for fn, _ in late:
+                    fn()
+
+            self.deferred.append((self.mark(), launch, tuple(t for _, ts in late for t in ts)))
 
     def mark(self):
         """Event at the current point of the main stream, for a later fork(..., after=event)."""
@@ -427,6 +438,12 @@ class SideStream:
 
     def submit(self, fn, *tensors):
         self.deferred.append((self.mark(), fn, tensors))
+
+    def submit_with_group(self, fn, *tensors):
+        """Side work that may wait for the layer's grouped launch: it shares that launch's dependency point, so
+        the main-stream kernel that produced its input does not become a fork point of the captured graph
+        (each one costs the main chain ~4 us)."""
+        self.late.append((fn, tensors))
 
     def flush(self):
         work, self.deferred = self.deferred, []
@@ -479,6 +496,10 @@ def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False, gro
     if need_dx:
         # a long reduction (the vocabulary: N = 10k..50k) over few output tiles is split over workgroups
         split = max(1, min(16, N // 1024)) if (M * K) <= 1280 * 512 else 1
+        if accumulate_dx and split == 1 and N >= 512 and (M * K) <= 1280 * 512:
+            # the output already holds the residual-path gradient: K slices of ~300 can simply add to it
+            # (1280 x 300 x 900: 22 -> ~10 us; the kernel is bound by the latency of its K loop)
+            split = max(1, min(8, (N + 150) // 300))
         if split > 1:
             if dx is None:
                 dx = torch.zeros(M, K, device=dy.device, dtype=torch.float32)

@@ -17,6 +17,7 @@ counter-based generator (see ick_dropout) and cannot be bit-identical to torch's
 parity of the training math is pinned with dropout disabled (p = 0 / eval-mode fixtures).
 """
 import math
+import os
 
 import torch
 
@@ -158,7 +159,7 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
             mem[:, P + K:].copy_(ctx_f)
             ops.project_heads(ctx_f, wkv, bkv, nseg, H, S, out=kv, s0=P + K, grp=Fn)
 
-    side = ops.SideStream() if overlap else None
+    side = ops.SideStream(priority=-1) if overlap else None
     if side is not None:
         side.submit(context_chain, ee, fe, mem, kv, wkv, bkv)
     else:
@@ -241,7 +242,7 @@ def _context_encoder_bwd(dec, stack, tapes, dx, grads):
     return dx
 
 
-def _decoder_layer_bwd(dec, li, layer, t, dx, dkv_rows, kv, S, grads):
+def _decoder_layer_bwd(dec, li, layer, t, dx, dkv_rows, kv, S, grads, mem2=None):
     H, d = dec.num_heads, dec.emb_dim
     dh = d // H
     B, T, _ = t["x"].shape
@@ -260,6 +261,10 @@ def _decoder_layer_bwd(dec, li, layer, t, dx, dkv_rows, kv, S, grads):
     c0 = 2 * li * d
     ops.attention_heads_bwd(t["qc"], kv, t["ca"], dca.view(B, T, d), t["lse_c"], dq, dkv_rows[:, :, c0:c0 + d],
                             dkv_rows[:, :, c0 + d:c0 + 2 * d], H, dh, T, S, 0, 2 * li, 2 * li + 1, drop=t["d_ca"])
+    if mem2 is not None:
+        # this layer's columns of the K/V-projection gradient are complete: its weight (and bias) gradient over
+        # all B * S memory rows joins this layer's group instead of waiting for the whole decoder stack
+        _kv_proj_param_grads(layer, li, dkv_rows, mem2, grads, d)
     dx1 = _lin_bwd(grads, dq.view(M, d), t["x1"].view(M, d), layer.multihead_attn.in_proj_weight,
                    layer.multihead_attn.in_proj_bias, w_rows=slice(0, d), dx=dz.view(M, d), acc=True)
     dz, do1 = ops.layernorm_bwd(dx1.view(B, T, d), t["o1"], t["x"], _p(layer.norm1.weight), t["m1"], t["r1"],
@@ -275,6 +280,22 @@ def _decoder_layer_bwd(dec, li, layer, t, dx, dkv_rows, kv, S, grads):
     if ops.SIDE is not None:
         ops.SIDE.flush_group()          # this layer's weight gradients: one grouped launch
     return dx0
+
+
+def _kv_proj_param_grads(layer, li, dkv_rows, mem2, grads, d):
+    """dW[d:3d] += dkv[:, layer columns].T @ memory, db[d:3d] += column sums (fused), for one decoder layer."""
+    gw, gb = _g(grads, layer.multihead_attn.in_proj_weight), _g(grads, layer.multihead_attn.in_proj_bias)
+    rows = mem2.shape[0]
+    sl = dkv_rows.view(rows, -1)[:, 2 * li * d:(2 * li + 2) * d]
+    if gw is not None:
+        wg = ops.gemm_args(sl, mem2, gw[d:], 2 * d, d, rows, 1, sl.stride(0), 1, d, d, atomic=True, split_k=16,
+                           colsum_a=None if gb is None else gb[d:])
+        if ops.SIDE is not None:
+            ops.SIDE.add_problem(wg, dkv_rows, mem2)
+        else:
+            ops.gemm_grouped([wg])
+    elif gb is not None:
+        ops.colsum(sl, gb[d:])
 
 
 def backward_from_tape(dec, tape, dscores, grads, overlap=True):
@@ -337,37 +358,16 @@ def _backward_from_tape(dec, tape, dscores, grads):
     dkv_rows = ops.attention_bwd_buffer((B, S, nseg * d), L, S, d // H, dev)
     dx = dh
     for li in reversed(range(len(layers))):
-        dx = _decoder_layer_bwd(dec, li, layers[li], tape.dec_layers[li], dx, dkv_rows, m["kv"], S, grads)
-    # ---- cross K/V projection: weight gradient over all memory rows, data gradient for context rows only
-    mem2 = m["mem"].view(B * S, d)
-    dkv2 = dkv_rows.view(B * S, nseg * d)
-    for li, layer in enumerate(layers):
-        gw, gb = _g(grads, layer.multihead_attn.in_proj_weight), _g(grads, layer.multihead_attn.in_proj_bias)
-        sl = dkv2[:, 2 * li * d:(2 * li + 2) * d]
-
-        wg = None
-        if gw is not None:
-            wg = ops.gemm_args(sl, mem2, gw[d:], 2 * d, d, B * S, 1, sl.stride(0), 1, d, d, atomic=True, split_k=16,
-                               colsum_a=None if gb is None else gb[d:])
-
-        def kv_param_grads(sl=sl, gb=gb, wg=wg):
-            if wg is not None:
-                ops.gemm_grouped([wg])
-            elif gb is not None:
-                ops.colsum(sl, gb[d:])
-
-        if ops.SIDE is not None and wg is not None:
-            ops.SIDE.add_problem(wg, dkv_rows, mem2)
-        elif ops.SIDE is not None:
-            ops.SIDE.submit(kv_param_grads, dkv_rows, mem2)
-        else:
-            kv_param_grads()
+        dx = _decoder_layer_bwd(dec, li, layers[li], tape.dec_layers[li], dx, dkv_rows, m["kv"], S, grads,
+                                mem2=m["mem"].view(B * S, d))
+    # ---- cross K/V projection: the weight gradients went out with the decoder layers; data gradient for the
+    # context rows only (the image rows' gradient would be Encoder.conv1's, which the reference never uses)
     nctx = K + Fn
-    dctx = torch.empty(B, nctx, d, device=dev, dtype=torch.float32)
+    # K = 2 * layers * d = 1800 over only B * nctx x d outputs: split the reduction (40 -> ~15 us with the fill)
+    ksplit = max(1, min(8, (nseg * d) // 450)) if B * nctx * d <= 1280 * 512 else 1
+    dctx = (torch.zeros if ksplit > 1 else torch.empty)(B, nctx, d, device=dev, dtype=torch.float32)
     ops.gemm_raw(dkv_rows[:, P:], m["wkv"], dctx, B * nctx, d, nseg * d, nseg * d, 1, 1, d, d, a_grp=nctx,
-                 a_gs=S * nseg * d)
-    if ops.SIDE is not None:
-        ops.SIDE.flush_group()          # the three K/V-projection weight gradients share a launch
+                 a_gs=S * nseg * d, atomic=ksplit > 1, split_k=ksplit)
     # ---- context encoders
     dee_enc = _context_encoder_bwd(dec, dec.transformer_encoder_entities, tape.enc_layers["entities"],
                                    dctx[:, :K].contiguous(), grads)
@@ -474,7 +474,8 @@ class TrainStep:
                                          seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
                                          overlap=self.use_graph)
         loss_sum, count, dscores = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True)
-        backward_from_tape(dec, tape, dscores, self.grads, overlap=self.use_graph)
+        backward_from_tape(dec, tape, dscores, self.grads,
+                           overlap=self.use_graph and not os.environ.get("ICK_NO_BWD_OVERLAP"))
         self.flat_g[self.n:self.n + 1].copy_(loss_sum)
         self.flat_g[self.n + 1:].copy_(count)
         return self.flat_g
