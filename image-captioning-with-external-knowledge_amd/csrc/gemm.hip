@@ -63,14 +63,15 @@ __device__ __forceinline__ int64_t col_offset(const ick_gemm_args& p, int col) {
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 constexpr uint32_t kOobOffset = 0x80000000u;   // >= any extent the vector path accepts (< 2 GiB)
 
-template <int R, bool KM, bool VEC, int BKT>
+template <int R, bool KM, bool VEC, int BKT, int NT = 256>
 struct Stager {
-    static constexpr int NP = R * BKT / 1024;        // float4 per thread (256 threads)
+    static constexpr int NP = R * BKT / (4 * NT);    // float4 per thread (NT threads)
+    static_assert(NP >= 1, "tile too small for the workgroup");
     static constexpr int CH = KM ? R / 4 : BKT / 4;  // float4 chunks along the contiguous dim
     static constexpr int LD = KM ? R + 4 : BKT + 4;
     static constexpr int FLOATS = KM ? BKT * LD : R * LD;
-    static constexpr int KP = 256 / CH;              // k-major: k lines covered per pass
-    static constexpr int RP = 256 / CH;              // k-contiguous: rows covered per pass
+    static constexpr int KP = NT / CH;               // k-major: k lines covered per pass
+    static constexpr int RP = NT / CH;               // k-contiguous: rows covered per pass
     const float* base;
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff[NP];         // VEC: byte offset of this thread's float4 of pass j at k = 0
@@ -199,8 +200,8 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
                                           int zid, float* smem) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     constexpr int BK = BKT;
-    using SA = Stager<BM, AKM, VEC, BKT>;
-    using SB = Stager<BN, BKM, VEC, BKT>;
+    using SA = Stager<BM, AKM, VEC, BKT, WM * WN * 64>;
+    using SB = Stager<BN, BKM, VEC, BKT, WM * WN * 64>;
     constexpr int STAGE = SA::FLOATS + SB::FLOATS;
 
     // XCD-aware tile order (blocks b, b+8, ... share an XCD).
@@ -344,7 +345,7 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
 }
 
 template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT>
-__global__ __launch_bounds__(256) void gemm_kernel(ick_gemm_args p, int tiles_m, int tiles_n, int kchunk) {
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(ick_gemm_args p, int tiles_m, int tiles_n, int kchunk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     gemm_tile<WM, WN, TM, TN, AKM, BKM, VEC, BKT>(p, tiles_m, tiles_n, kchunk, blockIdx.x, blockIdx.z, smem);
 }
@@ -375,19 +376,24 @@ struct Plan {
     ick_gemm_args a;
     bool akm, bkm, vec;
     bool big;                    // 64 x 64 tiles (else 32 x 32)
+    bool wide;                   // 128 x 64 tiles, 8 waves (single launches only)
     int tiles_m, tiles_n, kchunk, split;
 };
 
-template <int TM, int TN, bool AKM, bool BKM, bool VEC>
-int launch_one(const Plan& pl, hipStream_t s) {
-    constexpr int BM = 2 * TM * 16, BN = 2 * TN * 16;
-    constexpr int STAGE = Stager<BM, AKM, VEC, 32>::FLOATS + Stager<BN, BKM, VEC, 32>::FLOATS;
+template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC>
+int launch_tile(const Plan& pl, hipStream_t s) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = WM * WN * 64;
+    constexpr int STAGE = Stager<BM, AKM, VEC, 32, NT>::FLOATS + Stager<BN, BKM, VEC, 32, NT>::FLOATS;
     constexpr size_t smem = 2 * STAGE * sizeof(float);
     static_assert(smem <= 64 * 1024, "tile needs the large-LDS attribute");
-    hipLaunchKernelGGL((gemm_kernel<2, 2, TM, TN, AKM, BKM, VEC, 32>), dim3(pl.tiles_m * pl.tiles_n, 1, pl.split),
-                       dim3(256), smem, s, pl.a, pl.tiles_m, pl.tiles_n, pl.kchunk);
+    hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, AKM, BKM, VEC, 32>), dim3(pl.tiles_m * pl.tiles_n, 1, pl.split),
+                       dim3(NT), smem, s, pl.a, pl.tiles_m, pl.tiles_n, pl.kchunk);
     ICK_LAUNCH_RET();
 }
+template <int TM, int TN, bool AKM, bool BKM, bool VEC>
+int launch_one(const Plan& pl, hipStream_t s) { return launch_tile<2, 2, TM, TN, AKM, BKM, VEC>(pl, s); }
+template <int TM, int TN, bool AKM, bool BKM, bool VEC>
+int launch_wide(const Plan& pl, hipStream_t s) { return launch_tile<4, 2, TM, TN, AKM, BKM, VEC>(pl, s); }   // 8 waves
 
 template <int TM, int TN, bool AKM, bool BKM>
 int launch_group(const Plan* const* pls, int n, hipStream_t s) {
@@ -475,9 +481,10 @@ int make_plan(const ick_gemm_args* in, Plan& pl) {
         if (forced == -2) { const char* e = getenv("ICK_GEMM_TILE"); forced = e ? atoi(e) : -1; }
         if (forced == 2) pl.big = true;
         if (forced == 3 && pl.vec) pl.big = false;
+        pl.wide = forced == 8 && pl.vec && pl.big && a.M >= 128;
     }
     const int BMN = pl.big ? 64 : 32;
-    pl.tiles_m = ceil_div(a.M, BMN); pl.tiles_n = ceil_div(a.N, BMN);
+    pl.tiles_m = ceil_div(a.M, pl.wide ? 128 : BMN); pl.tiles_n = ceil_div(a.N, BMN);
     pl.kchunk = ceil_div(ceil_div(a.K, split_req), 32) * 32;
     pl.split = ceil_div(a.K, pl.kchunk);
     return ICK_OK;
@@ -495,6 +502,7 @@ int make_plan(const ick_gemm_args* in, Plan& pl) {
 
 int launch_plan(const Plan& pl, hipStream_t s) {
     if (!pl.vec) ICK_BY_LAYOUT(launch_one, 2, 2, ICK_COMMA_FALSE, pl, s);
+    if (pl.wide) ICK_BY_LAYOUT(launch_wide, 2, 2, ICK_COMMA_TRUE, pl, s);
     if (pl.big) ICK_BY_LAYOUT(launch_one, 2, 2, ICK_COMMA_TRUE, pl, s);
     ICK_BY_LAYOUT(launch_one, 1, 1, ICK_COMMA_TRUE, pl, s);
 }
@@ -525,7 +533,7 @@ extern "C" int ick_gemm_grouped(const ick_gemm_args* problems, int32_t count, vo
     bool done[64] = {false};
     for (int i = 0; i < count; ++i) {
         if (done[i]) continue;
-        if (!plans[i].vec) {          // element-wise staging: no grouped instantiation, launch alone
+        if (!plans[i].vec || plans[i].wide) {   // element-wise staging / 8-wave tiles: no grouped instantiation
             done[i] = true;
             if (int rc = launch_plan(plans[i], s)) return rc;
             continue;
@@ -533,7 +541,7 @@ extern "C" int ick_gemm_grouped(const ick_gemm_args* problems, int32_t count, vo
         const Plan* grp[kGroupMax];
         int n = 0;
         for (int j = i; j < count && n < kGroupMax; ++j) {
-            if (done[j] || !plans[j].vec || plans[j].akm != plans[i].akm || plans[j].bkm != plans[i].bkm ||
+            if (done[j] || !plans[j].vec || plans[j].wide || plans[j].akm != plans[i].akm || plans[j].bkm != plans[i].bkm ||
                 plans[j].big != plans[i].big) continue;
             grp[n++] = &plans[j];
             done[j] = true;

@@ -42,7 +42,7 @@ class _GraphedCall:
     forward, ~900 for a 20-step greedy decode -- replays from one hipGraphLaunch with no host work in between."""
 
     def __init__(self, fn, example_inputs):
-        self.static_in = [None if t is None else t.clone() for t in example_inputs]
+        self.static_in = [None if t is None else t.contiguous().clone() for t in example_inputs]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):            # warm-up off the capture: lazy hipFuncSetAttribute, caches
@@ -183,6 +183,7 @@ class DecoderTransformer(nn.Module):
 
     def load_pretrained_embeddings(self, embeddings):
         self.word_embedding.weight = nn.Parameter(embeddings)
+        self.invalidate_caches()      # a new Parameter object: cached parameter list, packed weights, graphs
 
     def fine_tune_embeddings(self, fine_tune=True):
         for p in self.word_embedding.parameters():
@@ -214,7 +215,7 @@ class DecoderTransformer(nn.Module):
         writes the flat bucket directly): drops the packed cross-K/V weights, the transposed predicate
         weights and every captured graph."""
         self.__dict__["_param_epoch"] = self.__dict__.get("_param_epoch", 0) + 1
-        for k in ("_kv_pack", "_pred_wt_cache", "_graphs"):
+        for k in ("_kv_pack", "_pred_wt_cache", "_graphs", "_plist"):
             self.__dict__.pop(k, None)
 
     def _token_major(self, encoder_out):
@@ -290,15 +291,22 @@ class DecoderTransformer(nn.Module):
         # large image-row projection; both write disjoint key/value rows of `kv`.  The caller joins the
         # side stream before the first cross-attention (`side.join()`).
         side = ops.SideStream(priority=-1)
-        with side.fork(ee, fe, kv, wkv, bkv):
-            ctx_e = self._context_encoder(self.transformer_encoder_entities, ee)
-            ops.project_heads(ctx_e, wkv, bkv, nseg, H, S, out=kv, s0=P, grp=K)
-            ctx_f = None
+        ctx = [None, None]
+
+        def context_chain():
+            ctx[0] = self._context_encoder(self.transformer_encoder_entities, ee)
+            ops.project_heads(ctx[0], wkv, bkv, nseg, H, S, out=kv, s0=P, grp=K)
             if self.has_facts:
-                ctx_f = self._context_encoder(self.transformer_encoder_facts, fe)
-                ops.project_heads(ctx_f, wkv, bkv, nseg, H, S, out=kv, s0=P + K, grp=Fn)
+                ctx[1] = self._context_encoder(self.transformer_encoder_facts, fe)
+                ops.project_heads(ctx[1], wkv, bkv, nseg, H, S, out=kv, s0=P + K, grp=Fn)
+
+        # dependency point now, enqueued after the main stream's next kernel: in a captured graph the main chain
+        # must be the first child of the fork node (see SideStream)
+        side.submit(context_chain, ee, fe, kv, wkv, bkv)
         # image rows (gathered through gmap = sort order)
         ops.project_heads(enc_tok, wkv, bkv, nseg, H, S, out=kv, s0=0, grp=P, a_gmap=gmap, a_gs=enc_tok.stride(0))
+        side.flush()
+        ctx_e, ctx_f = ctx
         return ee, fe, kv, (ctx_e, ctx_f), side
 
     def _decoder_layer(self, li, layer, x, kv, S, qkv_buf=None, pos=None, side=None):
@@ -385,7 +393,11 @@ class DecoderTransformer(nn.Module):
         through their device pointers, so in-place weight updates are seen, re-allocation is not
         (the key includes the parameters' storage pointers)."""
         cache = self.__dict__.setdefault("_graphs", {})
-        pkey = (self.__dict__.get("_param_epoch", 0),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        plist = self.__dict__.get("_plist")
+        if plist is None:       # the module tree is fixed after construction; invalidate_caches() drops this list
+            plist = self.__dict__["_plist"] = list(self.parameters())
+        pkey = (self.__dict__.get("_param_epoch", 0),) + tuple(p._version for p in plist) + \
+            tuple(p.data_ptr() for p in plist)
         full = (kind, key, pkey)
         g = cache.get(full)
         if g is None:
@@ -398,27 +410,36 @@ class DecoderTransformer(nn.Module):
         encoder_out, entities, facts = self._prepare_inputs(encoder_out, entities, facts)
         dev = encoder_out.device
         # length sort on the host, like the reference's CPU path (the result feeds a Python list anyway)
-        lengths, sort_ind = caption_lengths.detach().squeeze(1).cpu().sort(dim=0, descending=True)
+        lengths, sort_ind = caption_lengths.detach().reshape(-1).cpu().sort(dim=0, descending=True)
         decode_lengths = (lengths - 1).tolist()
-        sort_dev = sort_ind.to(dev)
-        captions = captions.to(dev)[sort_dev].contiguous()
-        caption_masks = caption_masks.to(dev)[sort_dev].contiguous()
-        entities = entities[sort_dev].contiguous()
-        if self.has_facts:
-            facts = facts[sort_dev].contiguous()
+        sort_dev = sort_ind.to(dev, non_blocking=True)
+        captions = captions.to(dev)
+        caption_masks = caption_masks.to(dev)
         enc_tok = self._token_major(encoder_out)
-        gmap = sort_dev.to(torch.int32)
+
+        def sorted_inputs(c, m, e, f, sd):
+            """Batch permutation into length order (reference: geo-aware/models.py:330-336), on the device."""
+            return (c.index_select(0, sd), m.index_select(0, sd), e.index_select(0, sd),
+                    None if f is None else f.index_select(0, sd), sd.to(torch.int32))
+
+        if stages is None and not self._wants_grad() and self.use_hip_graphs:
+            # the permutation is part of the captured graph: per call the host only sorts B lengths, copies the raw
+            # inputs into the graph's buffers and replays
+            def device_fn(c, m, e, f, t, sd):
+                c2, m2, e2, f2, gmap = sorted_inputs(c, m, e, f, sd)
+                return self._forward_device(c2, m2, e2, f2, t, gmap), c2
+
+            key = (tuple(captions.shape), tuple(enc_tok.shape), tuple(entities.shape),
+                   None if facts is None else tuple(facts.shape))
+            scores, caps_sorted = self._graphed("fwd", key, device_fn,
+                                                [captions, caption_masks, entities, facts, enc_tok, sort_dev])
+            return scores, caps_sorted, decode_lengths
+        captions, caption_masks, entities, facts, gmap = sorted_inputs(captions, caption_masks, entities, facts, sort_dev)
         if self._wants_grad() and stages is None:
             # autograd bridge: the HIP backward pass runs when the caller's loss.backward() reaches us
             from . import training
             scores = training.DecoderGraphFn.apply(self, captions, caption_masks, entities, facts, enc_tok.detach(),
                                                    gmap, *training.unique_parameters(self))
-            return scores, captions, decode_lengths
-        if stages is None and self.use_hip_graphs:
-            key = (tuple(captions.shape), tuple(enc_tok.shape), tuple(entities.shape),
-                   None if facts is None else tuple(facts.shape))
-            scores = self._graphed("fwd", key, lambda c, m, e, f, t, g: self._forward_device(c, m, e, f, t, g),
-                                   [captions, caption_masks, entities, facts, enc_tok.contiguous(), gmap])
             return scores, captions, decode_lengths
         return self._forward_device(captions, caption_masks, entities, facts, enc_tok, gmap, stages), captions, \
             decode_lengths
