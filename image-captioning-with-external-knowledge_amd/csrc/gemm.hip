@@ -326,6 +326,8 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
                 v[b] = acc[a][b][r] * alpha + bv[b];
                 if (relu) v[b] = fmaxf(v[b], 0.f);
                 if (drop.on()) v[b] *= drop.mask((uint32_t)rowid[a][r] * (uint32_t)p.N + (uint32_t)cols[b]);
+                if (p.gate != nullptr && cols[b] < p.N)
+                    v[b] = p.gate[(int64_t)rowid[a][r] * p.gate_rs + cols[b]] > 0.f ? v[b] * p.gate_scale : 0.f;
             }
             if (mode == 0) {
 #pragma unroll
@@ -428,6 +430,7 @@ int make_plan(const ick_gemm_args* in, Plan& pl) {
     ICK_CHECK_ARG((a.b_rs == 1) || (a.b_ks == 1));
     if (a.split_k > 1) ICK_CHECK_ARG(a.flags & ICK_GEMM_ATOMIC);
     if (a.colsum_a) ICK_CHECK_ARG(akm);       // column sums come from the k-major A tile
+    if (a.gate) ICK_CHECK_ARG(a.hs_dh <= 0 && a.c_grp <= 0 && a.split_k <= 1 && !(a.flags & (ICK_GEMM_ATOMIC | ICK_GEMM_ACCUM)));
     if (a.hs_dh > 0) {
         ICK_CHECK_ARG(a.hs_dhp >= a.hs_dh && a.hs_H > 0 && a.hs_S > 0 && a.hs_s0 >= 0);
         ICK_CHECK_ARG(a.N % (a.hs_H * a.hs_dh) == 0);

@@ -31,6 +31,7 @@ class GemmArgs(C.Structure):
         ("hs_dh", i32), ("hs_dhp", i32), ("hs_H", i32), ("hs_S", i32), ("hs_s0", i32),
         ("drop_p", f32), ("drop_seed", u32), ("drop_site", u32), ("drop_epoch", vp),
         ("a_extent", i64), ("b_extent", i64), ("colsum_a", vp),
+        ("gate", vp), ("gate_rs", i64), ("gate_scale", f32),
     ]
 
 

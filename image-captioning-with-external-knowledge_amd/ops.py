@@ -48,7 +48,7 @@ def _dargs(drop):
 
 def gemm_args(A, B, Cout, M, N, K, a_rs, a_ks, b_rs, b_ks, c_rs, bias=None, a_grp=0, a_gs=0, a_gmap=None,
               c_grp=0, c_gs=0, c_gmap=None, relu=False, accumulate=False, atomic=False, split_k=1, alpha=1.0,
-              drop=None, colsum_a=None):
+              drop=None, colsum_a=None, gate=None, gate_scale=1.0):
     """ick_gemm_args for C[m,n] = act(alpha * sum_k A(m,k) B(n,k) + bias[n]) with explicit element strides; A/B/Cout
     are tensors (only their data pointers are used -- the caller guarantees the strides stay in bounds).
     colsum_a (k-major A only): colsum_a[m] += sum_k A(m,k)."""
@@ -63,6 +63,8 @@ def gemm_args(A, B, Cout, M, N, K, a_rs, a_ks, b_rs, b_ks, c_rs, bias=None, a_gr
     a.alpha = alpha
     a.a_extent, a.b_extent = _extent(A), _extent(B)
     a.colsum_a = _p(colsum_a)
+    if gate is not None:
+        a.gate, a.gate_rs, a.gate_scale = _p(gate), gate.stride(0), gate_scale
     _drop(a, drop)
     return a
 
@@ -462,7 +464,8 @@ class SideStream:
 SIDE = None   # set by training.TrainStep / backward_from_tape for the duration of a backward pass
 
 
-def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False, group_now=False):
+def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False, group_now=False, gate=None,
+               gate_scale=1.0):
     """Backward of y = x @ w.T + b for row-major 2-D views dy (M,N), x (M,K), w (N,K):
     dw += dy.T @ x (split-K over M, float atomics), db += colsum(dy), dx = dy @ w.
     With a SideStream installed the two parameter gradients run beside the data gradient."""
@@ -509,9 +512,14 @@ def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False, gro
         else:
             if dx is None:
                 dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
-            gemm_raw(dy, w, dx, M, K, N, dy.stride(0), 1, 1, w.stride(0), dx.stride(0), accumulate=accumulate_dx)
+            # gate: the consumer wants ReLU'(act) * dx (FFN inner activation): applied in the epilogue
+            gemm_raw(dy, w, dx, M, K, N, dy.stride(0), 1, 1, w.stride(0), dx.stride(0), accumulate=accumulate_dx,
+                     gate=gate, gate_scale=gate_scale)
+            gate = None
     if not overlap:
         param_grads()
+    if gate is not None:        # split-K path: the gate cannot ride on partial sums
+        relu_bwd(dx, gate, out=dx, scale=gate_scale)
     return dx
 
 

@@ -206,7 +206,8 @@ def _g(grads, param):
     return grads.get(id(param))
 
 
-def _lin_bwd(grads, dy2, x2, lin_w, lin_b, w_rows=None, need_dx=True, dx=None, acc=False, group_now=False):
+def _lin_bwd(grads, dy2, x2, lin_w, lin_b, w_rows=None, need_dx=True, dx=None, acc=False, group_now=False,
+             gate=None, gate_scale=1.0):
     """Backward of a Linear whose weight is `lin_w` (optionally the row slice w_rows of it)."""
     gw, gb = _g(grads, lin_w), _g(grads, lin_b)
     w = _p(lin_w)
@@ -214,7 +215,8 @@ def _lin_bwd(grads, dy2, x2, lin_w, lin_b, w_rows=None, need_dx=True, dx=None, a
         w = w[w_rows]
         gw = gw[w_rows] if gw is not None else None
         gb = gb[w_rows] if gb is not None else None
-    return ops.linear_bwd(dy2, x2, w, gw, gb, need_dx=need_dx, dx=dx, accumulate_dx=acc, group_now=group_now)
+    return ops.linear_bwd(dy2, x2, w, gw, gb, need_dx=need_dx, dx=dx, accumulate_dx=acc, group_now=group_now,
+                          gate=gate, gate_scale=gate_scale)
 
 
 def _context_encoder_bwd(dec, stack, tapes, dx, grads):
@@ -224,8 +226,8 @@ def _context_encoder_bwd(dec, stack, tapes, dx, grads):
         M = B * T
         dz, do2 = ops.layernorm_bwd(dx, t["o2"], t["x1"], _p(layer.norm2.weight), t["m2"], t["r2"],
                                     _g(grads, layer.norm2.weight), _g(grads, layer.norm2.bias), drop=t["d2"])
-        df = _lin_bwd(grads, do2.view(M, d), t["f"].view(M, -1), layer.linear2.weight, layer.linear2.bias)
-        dpre = ops.relu_bwd(df, t["f"].view(M, -1), scale=_keep_scale(t["d_ff"]))
+        dpre = _lin_bwd(grads, do2.view(M, d), t["f"].view(M, -1), layer.linear2.weight, layer.linear2.bias,
+                        gate=t["f"].view(M, -1), gate_scale=_keep_scale(t["d_ff"]))   # ReLU' (+ dropout) fused
         dx1 = _lin_bwd(grads, dpre, t["x1"].view(M, d), layer.linear1.weight, layer.linear1.bias, dx=dz.view(M, d),
                        acc=True)
         dz, do1 = ops.layernorm_bwd(dx1.view(B, T, d), t["o1"], t["x"], _p(layer.norm1.weight), t["m1"], t["r1"],
@@ -249,8 +251,8 @@ def _decoder_layer_bwd(dec, li, layer, t, dx, dkv_rows, kv, S, grads, mem2=None)
     M = B * T
     dz, do3 = ops.layernorm_bwd(dx, t["o3"], t["x2"], _p(layer.norm3.weight), t["m3"], t["r3"],
                                 _g(grads, layer.norm3.weight), _g(grads, layer.norm3.bias), drop=t["d3"])
-    df = _lin_bwd(grads, do3.view(M, d), t["f"].view(M, -1), layer.linear2.weight, layer.linear2.bias)
-    dpre = ops.relu_bwd(df, t["f"].view(M, -1), scale=_keep_scale(t["d_ff"]))
+    dpre = _lin_bwd(grads, do3.view(M, d), t["f"].view(M, -1), layer.linear2.weight, layer.linear2.bias,
+                    gate=t["f"].view(M, -1), gate_scale=_keep_scale(t["d_ff"]))       # ReLU' (+ dropout) fused
     dx2 = _lin_bwd(grads, dpre, t["x2"].view(M, d), layer.linear1.weight, layer.linear1.bias, dx=dz.view(M, d),
                    acc=True)
     dz, do2 = ops.layernorm_bwd(dx2.view(B, T, d), t["o2"], t["x1"], _p(layer.norm2.weight), t["m2"], t["r2"],

@@ -69,6 +69,10 @@ typedef struct {
                                      the strides -- required when a_gmap is given, otherwise the slow path is taken */
     float* colsum_a;              /* optional, k-major A only: colsum_a[m] += sum_k A(m,k) (float atomics) -- the bias
                                      gradient of a Linear rides on its weight-gradient GEMM (A = dY^T) */
+    const float* gate;            /* optional (plain row-major C only): C[m,n] = gate[m*gate_rs + n] > 0 ? v * gate_scale : 0,
+                                     applied last -- the ReLU (+ dropout) backward of the FFN rides on the data-gradient
+                                     GEMM of linear2 (gate = the saved activation, gate_scale = 1/(1-p)) */
+    int64_t gate_rs; float gate_scale;
 } ick_gemm_args;
 
 #define ICK_GEMM_RELU 1

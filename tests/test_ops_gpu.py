@@ -132,6 +132,19 @@ def test_gemm_grouped_and_colsum_fusion(ops):
         ops.gemm_grouped([bad])
 
 
+def test_gemm_gate_epilogue(ops):
+    """The FFN's ReLU (+ dropout) backward fused into the data-gradient GEMM: C = gate > 0 ? (A B^T) * s : 0."""
+    M, N, K = 1280, 512, 300
+    dy, w = rnd(M, K, seed=1), rnd(K, N, seed=2, scale=0.1)     # dx = dy @ w  (w: (out=K, in=N) row-major)
+    act = torch.relu(rnd(M, N, seed=3))
+    out = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_raw(dev(dy), dev(w), out, M, N, K, K, 1, 1, N, N, gate=dev(act), gate_scale=2.0)
+    ref = (dy.double() @ w.double()) * 2.0 * (act > 0).double()
+    close(out, ref, 2e-5, "gate epilogue")
+    with pytest.raises(Exception):      # not combinable with accumulation / split-K
+        ops.gemm_raw(dev(dy), dev(w), out, M, N, K, K, 1, 1, N, N, gate=dev(act), accumulate=True)
+
+
 def test_gemm_argument_errors(ops):
     x = torch.zeros(4, 4, device="cuda")
     import ick_amd.lib as L
