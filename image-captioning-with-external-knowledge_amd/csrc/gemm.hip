@@ -221,7 +221,8 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
     const RowMap bmap{0, 0, nullptr, p.b_rs};
     SA sa; SB sb;
     sa.init(p.A, amap, p.a_ks, m0, p.M, p.a_extent);
-    sb.init(p.B, bmap, p.b_ks, n0, p.N, p.b_extent);
+    const bool only = (p.flags & ICK_GEMM_COLSUM_ONLY) != 0;   // uniform: column sums of A, no product
+    sb.init(only ? p.A : p.B, bmap, p.b_ks, n0, p.N, p.b_extent);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -240,9 +241,11 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
     // in register set (i+1)&1 and is written to the other LDS buffer after the MFMAs of slice i, slice i+2
     // is requested into register set i&1 before them -- every global load has two MFMA phases to land.
     if (nk > 0) {
-        sa.template load<0>(kbeg, kend); sb.template load<0>(kbeg, kend);
-        if (nk > 1) { sa.template load<1>(kbeg + BK, kend); sb.template load<1>(kbeg + BK, kend); }
-        sa.template store<0>(smem, kbeg, kend); sb.template store<0>(smem + SA::FLOATS, kbeg, kend);
+        sa.template load<0>(kbeg, kend);
+        if (!only) sb.template load<0>(kbeg, kend);
+        if (nk > 1) { sa.template load<1>(kbeg + BK, kend); if (!only) sb.template load<1>(kbeg + BK, kend); }
+        sa.template store<0>(smem, kbeg, kend);
+        if (!only) sb.template store<0>(smem + SA::FLOATS, kbeg, kend);
     }
     __syncthreads();
     auto phase = [&](int it, auto cur) {
@@ -250,8 +253,8 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
         const float* As = smem + CUR * STAGE;
         const float* Bs = As + SA::FLOATS;
         const int k0 = kbeg + it * BK;
-        if (it + 2 < nk) { sa.template load<CUR>(k0 + 2 * BK, kend); sb.template load<CUR>(k0 + 2 * BK, kend); }
-        const int nchunk = min(BK / 16, (kend - k0 + 15) >> 4);
+        if (it + 2 < nk) { sa.template load<CUR>(k0 + 2 * BK, kend); if (!only) sb.template load<CUR>(k0 + 2 * BK, kend); }
+        const int nchunk = only ? 0 : min(BK / 16, (kend - k0 + 15) >> 4);
         for (int t = 0; t < nchunk; ++t) {
             float af[TM][4], bf[TN][4];
 #pragma unroll
@@ -276,7 +279,8 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
         }
         if (it + 1 < nk) {
             float* An = smem + NXT * STAGE;
-            sa.template store<NXT>(An, k0 + BK, kend); sb.template store<NXT>(An + SA::FLOATS, k0 + BK, kend);
+            sa.template store<NXT>(An, k0 + BK, kend);
+            if (!only) sb.template store<NXT>(An + SA::FLOATS, k0 + BK, kend);
         }
         __syncthreads();
     };
@@ -286,6 +290,7 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
     }
 
     if (colsum && threadIdx.x < BM && m0 + (int)threadIdx.x < p.M) atomicAdd(p.colsum_a + m0 + threadIdx.x, csum);
+    if (only) return;
 
     // Epilogue.  C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.
     const bool hs = p.hs_dh > 0;
@@ -423,6 +428,14 @@ int make_plan(const ick_gemm_args* in, Plan& pl) {
     if (!in) return ICK_EINVAL;
     ick_gemm_args& a = pl.a;
     a = *in;
+    if (a.flags & ICK_GEMM_COLSUM_ONLY) {
+        // colsum_a[m] += sum_k A(m,k) and nothing else: B / C / N are ignored (one tile column, no product)
+        ICK_CHECK_ARG(a.A && a.colsum_a && a.M > 0 && a.K > 0);
+        a.B = a.A; a.C = a.colsum_a; a.bias = nullptr; a.gate = nullptr;
+        a.N = 1; a.b_rs = 1; a.b_ks = a.a_ks; a.c_rs = 1; a.c_grp = 0; a.hs_dh = 0; a.b_extent = a.a_extent;
+        a.drop_p = 0.f;
+        a.flags = ICK_GEMM_COLSUM_ONLY | ICK_GEMM_ATOMIC;
+    }
     ICK_CHECK_ARG(a.A && a.B && a.C);
     ICK_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0);
     const bool akm = a.a_rs == 1 && a.a_ks != 1, bkm = a.b_rs == 1 && a.b_ks != 1;
@@ -447,7 +460,8 @@ int make_plan(const ick_gemm_args* in, Plan& pl) {
     } else {
         avec = aligned16(a.A) && a.a_rs % 4 == 0 && a.K % 4 == 0 && (a.a_grp == 0 || a.a_gs % 4 == 0);
     }
-    if (bkm) bvec = aligned16(a.B) && a.b_ks % 4 == 0 && a.N % 4 == 0;
+    if (a.flags & ICK_GEMM_COLSUM_ONLY) bvec = true;
+    else if (bkm) bvec = aligned16(a.B) && a.b_ks % 4 == 0 && a.N % 4 == 0;
     else bvec = aligned16(a.B) && a.b_rs % 4 == 0 && a.K % 4 == 0;
     // operand extents (elements addressable from the base pointer) bound the buffer descriptors of the vector
     // path; without a group map they follow from the strides, with one the caller must state them

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_PKG, "libick_amd.so")
 
 ICK_GEO, ICK_KNOWLEDGE, ICK_NEWS = 0, 1, 2
 VARIANT_ID = {"geo": ICK_GEO, "knowledge": ICK_KNOWLEDGE, "news": ICK_NEWS}
-GEMM_RELU, GEMM_ACCUM, GEMM_ATOMIC = 1, 2, 4
+GEMM_RELU, GEMM_ACCUM, GEMM_ATOMIC, GEMM_COLSUM_ONLY = 1, 2, 4, 16
 
 vp = C.c_void_p
 i32 = C.c_int32
@@ -90,6 +90,7 @@ SIGNATURES = {
     "ick_context_gate_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "ick_adam_clamp": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, i32, vp, vp, vp],
     "ick_counter_add": [vp, u32, vp],
+    "ick_timestamp": [vp, vp],
     "ick_scale_by_ratio": [vp, i64, vp, vp, vp],
 }
 

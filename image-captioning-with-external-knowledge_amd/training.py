@@ -97,6 +97,7 @@ def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds, side=None):
     t["qc"] = ops.project_heads(t["x1"], ca_w[:d], ca_b[:d], 1, H, T)
     t["ca"] = torch.empty_like(x)
     t["lse_c"] = torch.empty(B * H * T, device=x.device, dtype=torch.float32)
+    ops.stamp("fwd: layer %d reaches cross-attention" % li)
     if side is not None:
         side.join()    # the context rows of kv (and of the saved memory) come from the side stream
     ops.attention_heads(t["qc"], kv, t["ca"], H, dh, T, S, 0, 2 * li, 2 * li + 1, lse=t["lse_c"], drop=t["d_ca"])
@@ -151,6 +152,7 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         tape.enc_layers["facts"] = []
 
     def context_chain():
+        ops.stamp("side: context chain starts")
         ctx_e = _context_encoder_fwd(dec, dec.transformer_encoder_entities, ee, tape.enc_layers["entities"], ds)
         mem[:, P:P + K].copy_(ctx_e)
         ops.project_heads(ctx_e, wkv, bkv, nseg, H, S, out=kv, s0=P, grp=K)
@@ -158,17 +160,22 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
             ctx_f = _context_encoder_fwd(dec, dec.transformer_encoder_facts, fe, tape.enc_layers["facts"], ds)
             mem[:, P + K:].copy_(ctx_f)
             ops.project_heads(ctx_f, wkv, bkv, nseg, H, S, out=kv, s0=P + K, grp=Fn)
+        ops.stamp("side: context chain done")
 
     side = ops.SideStream(priority=-1) if overlap else None
+    img = enc_tok.index_select(0, gmap.long()) if gmap is not None else enc_tok
     if side is not None:
-        side.submit(context_chain, ee, fe, mem, kv, wkv, bkv)
+        side.submit(context_chain, ee, fe, mem, kv, wkv, bkv, img)
     else:
         context_chain()
-    img = enc_tok.index_select(0, gmap.long()) if gmap is not None else enc_tok
     mem[:, :P].copy_(img)
     if side is not None:
         side.flush()     # enqueued after the main stream's next kernel (see SideStream)
+    # One GEMM for the image rows of every layer.  Projecting the later layers' rows on the side stream after the
+    # chain was measured (device time stamps): the chain ends 70 us earlier, the first decoder layer 90 us later --
+    # a 5000-workgroup GEMM beside a chain of small kernels delays the chain by about its own duration either way.
     ops.project_heads(img, wkv, bkv, nseg, H, S, out=kv, s0=0, grp=P)
+    ops.stamp("fwd: image K/V projection done")
     pe = dec.pos_encoder.pe.view(-1, d)
     m["d_pos"] = ds.site(dec.pos_encoder.dropout.p)
     x = ops.caption_embed(captions, caption_masks, _p(dec.word_embedding.weight), ee, fe, pe, V,
@@ -177,6 +184,7 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         x = _decoder_layer_fwd(dec, li, layer, x, kv, S, tape.dec_layers, ds, side=side if li == 0 else None)
     if side is not None:
         side.join()
+    ops.stamp("fwd: decoder layers done")
     eib = gate = hv = None
     if dec.has_facts:
         pred_wt = _p(dec.fc_predicate.weight).t().contiguous() if fresh_pack else dec._pred_wt()
@@ -359,9 +367,11 @@ def _backward_from_tape(dec, tape, dscores, grads):
     nseg = 2 * len(layers)
     dkv_rows = ops.attention_bwd_buffer((B, S, nseg * d), L, S, d // H, dev)
     dx = dh
+    ops.stamp("bwd: head done")
     for li in reversed(range(len(layers))):
         dx = _decoder_layer_bwd(dec, li, layers[li], tape.dec_layers[li], dx, dkv_rows, m["kv"], S, grads,
                                 mem2=m["mem"].view(B * S, d))
+        ops.stamp("bwd: decoder layer %d done" % li)
     # ---- cross K/V projection: the weight gradients went out with the decoder layers; data gradient for the
     # context rows only (the image rows' gradient would be Encoder.conv1's, which the reference never uses)
     nctx = K + Fn
@@ -371,8 +381,10 @@ def _backward_from_tape(dec, tape, dscores, grads):
     ops.gemm_raw(dkv_rows[:, P:], m["wkv"], dctx, B * nctx, d, nseg * d, nseg * d, 1, 1, d, d, a_grp=nctx,
                  a_gs=S * nseg * d, atomic=ksplit > 1, split_k=ksplit)
     # ---- context encoders
+    ops.stamp("bwd: context gradient ready")
     dee_enc = _context_encoder_bwd(dec, dec.transformer_encoder_entities, tape.enc_layers["entities"],
                                    dctx[:, :K].contiguous(), grads)
+    ops.stamp("bwd: entity context encoder done")
     dee += dee_enc
     if dec.has_facts:
         dfe_enc = _context_encoder_bwd(dec, dec.transformer_encoder_facts, tape.enc_layers["facts"],
@@ -472,22 +484,28 @@ class TrainStep:
     def _part_a(self, captions, caption_masks, entities, facts, enc_tok, gmap, decode_len):
         dec = self.dec
         self.flat_g.zero_()
+        ops.stamp("A: start")
         scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gmap,
                                          seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
                                          overlap=self.use_graph)
+        ops.stamp("fwd: scores done")
         loss_sum, count, dscores = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True)
+        ops.stamp("CE done")
         backward_from_tape(dec, tape, dscores, self.grads,
                            overlap=self.use_graph and not os.environ.get("ICK_NO_BWD_OVERLAP"))
         self.flat_g[self.n:self.n + 1].copy_(loss_sum)
         self.flat_g[self.n + 1:].copy_(count)
+        ops.stamp("A: end (after join)")
         return self.flat_g
 
     def _part_b(self):
         # divide by the global token count (device-resident), clamp, Adam with the device step counter
+        ops.stamp("B: start")
         ops.adam_clamp(self.flat_p, self.flat_g, self.flat_m, self.flat_v, 1, self.lr, self.clip, 1.0,
                        self.betas[0], self.betas[1], self.eps, step_tensor=self.counter,
                        gscale_den=self.flat_g[self.n + 1:])
         ops.counter_add(self.counter, 1)
+        ops.stamp("B: end")
         return self.flat_g
 
     def _capture(self, fn, inputs):

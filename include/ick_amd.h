@@ -78,6 +78,8 @@ typedef struct {
 #define ICK_GEMM_RELU 1
 #define ICK_GEMM_ACCUM 2
 #define ICK_GEMM_ATOMIC 4
+#define ICK_GEMM_COLSUM_ONLY 16   /* no product: colsum_a[m] += sum_k A(m,k) for a k-major A (B, C, N ignored) -- lets plain
+                                    column sums (LayerNorm gamma/beta partials) ride in an ick_gemm_grouped launch */
 
 int ick_gemm(const ick_gemm_args* args, void* stream);
 /* `count` (<= 64) independent problems; those that select the same kernel configuration share one launch (up to 8
@@ -272,6 +274,8 @@ int ick_adam_clamp(float* p, float* g, float* m, float* v, int64_t n, float gsca
                    const float* gscale_den, void* stream);
 /* *counter += inc on the stream (step / dropout-epoch counter of captured training graphs). */
 int ick_counter_add(uint32_t* counter, uint32_t inc, void* stream);
+/* Diagnostic: *out = device wall clock (100 MHz ticks) when the stream reaches this point. */
+int ick_timestamp(unsigned long long* out, void* stream);
 /* x *= num[0] / den[0] with device-resident scalars (token-mean normalisation without a host sync). */
 int ick_scale_by_ratio(float* x, int64_t n, const float* num, const float* den, void* stream);
 

@@ -122,7 +122,16 @@ def test_gemm_grouped_and_colsum_fusion(ops):
         problems.append(ops.gemm_args(ddy, dx_, dw, N, K, M, 1, N, 1, K, K, atomic=True,
                                       split_k=max(1, min(16, M // 256)), colsum_a=db))
         refs.append((dw, db, dw0.double() + dy.double().t() @ x.double(), db0.double() + dy.double().sum(0)))
+    # plain column sums (LayerNorm gamma / beta partials) ride in the same launch
+    part = rnd(160, 600, seed=77)
+    acc0 = rnd(600, seed=78)
+    dpart, dacc, dacc2 = dev(part), dev(acc0), dev(acc0)
+    problems.insert(3, ops.colsum_problem(dpart, dacc))
+    problems.append(ops.colsum_problem(dpart[:, 300:], dacc2[300:]))
     ops.gemm_grouped(problems)
+    close(dacc, acc0.double() + part.double().sum(0), 2e-5, "grouped column sum")
+    close(dacc2[300:], acc0[300:].double() + part[:, 300:].double().sum(0), 2e-5, "grouped column sum of a column slice")
+    assert torch.equal(dacc2[:300].cpu(), acc0[:300])
     for i, (dw, db, rw, rb) in enumerate(refs):
         close(dw, rw, 2e-4, "grouped dw %d" % i)
         close(db, rb, 2e-4, "grouped db %d" % i)

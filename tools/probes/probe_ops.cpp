@@ -88,6 +88,13 @@ int main(int argc, char** argv) {
     gemm_bwd("wgrad out-proj", 300, 300, 1280, true, 5);
     gemm_bwd("wgrad qkv", 900, 300, 1280, true, 5);
     gemm_bwd("wgrad vocab", 10000, 300, 1280, true, 5);
+    gemm_bwd("wgrad vocab s=1", 10000, 300, 1280, true, 1);
+    gemm_bwd("wgrad vocab s=2", 10000, 300, 1280, true, 2);
+    gemm_bwd("wgrad vocab s=3", 10000, 300, 1280, true, 3);
+    gemm_bwd("wgrad cross kv s=8", 600, 300, 13824, true, 8);
+    gemm_bwd("wgrad cross kv s=24", 600, 300, 13824, true, 24);
+    gemm_bwd("wgrad cross kv x3 s=8", 1800, 300, 13824, true, 8);
+    gemm_bwd("wgrad cross kv x3 s=16", 1800, 300, 13824, true, 16);
     gemm_bwd("wgrad cross kv", 600, 300, 13824, true, 16);
     // attention
     float* Q = A; float* KV = B; float* O = C;
