@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ick_attn_args p, int
 // backward
 // ---------------------------------------------------------------------------------------------
 template <int NQT, int MAXT>
-__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p, int SP) {
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p, int SP, bool st2) {
     constexpr int NQ = NQT * 16;
     constexpr int TLD = NQ + 4;          // row stride of the transposed Q / dO tiles ([col][query])
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -337,16 +337,28 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p,
                 dkt[jt] = mfma4(qt4, df, dkt[jt]);
             }
         }
-        // dV^T / dK^T tiles: lane <-> key, registers <-> columns 16 jt + 4 lq + r (4 consecutive floats of a row)
+        // dV^T / dK^T tiles: lane <-> key, registers <-> columns 16 jt + 4 lq + r (4 consecutive floats of a row):
+        // two 8-byte stores per tile where the layout allows (row-major gradients at even offsets), else scalars
         if (kok) {
             float* dvr = p.dV + (int64_t)b * p.dv_bs + (int64_t)key * p.dv_ss + h * dh;
             float* dkr = p.dK + (int64_t)b * p.dk_bs + (int64_t)key * p.dk_ss + h * dh;
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
                 const int j0 = 16 * jt + 4 * lq;
+                if (st2) {
+                    if (j0 + 1 < dh) {
+                        *reinterpret_cast<float2*>(dvr + j0) = make_float2(dvt[jt][0], dvt[jt][1]);
+                        *reinterpret_cast<float2*>(dkr + j0) = make_float2(dkt[jt][0], dkt[jt][1]);
+                    }
+                    if (j0 + 3 < dh) {
+                        *reinterpret_cast<float2*>(dvr + j0 + 2) = make_float2(dvt[jt][2], dvt[jt][3]);
+                        *reinterpret_cast<float2*>(dkr + j0 + 2) = make_float2(dkt[jt][2], dkt[jt][3]);
+                    }
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (j0 + r < dh) { dvr[j0 + r] = dvt[jt][r]; dkr[j0 + r] = dkt[jt][r]; }
+                    for (int r = 0; r < 4; ++r)
+                        if (j0 + r < dh) { dvr[j0 + r] = dvt[jt][r]; dkr[j0 + r] = dkt[jt][r]; }
+                }
             }
         }
     }
@@ -362,16 +374,22 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p,
         const bool jok = j < dh;
         const float* kc = kb + (jok ? j : 0);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-        for (int kt = 0; kt < nkt; ++kt) {
-            const float4 da = *reinterpret_cast<const float4*>(dSs + (16 * qt + li) * SP + 16 * kt + 4 * lq);
+        // all K values of this lane's column first (one round trip to L2 instead of one per pair of key tiles)
+        float4 kq[4 * MAXT];
+#pragma unroll
+        for (int kt = 0; kt < 4 * MAXT; ++kt) {
             const int k0 = 16 * kt + 4 * lq;
-            float4 kb4;
-            kb4.x = (jok && k0 + 0 < S) ? kc[(int64_t)(k0 + 0) * DHP] : 0.f;
-            kb4.y = (jok && k0 + 1 < S) ? kc[(int64_t)(k0 + 1) * DHP] : 0.f;
-            kb4.z = (jok && k0 + 2 < S) ? kc[(int64_t)(k0 + 2) * DHP] : 0.f;
-            kb4.w = (jok && k0 + 3 < S) ? kc[(int64_t)(k0 + 3) * DHP] : 0.f;
-            acc = mfma4(da, kb4, acc);
+            kq[kt].x = (jok && k0 + 0 < S) ? kc[(int64_t)(k0 + 0) * DHP] : 0.f;
+            kq[kt].y = (jok && k0 + 1 < S) ? kc[(int64_t)(k0 + 1) * DHP] : 0.f;
+            kq[kt].z = (jok && k0 + 2 < S) ? kc[(int64_t)(k0 + 2) * DHP] : 0.f;
+            kq[kt].w = (jok && k0 + 3 < S) ? kc[(int64_t)(k0 + 3) * DHP] : 0.f;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4 * MAXT; ++kt) {
+            if (kt < nkt) {
+                const float4 da = *reinterpret_cast<const float4*>(dSs + (16 * qt + li) * SP + 16 * kt + 4 * lq);
+                acc = mfma4(da, kq[kt], acc);
+            }
         }
         if (jok) {
 #pragma unroll
@@ -411,7 +429,10 @@ int launch_bwd(const ick_attn_bwd_args& a, int SP, hipStream_t s) {
     auto kern = attn_bwd_mfma_kernel<NQT, MAXT>;
     static bool attr = false;
     if (!attr) { if (int e = set_lds(kern, 160 * 1024)) return e; attr = true; }
-    hipLaunchKernelGGL(kern, dim3(a.H, a.B), dim3(256), fl * sizeof(float), s, a, SP);
+    // 8-byte stores of dK / dV: every (sample, key, head) row segment starts at an even float offset
+    const bool st2 = a.dh % 2 == 0 && a.dk_bs % 2 == 0 && a.dk_ss % 2 == 0 && a.dv_bs % 2 == 0 && a.dv_ss % 2 == 0 &&
+                     (reinterpret_cast<uintptr_t>(a.dK) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.dV) & 7) == 0;
+    hipLaunchKernelGGL(kern, dim3(a.H, a.B), dim3(256), fl * sizeof(float), s, a, SP, st2);
     ICK_LAUNCH_RET();
 }
 
@@ -431,9 +452,10 @@ int launch_attn_mfma(const ick_attn_args& a, hipStream_t s) {
         return kAttnMfmaUnsupported;
     const int SP = ((a.S + 15) / 16) * 16 + 4;
     const int nqt = (a.T + 15) / 16;
-    const bool small = a.S <= 256;
+    // key tiles per wave (compile time: register arrays): 1 for S <= 64 (self-attention), 4 up to 256, 8 up to 512
+    const int mt = a.S <= 64 ? 1 : (a.S <= 256 ? 4 : 8);
 #define ICK_FWD(N)                                                    \
-    case N: return small ? launch_fwd<N, 4>(a, SP, s) : launch_fwd<N, 8>(a, SP, s)
+    case N: return mt == 1 ? launch_fwd<N, 1>(a, SP, s) : (mt == 4 ? launch_fwd<N, 4>(a, SP, s) : launch_fwd<N, 8>(a, SP, s))
     switch (nqt) {
         ICK_FWD(1); ICK_FWD(2); ICK_FWD(3); ICK_FWD(4);
     }
@@ -444,13 +466,13 @@ int launch_attn_mfma(const ick_attn_args& a, hipStream_t s) {
 int launch_attn_bwd_mfma(const ick_attn_bwd_args& a, hipStream_t s) {
     if (!attn_mfma_shape_ok(a.T, a.S, a.dh)) return kAttnMfmaUnsupported;
     const int SP = ((a.S + 15) / 16) * 16 + 4;
-    const bool small = a.S <= 256;
+    const int mt = a.S <= 64 ? 1 : (a.S <= 256 ? 4 : 8);
+#define ICK_BWD(N)                                                    \
+    case N: return mt == 1 ? launch_bwd<N, 1>(a, SP, s) : (mt == 4 ? launch_bwd<N, 4>(a, SP, s) : launch_bwd<N, 8>(a, SP, s))
     switch ((a.T + 15) / 16) {
-        case 1: return small ? launch_bwd<1, 4>(a, SP, s) : launch_bwd<1, 8>(a, SP, s);
-        case 2: return small ? launch_bwd<2, 4>(a, SP, s) : launch_bwd<2, 8>(a, SP, s);
-        case 3: return small ? launch_bwd<3, 4>(a, SP, s) : launch_bwd<3, 8>(a, SP, s);
-        case 4: return small ? launch_bwd<4, 4>(a, SP, s) : launch_bwd<4, 8>(a, SP, s);
+        ICK_BWD(1); ICK_BWD(2); ICK_BWD(3); ICK_BWD(4);
     }
+#undef ICK_BWD
     return kAttnMfmaUnsupported;
 }
 
