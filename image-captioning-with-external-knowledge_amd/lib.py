@@ -109,6 +109,9 @@ def load():
             raise IckError(
                 "libick_amd.so is missing (%s): build it with `python -c 'import __graft_entry__ as g; g.build()'`"
                 " -- there is no fallback path" % LIB_PATH)
+        # torch first: PyTorch-ROCm ships its own libamdhip64; if ours were loaded before it, the process would hold
+        # two HIP runtimes and every launch from this library would fail with hipErrorNoDevice on torch's streams
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
