@@ -55,11 +55,21 @@ class _GraphedCall:
             self.static_out = fn(*self.static_in)
 
     def __call__(self, *inputs):
-        for dst, src in zip(self.static_in, inputs):
-            if dst is not None:
-                dst.copy_(src, non_blocking=True)
+        copy_inputs(self.static_in, inputs)
         self.graph.replay()
         return self.static_out
+
+
+def copy_inputs(static, inputs):
+    """Refresh a graph's input buffers: one foreach call instead of a Python-level copy_ per tensor (the host is
+    on the critical path here: forward() has just synchronised for the length sort)."""
+    dst = [d for d, s in zip(static, inputs) if d is not None]
+    src = [s for d, s in zip(static, inputs) if d is not None]
+    if all(s.is_cuda and s.shape == d.shape for d, s in zip(dst, src)):
+        torch._foreach_copy_(dst, src, non_blocking=True)
+    else:
+        for d, s in zip(dst, src):
+            d.copy_(s, non_blocking=True)
 
 
 class PositionEncoder(nn.Module):

@@ -554,9 +554,8 @@ class TrainStep:
                 t.copy_(sv)
         if self.use_graph:
             ga, static, gb = self._graphs[key]
-            for dst, src in zip(static, inputs):
-                if dst is not None:
-                    dst.copy_(src, non_blocking=True)
+            from .decoder import copy_inputs
+            copy_inputs(static, inputs)
             ga.replay()
             dp.allreduce_bucket(self.flat_g, self.pg)
             gb.replay()
