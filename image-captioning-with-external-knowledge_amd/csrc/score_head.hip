@@ -61,13 +61,25 @@ __device__ __forceinline__ void top2_push(Top2& s, float v, int i) {
         s.v2 = v; s.i2 = i;
     }
 }
-__global__ __launch_bounds__(256) void top2_kernel(const float* __restrict__ scores, int64_t ld, int Vx,
-                                                   int32_t* __restrict__ best, int32_t* __restrict__ second) {
-    __shared__ Top2 sh[256];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const float* r = scores + (int64_t)b * ld;
+// Top-2 of one score row by a 256-thread workgroup; the result is valid in thread 0 (sh[0]).  The row is read
+// eight elements per thread at a time (loads first, comparisons after: one memory round trip per batch instead of
+// one per element).
+__device__ __forceinline__ Top2 row_top2(const float* __restrict__ r, int Vx, Top2* sh) {
+    const int tid = threadIdx.x;
     Top2 s{-INFINITY, -INFINITY, 0x7fffffff, 0x7fffffff};
-    for (int i = tid; i < Vx; i += 256) top2_push(s, r[i], i);
+    for (int i0 = 0; i0 < Vx; i0 += 256 * 8) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = i0 + tid + 256 * j;
+            x[j] = i < Vx ? r[i] : -INFINITY;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = i0 + tid + 256 * j;
+            if (i < Vx) top2_push(s, x[j], i);
+        }
+    }
     sh[tid] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -80,20 +92,25 @@ __global__ __launch_bounds__(256) void top2_kernel(const float* __restrict__ sco
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        best[b] = sh[0].i1;
-        second[b] = sh[0].i2 == 0x7fffffff ? sh[0].i1 : sh[0].i2;
+    return sh[0];
+}
+
+__global__ __launch_bounds__(256) void top2_kernel(const float* __restrict__ scores, int64_t ld, int Vx,
+                                                   int32_t* __restrict__ best, int32_t* __restrict__ second) {
+    __shared__ Top2 sh[256];
+    const int b = blockIdx.x;
+    const Top2 t = row_top2(scores + (int64_t)b * ld, Vx, sh);
+    if (threadIdx.x == 0) {
+        best[b] = t.i1;
+        second[b] = t.i2 == 0x7fffffff ? t.i1 : t.i2;
     }
 }
 
-// predict()'s per-step bookkeeping for B independent captions (one lane per caption).
-__global__ void greedy_update_kernel(const int32_t* __restrict__ best, const int32_t* __restrict__ second,
-                                     int64_t* __restrict__ output, int32_t* __restrict__ hist,
-                                     int32_t* __restrict__ finished, int64_t* __restrict__ next_token,
-                                     int64_t* __restrict__ next_mask, int B, int step, int max_len, int V, int K,
-                                     int has_facts, int end_token) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+// predict()'s per-step bookkeeping for caption b (geo-aware/models.py:410-441), given the step's two best tokens.
+__device__ __forceinline__ void greedy_update_one(int b, int best_b, int second_b, int64_t* __restrict__ output,
+                                                  int32_t* __restrict__ hist, int32_t* __restrict__ finished,
+                                                  int64_t* __restrict__ next_token, int64_t* __restrict__ next_mask,
+                                                  int step, int max_len, int V, int K, int has_facts, int end_token) {
     if (finished[b]) {
         next_token[b] = 0;
         next_mask[b] = 0;
@@ -102,7 +119,7 @@ __global__ void greedy_update_kernel(const int32_t* __restrict__ best, const int
     int64_t* o = output + (int64_t)b * max_len;
     int32_t* hs = hist + (int64_t)b * max_len;
     const int i = step;
-    int64_t out = best[b];
+    int64_t out = best_b;
     o[i] = out;
     if (out == end_token) {
         finished[b] = 1;
@@ -110,7 +127,7 @@ __global__ void greedy_update_kernel(const int32_t* __restrict__ best, const int
         next_mask[b] = 0;
         return;
     }
-    hs[i] = second[b];
+    hs[i] = second_b;
     // repeated n-gram clean-up (geo-aware/models.py:421-435)
     for (int dupl = 0; dupl <= 4; dupl += 2) {
         if (i > dupl) {
@@ -129,6 +146,34 @@ __global__ void greedy_update_kernel(const int32_t* __restrict__ best, const int
         next_token[b] = out;
         next_mask[b] = (has_facts && out >= V + K) ? 2 : (out >= V ? 1 : 0);
     }
+}
+
+// One lane per caption (separate selection and bookkeeping: ick_top2 + ick_greedy_update).
+__global__ void greedy_update_kernel(const int32_t* __restrict__ best, const int32_t* __restrict__ second,
+                                     int64_t* __restrict__ output, int32_t* __restrict__ hist,
+                                     int32_t* __restrict__ finished, int64_t* __restrict__ next_token,
+                                     int64_t* __restrict__ next_mask, int B, int step, int max_len, int V, int K,
+                                     int has_facts, int end_token) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    greedy_update_one(b, best[b], second[b], output, hist, finished, next_token, next_mask, step, max_len, V, K,
+                      has_facts, end_token);
+}
+
+// Selection and bookkeeping of a greedy step in one launch: workgroup b scans caption b's score row, its thread 0
+// updates the caption's state (one launch less per token of the decode loop).
+__global__ __launch_bounds__(256) void greedy_select_kernel(const float* __restrict__ scores, int64_t ld, int Vx,
+                                                            int64_t* __restrict__ output, int32_t* __restrict__ hist,
+                                                            int32_t* __restrict__ finished,
+                                                            int64_t* __restrict__ next_token,
+                                                            int64_t* __restrict__ next_mask, int step, int max_len,
+                                                            int V, int K, int has_facts, int end_token) {
+    __shared__ Top2 sh[256];
+    const int b = blockIdx.x;
+    const Top2 t = row_top2(scores + (int64_t)b * ld, Vx, sh);
+    if (threadIdx.x == 0)
+        greedy_update_one(b, t.i1, t.i2 == 0x7fffffff ? t.i1 : t.i2, output, hist, finished, next_token, next_mask, step,
+                          max_len, V, K, has_facts, end_token);
 }
 
 // Packed cross entropy: one workgroup per (b, t) score row.
@@ -258,6 +303,18 @@ extern "C" int ick_greedy_update(const int32_t* best, const int32_t* second, int
     hipLaunchKernelGGL(greedy_update_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, best, second,
                        output, top2_hist, finished, next_token, next_mask, B, step, max_len, V, K, has_facts,
                        end_token);
+    ICK_LAUNCH_RET();
+}
+
+extern "C" int ick_greedy_select(const float* scores, int64_t ld, int32_t B, int32_t Vx, int64_t* output,
+                                 int32_t* top2_hist, int32_t* finished, int64_t* next_token, int64_t* next_mask,
+                                 int32_t step, int32_t max_len, int32_t V, int32_t K, int32_t has_facts,
+                                 int32_t end_token, void* stream) {
+    using namespace ick;
+    ICK_CHECK_ARG(scores && output && top2_hist && finished && next_token && next_mask);
+    ICK_CHECK_ARG(B > 0 && Vx > 0 && ld >= Vx && step >= 0 && step < max_len);
+    hipLaunchKernelGGL(greedy_select_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, scores, ld, Vx, output,
+                       top2_hist, finished, next_token, next_mask, step, max_len, V, K, has_facts, end_token);
     ICK_LAUNCH_RET();
 }
 

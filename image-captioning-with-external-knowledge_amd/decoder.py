@@ -486,8 +486,7 @@ class DecoderTransformer(nn.Module):
                 eib, gate = ops.context_indicators(cap_buf, facts, K, V, self._pred_wt(),
                                                    self.fc_predicate.bias.detach(), mode=1)
             self._score_head(x, ee, fe, eib, gate, out=scores)
-            best, second = ops.top2(scores.view(B, -1))
-            ops.greedy_update(best, second, output, hist, finished, tok.view(-1), msk.view(-1), i, V, K,
+            ops.greedy_select(scores.view(B, -1), output, hist, finished, tok.view(-1), msk.view(-1), i, V, K,
                               self.has_facts, self.word_map["<end>"])
             if self.has_facts and i + 1 < max_pred_len:
                 cap_buf[:, i + 1] = tok.view(-1)

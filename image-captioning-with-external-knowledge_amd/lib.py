@@ -75,6 +75,7 @@ SIGNATURES = {
     "ick_dropout_mask": [vp, i64, i32, f32, u32, u32, vp],
     "ick_top2": [vp, i64, i32, i32, vp, vp, vp],
     "ick_greedy_update": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "ick_greedy_select": [vp, i64, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "ick_packed_ce": [vp, i64, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "ick_attention_bwd": [C.POINTER(AttnBwdArgs), vp],
     "ick_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, f32, u32, u32, vp, vp, vp],

@@ -292,6 +292,14 @@ def top2(scores):
     return best, second
 
 
+def greedy_select(scores, output, hist, finished, next_token, next_mask, step, V, K, has_facts, end_token):
+    """top2 + greedy_update of one decode step in one launch; scores (B, Vx) rows."""
+    B, Vx = scores.shape
+    L.check(L.load().ick_greedy_select(_p(scores), scores.stride(0), B, Vx, _p(output), _p(hist), _p(finished),
+                                       _p(next_token), _p(next_mask), step, output.shape[1], V, K, int(has_facts),
+                                       end_token, _stream()), "ick_greedy_select")
+
+
 def greedy_update(best, second, output, hist, finished, next_token, next_mask, step, V, K, has_facts, end_token):
     B, max_len = output.shape
     L.check(L.load().ick_greedy_update(_p(best), _p(second), _p(output), _p(hist), _p(finished), _p(next_token),

@@ -192,6 +192,10 @@ int ick_greedy_update(const int32_t* best, const int32_t* second, int64_t* outpu
                       int32_t* finished, int64_t* next_token, int64_t* next_mask, int32_t B,
                       int32_t step, int32_t max_len, int32_t V, int32_t K, int32_t has_facts,
                       int32_t end_token, void* stream);
+/* ick_top2 + ick_greedy_update in one launch (one workgroup per caption): the per-token selection of predict(). */
+int ick_greedy_select(const float* scores, int64_t ld, int32_t B, int32_t Vx, int64_t* output, int32_t* top2_hist,
+                      int32_t* finished, int64_t* next_token, int64_t* next_mask, int32_t step, int32_t max_len,
+                      int32_t V, int32_t K, int32_t has_facts, int32_t end_token, void* stream);
 
 /* fused token-mean cross entropy over the packed rows of train.py
  * (pack_padded_sequence + CrossEntropyLoss(ignore_index=<pad>), geo-aware/train.py:275-281):

@@ -406,6 +406,29 @@ def test_top2_and_ties(ops):
             assert (best[b].item(), second[b].item()) == (tk[b, 0].item(), tk[b, 1].item())
 
 
+def test_greedy_select_equals_top2_plus_update(ops):
+    """The fused per-token kernel == ick_top2 followed by ick_greedy_update, over a scripted decode (repeats that
+    trigger the n-gram clean-up, an <end>, ties broken towards the lower index)."""
+    V, K, max_len, end = 50, 6, 12, 49
+    B, Vx = 5, V + K
+    g = torch.Generator().manual_seed(3)
+    state = [[torch.zeros(B, max_len, dtype=torch.long, device="cuda"), torch.zeros(B, max_len, dtype=torch.int32, device="cuda"),
+              torch.zeros(B, dtype=torch.int32, device="cuda"), torch.zeros(B, dtype=torch.long, device="cuda"),
+              torch.zeros(B, dtype=torch.long, device="cuda")] for _ in range(2)]
+    for i in range(max_len):
+        scores = torch.randn(B, Vx, generator=g)
+        scores[0, 7] = 9.0                       # caption 0 repeats token 7 (1-gram clean-up)
+        scores[1, 3 + (i % 2)] = 9.0             # caption 1 alternates 3, 4 (2-gram clean-up)
+        scores[2, end if i == 4 else 11] = 9.0   # caption 2 ends at step 4
+        scores[3, 20] = scores[3, 21] = 8.0      # caption 3: exact tie -> lower index wins, other is second
+        d = dev(scores)
+        best, second = ops.top2(d)
+        ops.greedy_update(best, second, *state[0], i, V, K, False, end)
+        ops.greedy_select(d, *state[1], i, V, K, False, end)
+        for a, b in zip(state[0], state[1]):
+            assert torch.equal(a, b), "step %d" % i
+
+
 def test_greedy_update_matches_reference_cleanup(ops):
     # drive the device bookkeeping with scripted (best, second) streams and compare with the oracle's loop
     V, K, max_len, end = 50, 6, 14, 49
