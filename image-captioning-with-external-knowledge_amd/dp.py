@@ -33,11 +33,13 @@ def shard(batch_size, rank, world):
     return lo, min(batch_size, lo + per)
 
 
-def allreduce_bucket(flat, group=None):
-    """Sum the flat gradient bucket (with its trailing [loss_sum, count]) over all ranks, in place."""
+def allreduce_bucket(flat, group=None, async_op=False):
+    """Sum (a slice of) the flat gradient bucket over all ranks, in place.  async_op: returns the work handle
+    (None for a single process) so that the caller can enqueue more device work before waiting."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    return flat
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        return work if async_op else flat
+    return None if async_op else flat
 
 
 def normalise_bucket(flat, n):

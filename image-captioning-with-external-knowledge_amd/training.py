@@ -312,17 +312,60 @@ def backward_from_tape(dec, tape, dscores, grads, overlap=True):
     """Accumulate parameter gradients of `dec` into `grads` (dict id(param) -> zero-initialised
     tensor shaped like the parameter; frozen parameters are simply absent).  With `overlap` the weight /
     bias gradients of the Linear layers run on a second HIP stream beside the data-gradient chain."""
-    side = ops.SideStream() if overlap else None
-    ops.SIDE = side
-    try:
-        _backward_from_tape(dec, tape, dscores, grads)
-    finally:
-        ops.SIDE = None
-        if side is not None:
-            side.join()
+    bp = BackwardPass(dec, tape, dscores, grads, overlap)
+    bp.early(join=False)     # one pass: the side stream is only joined at the very end
+    bp.late()
 
 
-def _backward_from_tape(dec, tape, dscores, grads):
+def early_parameters(dec):
+    """Parameters whose gradients are complete after BackwardPass.early(): the score head and the decoder stack
+    (54 % of the geo model's bytes).  The rest -- context encoders, embeddings -- completes in late()."""
+    mods = [dec.fc_vocab, dec.fc_entity, dec.transformer_decoder]
+    for name in ("fc_fact", "fc_predicate"):
+        if getattr(dec, name, None) is not None:
+            mods.append(getattr(dec, name))
+    seen, out = set(), []
+    for mod in mods:
+        for prm in mod.parameters():
+            if id(prm) not in seen:
+                seen.add(id(prm))
+                out.append(prm)
+    return out
+
+
+class BackwardPass:
+    """The backward pass in two phases, so that a data-parallel step can start reducing the first half of the
+    gradient bucket while the second half is still being computed (TrainStep with more than one rank):
+    early() = score head + decoder stack, with the side stream joined at its end; late() = context encoders and
+    embeddings.  The two phases may be captured into two hipGraphs."""
+
+    def __init__(self, dec, tape, dscores, grads, overlap=True):
+        self.side = ops.SideStream() if overlap else None
+        self.gen = _backward_phases(dec, tape, dscores, grads)
+
+    def _run(self, join):
+        ops.SIDE = self.side
+        try:
+            next(self.gen, None)
+        finally:
+            ops.SIDE = None
+            if self.side is not None and join:
+                self.side.join()
+
+    def early(self, join=True):
+        self._run(join)
+        self.joined = join
+
+    def late(self):
+        if self.side is not None and getattr(self, "joined", False):
+            # the two phases may be captured into two graphs: each graph gets a side stream of its own (one stream
+            # object forked into two captures made every kernel of both graphs run ~2.5x slower on ROCm 7.2)
+            self.retired = self.side          # keeps the tensors the first phase's side work read alive
+            self.side = ops.SideStream()
+        self._run(True)
+
+
+def _backward_phases(dec, tape, dscores, grads):
     m = tape.misc
     d, V, H = dec.emb_dim, dec.vocab_size, dec.num_heads
     h, ee, fe = m["h"], m["ee"], m["fe"]
@@ -372,6 +415,7 @@ def _backward_from_tape(dec, tape, dscores, grads):
         dx = _decoder_layer_bwd(dec, li, layers[li], tape.dec_layers[li], dx, dkv_rows, m["kv"], S, grads,
                                 mem2=m["mem"].view(B * S, d))
         ops.stamp("bwd: decoder layer %d done" % li)
+    yield    # ---- end of the early phase: every gradient of early_parameters() has been enqueued
     # ---- cross K/V projection: the weight gradients went out with the decoder layers; data gradient for the
     # context rows only (the image rows' gradient would be Encoder.conv1's, which the reference never uses)
     nctx = K + Fn
@@ -458,11 +502,19 @@ class TrainStep:
         self.use_graph = use_graph
         self.step_count = 0
         params = [p for p in unique_parameters(decoder) if p.requires_grad]
+        # bucket order: the parameters whose gradients are complete first come first, so that with several ranks
+        # their part of the bucket can be all-reduced while the rest of the backward pass still runs
+        early_ids = {id(p) for p in early_parameters(decoder)}
+        params = [p for p in params if id(p) in early_ids] + [p for p in params if id(p) not in early_ids]
         dev = params[0].device
-        n = sum(p.numel() for p in params)
+        # every parameter starts at a multiple of 64 floats (256 bytes): the GEMM's 16-byte vector loads need aligned
+        # weight rows, and one odd-sized parameter (fc_entity.bias has a single element) would misalign all that follow
+        pad = lambda k: (k + 63) // 64 * 64     # noqa: E731
+        n = sum(pad(p.numel()) for p in params)
         self.n = n
+        self.n_early = sum(pad(p.numel()) for p in params if id(p) in early_ids)
         # +2 trailing floats travel with the gradient bucket: [sum of token losses, token count]
-        self.flat_p = torch.empty(n, device=dev, dtype=torch.float32)
+        self.flat_p = torch.zeros(n, device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros(n + 2, device=dev, dtype=torch.float32)
         self.flat_m = torch.zeros(n, device=dev, dtype=torch.float32)
         self.flat_v = torch.zeros(n, device=dev, dtype=torch.float32)
@@ -476,9 +528,14 @@ class TrainStep:
                 self.flat_p[off:off + k].copy_(p.reshape(-1))
                 p.data = self.flat_p[off:off + k].view(p.shape)      # parameters become views of the bucket
                 self.grads[id(p)] = self.flat_g[off:off + k].view(p.shape)
-                off += k
+                off += pad(k)
         self.params = params
         self._graphs = {}
+        # ICK_SPLIT_ALLREDUCE=1: the step as two graphs around two all-reduces (the early half of the bucket travels
+        # while the late half is computed).  Measured on one GPU the split itself costs ~130 us (a join in the middle
+        # of the backward pass, one more graph launch) and hides ~half of the collective, so it pays off only when
+        # the 46 MB all-reduce takes more than ~0.3 ms; off until that is measured on a multi-GPU node.
+        self.split = os.environ.get("ICK_SPLIT_ALLREDUCE", "0") != "0"
 
     # ---- device-only halves -------------------------------------------------------------------
     def _part_a(self, captions, caption_masks, entities, facts, enc_tok, gmap, decode_len):
@@ -496,6 +553,25 @@ class TrainStep:
         self.flat_g[self.n:self.n + 1].copy_(loss_sum)
         self.flat_g[self.n + 1:].copy_(count)
         ops.stamp("A: end (after join)")
+        return self.flat_g
+
+    # ---- the same step in two halves (several ranks: the early half's all-reduce overlaps the late half) ----
+    def _part_a1(self, captions, caption_masks, entities, facts, enc_tok, gmap, decode_len):
+        dec = self.dec
+        self.flat_g.zero_()
+        scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gmap,
+                                         seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
+                                         overlap=self.use_graph)
+        self._loss = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True)
+        self._bp = BackwardPass(dec, tape, self._loss[2], self.grads,
+                                overlap=self.use_graph and not os.environ.get("ICK_NO_BWD_OVERLAP"))
+        self._bp.early(join=True)
+        return self.flat_g
+
+    def _part_a2(self):
+        self._bp.late()
+        self.flat_g[self.n:self.n + 1].copy_(self._loss[0])
+        self.flat_g[self.n + 1:].copy_(self._loss[1])
         return self.flat_g
 
     def _part_b(self):
@@ -522,6 +598,23 @@ class TrainStep:
             fn(*static)
         return g, static
 
+    def _capture_split(self, inputs):
+        """Graphs A1 (forward, CE, early backward) and A2 (late backward) over one memory pool: A2 reads what A1 left
+        in the tape."""
+        static = [None if t is None else t.contiguous().clone() for t in inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._part_a1(*static)
+            self._part_a2()
+        torch.cuda.current_stream().wait_stream(side)
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+            self._part_a1(*static)
+        with torch.cuda.graph(g2, capture_error_mode="thread_local"):   # own pool: the tape keeps A1's tensors alive
+            self._part_a2()
+        return g1, static, g2
+
     def __call__(self, captions, encoder_out, caption_masks, caption_lengths, entities, facts=None):
         dec = self.dec
         encoder_out, entities, facts = dec._prepare_inputs(encoder_out, entities, facts)
@@ -542,9 +635,13 @@ class TrainStep:
             state = (self.flat_p, self.flat_m, self.flat_v, self.counter)
             snap = [t.clone() for t in state]
             try:
-                ga, static = self._capture(self._part_a, inputs)
+                if self.split:
+                    ga, static, ga2 = self._capture_split(inputs)
+                else:
+                    ga, static = self._capture(self._part_a, inputs)
+                    ga2 = None
                 gb, _ = self._capture(self._part_b, [])
-                self._graphs[key] = (ga, static, gb)
+                self._graphs[key] = (ga, static, gb, ga2)
             except RuntimeError as e:   # capture refused (driver / collective library state): run eagerly
                 import warnings
                 warnings.warn("ick_amd TrainStep: hipGraph capture failed (%s); continuing without graphs" % e)
@@ -553,12 +650,30 @@ class TrainStep:
             for t, sv in zip(state, snap):
                 t.copy_(sv)
         if self.use_graph:
-            ga, static, gb = self._graphs[key]
+            ga, static, gb, ga2 = self._graphs[key]
             from .decoder import copy_inputs
             copy_inputs(static, inputs)
             ga.replay()
-            dp.allreduce_bucket(self.flat_g, self.pg)
+            if ga2 is None:
+                dp.allreduce_bucket(self.flat_g, self.pg)
+            else:
+                # [early gradients] travel while graph A2 computes [late gradients | loss_sum, count]
+                w1 = dp.allreduce_bucket(self.flat_g[:self.n_early], self.pg, async_op=True)
+                ga2.replay()
+                w2 = dp.allreduce_bucket(self.flat_g[self.n_early:], self.pg, async_op=True)
+                for w in (w1, w2):
+                    if w is not None:
+                        w.wait()
             gb.replay()
+        elif self.split:
+            self._part_a1(*inputs)
+            w1 = dp.allreduce_bucket(self.flat_g[:self.n_early], self.pg, async_op=True)
+            self._part_a2()
+            w2 = dp.allreduce_bucket(self.flat_g[self.n_early:], self.pg, async_op=True)
+            for w in (w1, w2):
+                if w is not None:
+                    w.wait()
+            self._part_b()
         else:
             self._part_a(*inputs)
             dp.allreduce_bucket(self.flat_g, self.pg)

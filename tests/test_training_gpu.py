@@ -371,6 +371,34 @@ def test_train_step_matches_reference_sequence_and_dp_split():
     assert err < 1e-4 * max(1.0, full.flat_g[:full.n].abs().max().item()), err
 
 
+def test_train_step_split_allreduce_path_equals_single_graph(monkeypatch):
+    """With several ranks TrainStep captures the step as two graphs (early / late gradients) around two all-reduces;
+    forced on here with one rank: same loss, same gradients, same update as the single-graph step, for two steps."""
+    from ick_amd.training import TrainStep, early_parameters
+    variant, B, L, K, V, Fn, seed = "knowledge", 6, 9, 5, 120, 4, 7
+    P = synth.make_params(variant, V, seed)
+    batch = synth.make_batch(variant, B, L, K, V, Fn, seed)
+    enc_out = synth.make_enc_out(B, seed)
+    args = (batch["captions"].cuda(), enc_out.cuda(), batch["caption_masks"].cuda(), batch["caption_lengths"].cuda(),
+            batch["entities"], batch["facts"].cuda())
+    steps = []
+    for split in ("0", "1"):
+        monkeypatch.setenv("ICK_SPLIT_ALLREDUCE", split)
+        dec = zero_dropout(build_decoder(variant, V, P).train())
+        ts = TrainStep(dec, lr=4e-4, grad_clip=5.0)
+        assert ts.split == (split == "1")
+        n_early = sum((p.numel() + 63) // 64 * 64 for p in early_parameters(dec))   # 256-byte aligned slots
+        assert ts.n_early == n_early and 0 < n_early < ts.n
+        losses = [ts(*args).item() for _ in range(2)]
+        steps.append((losses, ts.flat_g[:ts.n].clone(), ts.flat_p.clone()))
+    (l0, g0, p0), (l1, g1, p1) = steps
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < 1e-5
+    assert (g0 - g1).abs().max().item() < 1e-5 * max(1.0, g0.abs().max().item())
+    # Adam divides by sqrt(v): where a gradient is rounding noise of the float atomics (1e-9), the two runs may step
+    # in different directions by up to lr; anywhere else the updates agree
+    assert ((p0 - p1).abs() > 5e-5).float().mean().item() < 1e-3
+
+
 def test_bench_two_ranks_share_the_gpu_over_gloo():
     """The driver's multi-GPU launch line, rehearsed with two ranks on the one GPU of this box (collectives
     over gloo instead of RCCL): rendezvous, per-rank shards, the bucket all-reduce inside the timed loop and
