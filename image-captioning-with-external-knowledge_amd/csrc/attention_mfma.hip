@@ -19,6 +19,8 @@
 // backward  S = Q K^T, dP = dO V^T   (A = Q / dO rows from LDS, B = K / V rows from global) -> lane <-> key
 //           dV^T = dO^T P, dK^T = Q^T dS (A = dO^T / Q^T from LDS, B = the P / dS registers)
 //           dS goes to LDS once ([query][key]); dQ = dS K with A = dS rows from LDS, B = K columns from global (L2).
+#include <algorithm>
+
 #include "attention_mfma.h"
 
 namespace ick {
@@ -75,10 +77,10 @@ template <int NQT, int MAXT>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ick_attn_args p, int SP) {
     constexpr int NQ = NQT * 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Vt = smem;                    // DHP * SP      V^T: [col][key]
-    float* Qs = Vt + DHP * SP;           // NQ * QLD      Q rows (zero padded)
-    float* Ored = Qs + NQ * QLD;         // 4 waves * NQT * 2 tiles * 256
-    float* red = Ored + 4 * NQT * 2 * 256;   // 4 * NQ   per-wave row statistics
+    float* Vt = smem;                    // max(DHP * SP, 4 waves * NQT * 2 tiles * 256)   V^T: [col][key]
+    float* Ored = smem;                  // the partial output tiles reuse V^T's space once every wave is done with it
+    float* Qs = Vt + max(DHP * SP, 4 * NQT * 2 * 256);   // NQ * QLD      Q rows (zero padded)
+    float* red = Qs + NQ * QLD;          // 4 * NQ       per-wave row statistics
     float* stat = red + 4 * NQ;          // 2 * NQ       final max / 1/sum
 
     const int h = blockIdx.x, b = blockIdx.y;
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ick_attn_args p, int
         sum[qt] = s;
     }
     // O^T partial sums over this wave's keys: lane <-> query, registers <-> columns 16 jt + 4 lq + r
+    f32x4 oacc[NQT][2];
 #pragma unroll
     for (int qt = 0; qt < NQT; ++qt) {
 #pragma unroll
@@ -186,11 +189,16 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ick_attn_args p, int
                     acc = mfma4(vt, pf, acc);
                 }
             }
-            *reinterpret_cast<f32x4*>(Ored + ((wave * NQT + qt) * 2 + jt) * 256 + lane * 4) = acc;
+            oacc[qt][jt] = acc;
         }
         if (lq == 0) red[wave * NQ + 16 * qt + li] = sum[qt];
     }
-    __syncthreads();
+    __syncthreads();     // every wave is done reading V^T: its space now takes the partial tiles
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+            *reinterpret_cast<f32x4*>(Ored + ((wave * NQT + qt) * 2 + jt) * 256 + lane * 4) = oacc[qt][jt];
     if (tid < NQ) {
         const float s = (red[tid] + red[NQ + tid]) + (red[2 * NQ + tid] + red[3 * NQ + tid]);
         stat[NQ + tid] = s > 0.f ? 1.f / s : 0.f;
@@ -223,8 +231,12 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p,
     constexpr int NQ = NQT * 16;
     constexpr int TLD = NQ + 4;          // row stride of the transposed Q / dO tiles ([col][query])
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* dSs = smem;                   // NQ * SP      dS: [query][key]
-    float* Qs = dSs + NQ * SP;           // NQ * QLD
+    // dS: [query][key], rows for the T real queries only (16-row padding would cost 12 x SP floats = the third or
+    // fourth workgroup per CU); the dQ phase reads "rows" T..NQ-1 out of whatever follows -- they only feed output
+    // rows that are never stored
+    const int TR = (p.T + 3) & ~3;
+    float* dSs = smem;                   // TR * SP
+    float* Qs = dSs + TR * SP;           // NQ * QLD
     float* Gs = Qs + NQ * QLD;           // NQ * QLD     dO rows
     float* Qt = Gs + NQ * QLD;           // DHP * TLD
     float* Gt = Qt + DHP * TLD;          // DHP * TLD
@@ -325,7 +337,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p,
                 if (drop.on()) mk = drop.mask((uint32_t)((b * p.H + h) * T + query) * (uint32_t)S + (uint32_t)key);
                 ds[r] = pr * (dp[r] * mk - dr[r]) * p.scale;
                 pd[r] = pr * mk;
-                dSs[query * SP + key] = ds[r];
+                if (query < T) dSs[query * SP + key] = ds[r];
             }
             const float4 pf = make_float4(pd[0], pd[1], pd[2], pd[3]);
             const float4 df = make_float4(ds[0], ds[1], ds[2], ds[3]);
@@ -412,7 +424,7 @@ int set_lds(K kern, size_t bytes) {
 
 template <int NQT, int MAXT>
 int launch_fwd(const ick_attn_args& a, int SP, hipStream_t s) {
-    const size_t fl = (size_t)DHP * SP + (size_t)NQT * 16 * QLD + 4 * NQT * 2 * 256 + 6 * NQT * 16;
+    const size_t fl = std::max<size_t>((size_t)DHP * SP, 4 * NQT * 2 * 256) + (size_t)NQT * 16 * QLD + 6 * NQT * 16;
     if (fl * sizeof(float) > 150 * 1024) return kAttnMfmaUnsupported;
     auto kern = attn_fwd_mfma_kernel<NQT, MAXT>;
     static bool attr = false;
@@ -424,7 +436,9 @@ int launch_fwd(const ick_attn_args& a, int SP, hipStream_t s) {
 template <int NQT, int MAXT>
 int launch_bwd(const ick_attn_bwd_args& a, int SP, hipStream_t s) {
     constexpr int NQ = NQT * 16;
-    const size_t fl = (size_t)NQ * SP + 2 * (size_t)NQ * QLD + 2 * (size_t)DHP * (NQ + 4) + 2 * NQ;
+    const size_t tr = (size_t)((a.T + 3) & ~3);
+    // the dQ phase reads NQ "rows" of dS: the allocation covers that extent even though only tr rows are written
+    const size_t fl = std::max(tr * SP + 2 * (size_t)NQ * QLD + 2 * (size_t)DHP * (NQ + 4) + 2 * NQ, (size_t)NQ * SP);
     if (fl * sizeof(float) > 150 * 1024) return kAttnMfmaUnsupported;
     auto kern = attn_bwd_mfma_kernel<NQT, MAXT>;
     static bool attr = false;
@@ -441,8 +455,8 @@ int launch_bwd(const ick_attn_bwd_args& a, int SP, hipStream_t s) {
 bool attn_mfma_shape_ok(int T, int S, int dh) {
     if (!(T >= 2 && T <= 64 && S >= 1 && S <= 512 && dh <= DHP)) return false;
     // the backward keeps dS ([query][key]) in LDS
-    const size_t nq = (size_t)((T + 15) / 16) * 16, sp = (size_t)((S + 15) / 16) * 16 + 4;
-    return (nq * sp + 2 * nq * QLD + 2 * DHP * (nq + 4) + 2 * nq) * sizeof(float) <= 150 * 1024;
+    const size_t nq = (size_t)((T + 15) / 16) * 16, sp = (size_t)((S + 15) / 16) * 16 + 4, tr = (size_t)((T + 3) & ~3);
+    return std::max(tr * sp + 2 * nq * QLD + 2 * DHP * (nq + 4) + 2 * nq, nq * sp) * sizeof(float) <= 150 * 1024;
 }
 
 int launch_attn_mfma(const ick_attn_args& a, hipStream_t s) {
@@ -452,10 +466,12 @@ int launch_attn_mfma(const ick_attn_args& a, hipStream_t s) {
         return kAttnMfmaUnsupported;
     const int SP = ((a.S + 15) / 16) * 16 + 4;
     const int nqt = (a.T + 15) / 16;
-    // key tiles per wave (compile time: register arrays): 1 for S <= 64 (self-attention), 4 up to 256, 8 up to 512
-    const int mt = a.S <= 64 ? 1 : (a.S <= 256 ? 4 : 8);
-#define ICK_FWD(N)                                                    \
-    case N: return mt == 1 ? launch_fwd<N, 1>(a, SP, s) : (mt == 4 ? launch_fwd<N, 4>(a, SP, s) : launch_fwd<N, 8>(a, SP, s))
+    // key tiles per wave (compile time: register arrays): 1 for S <= 64 (self-attention), 4 up to 256 (geo: 216),
+    // 5 up to 320 (knowledge: 267), 8 up to 512
+    const int mt = a.S <= 64 ? 1 : (a.S <= 256 ? 4 : (a.S <= 320 ? 5 : 8));
+#define ICK_FWD(N)                                                                                   \
+    case N: return mt == 1 ? launch_fwd<N, 1>(a, SP, s) : (mt == 4 ? launch_fwd<N, 4>(a, SP, s) :   \
+                   (mt == 5 ? launch_fwd<N, 5>(a, SP, s) : launch_fwd<N, 8>(a, SP, s)))
     switch (nqt) {
         ICK_FWD(1); ICK_FWD(2); ICK_FWD(3); ICK_FWD(4);
     }
@@ -466,9 +482,10 @@ int launch_attn_mfma(const ick_attn_args& a, hipStream_t s) {
 int launch_attn_bwd_mfma(const ick_attn_bwd_args& a, hipStream_t s) {
     if (!attn_mfma_shape_ok(a.T, a.S, a.dh)) return kAttnMfmaUnsupported;
     const int SP = ((a.S + 15) / 16) * 16 + 4;
-    const int mt = a.S <= 64 ? 1 : (a.S <= 256 ? 4 : 8);
-#define ICK_BWD(N)                                                    \
-    case N: return mt == 1 ? launch_bwd<N, 1>(a, SP, s) : (mt == 4 ? launch_bwd<N, 4>(a, SP, s) : launch_bwd<N, 8>(a, SP, s))
+    const int mt = a.S <= 64 ? 1 : (a.S <= 256 ? 4 : (a.S <= 320 ? 5 : 8));
+#define ICK_BWD(N)                                                                                   \
+    case N: return mt == 1 ? launch_bwd<N, 1>(a, SP, s) : (mt == 4 ? launch_bwd<N, 4>(a, SP, s) :   \
+                   (mt == 5 ? launch_bwd<N, 5>(a, SP, s) : launch_bwd<N, 8>(a, SP, s)))
     switch ((a.T + 15) / 16) {
         ICK_BWD(1); ICK_BWD(2); ICK_BWD(3); ICK_BWD(4);
     }

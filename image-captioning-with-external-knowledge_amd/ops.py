@@ -314,7 +314,10 @@ def packed_ce(scores, captions_sorted, decode_len, pad_token, want_grad=False):
     row_loss = torch.empty(B * Lc, device=dev, dtype=torch.float32)
     loss_sum = torch.empty(1, device=dev, dtype=torch.float32)
     count = torch.empty(1, device=dev, dtype=torch.float32)
-    dscores = torch.empty_like(scores) if want_grad else None
+    dscores = None
+    if want_grad:     # same (possibly padded) row stride as the scores: the kernel takes one leading dimension
+        dscores = torch.empty(B, Lc, scores.stride(1), device=dev, dtype=torch.float32)[:, :, :Vx]
+        assert scores.stride(0) == Lc * scores.stride(1) and scores.stride(2) == 1
     L.check(L.load().ick_packed_ce(_p(scores), scores.stride(1), _p(captions_sorted), _p(decode_len), B, Lc, Vx,
                                    pad_token, _p(row_loss), _p(loss_sum), _p(count), _p(dscores), _stream()),
             "ick_packed_ce")

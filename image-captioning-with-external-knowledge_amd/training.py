@@ -191,8 +191,11 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         eib, gate = ops.context_indicators(captions, facts, K, V, pred_wt, _p(dec.fc_predicate.bias), mode=0)
         hv = ops.mul(x, gate)
     Vx = V + K + Fn
-    scores = torch.empty(B, L, Vx, device=x.device, dtype=torch.float32)
-    ops.gemm_raw(hv if dec.has_facts else x, _p(dec.fc_vocab.weight), scores, B * L, V, d, d, 1, d, 1, Vx,
+    # rows padded to a multiple of 4 floats (knowledge: 50 000 + 20 + 51 = 50 071 columns): the vocabulary's data- and
+    # weight-gradient GEMMs read the score gradients with 16-byte loads only from aligned rows (645 -> ~470 us)
+    ld = (Vx + 3) // 4 * 4
+    scores = torch.empty(B, L, ld, device=x.device, dtype=torch.float32)[:, :, :Vx]
+    ops.gemm_raw(hv if dec.has_facts else x, _p(dec.fc_vocab.weight), scores, B * L, V, d, d, 1, d, 1, ld,
                  bias=_p(dec.fc_vocab.bias))
     ops.pointer_scores(x, ee, _p(dec.fc_entity.weight), _p(dec.fc_entity.bias), scores, V)
     if dec.has_facts:

@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
     int iters = argc > 1 ? atoi(argv[1]) : 200;
     CK(hipStreamCreate(&st));
     float *A, *B, *C, *bias;
-    size_t na = (size_t)64 * 2048 * 196, nb = (size_t)64 * 6 * 10 * 256 * 32 /* >= KV of 64 samples */, nc = (size_t)13824 * 2048;
+    size_t na = (size_t)64 * 2048 * 196, nb = (size_t)64 * 6 * 10 * 288 * 32 /* >= KV of 64 samples, S <= 288 */, nc = (size_t)13824 * 2048;
     setvbuf(stdout, nullptr, _IONBF, 0);
     CK(hipMalloc(&A, na * 4)); CK(hipMalloc(&B, nb * 4)); CK(hipMalloc(&C, nc * 4)); CK(hipMalloc(&bias, 65536 * 4));
     std::vector<float> h(na);
@@ -112,6 +112,8 @@ int main(int argc, char** argv) {
     attn("cross attention", 64, 20, 216, 0);
     attn("self attention", 64, 20, 20, 1);
     attn("decode cross", 64, 1, 216, 0);
+    attn("fact self-attention", 64, 51, 51, 0);
+    attn("cross attention S=267", 64, 20, 267, 0);
     float us = timeit([&] { ick_add_layernorm(A, B, bias, bias, C, 1280, 300, 1e-5f, 300, 300, 300, nullptr, nullptr, 0.f, 0, 0, nullptr, st); }, iters);
     printf("%-28s rows=1280               : %8.2f us\n", "add_layernorm", us);
     // backward probes
@@ -138,5 +140,7 @@ int main(int argc, char** argv) {
     };
     attn_bwd("cross attention bwd", 64, 20, 216, 0);
     attn_bwd("self attention bwd", 64, 20, 20, 1);
+    attn_bwd("fact self-attention bwd", 64, 51, 51, 0);
+    attn_bwd("cross attention bwd S=267", 64, 20, 267, 0);
     return 0;
 }
