@@ -191,20 +191,38 @@ __global__ __launch_bounds__(256) void context_indicators_kernel(const int64_t* 
         rep[j] = r;
     }
     __syncthreads();
-    // entity_idx_before
-    for (int idx = tid; idx < T * F; idx += 256) {
+    // entity_idx_before (written by the first workgroup of the sample's column split)
+    for (int idx = tid; blockIdx.y == 0 && idx < T * F; idx += 256) {
         const int p = idx / F, j = idx - p * F;
         eib[((int64_t)b * T + p) * F + j] = act[j] <= p ? 1.f : 0.f;
     }
-    // gate rows, running over positions
+    // gate rows, running over positions: the row only changes at the (at most F) positions where a representative
+    // fact becomes active, so the facts are ranked by (act, index) once and the running sum walks that list
+    // (same summation order as a position-by-position, fact-by-fact scan, ~T + F steps instead of T * F)
     if (gate) {
-        for (int c0 = 0; c0 < d; c0 += 256) {
-            const int c = c0 + tid;
-            float acc = c < d ? bias[c] : 0.f;
+        int* ord_act = rep + F;     // F
+        int* ord_pred = ord_act + F;  // F
+        int* nrep = ord_pred + F;   // 1
+        if (tid == 0) *nrep = 0;
+        __syncthreads();
+        for (int j = tid; j < F; j += 256) {
+            if (rep[j] && act[j] < T) {
+                int rank = 0;
+                for (int i = 0; i < F; ++i)
+                    if (rep[i] && act[i] < T && (act[i] < act[j] || (act[i] == act[j] && i < j))) ++rank;
+                ord_act[rank] = act[j];
+                ord_pred[rank] = pred[j];
+                atomicAdd(nrep, 1);
+            }
+        }
+        __syncthreads();
+        const int n = *nrep;
+        for (int c = blockIdx.y * 256 + tid; c < d; c += 256 * gridDim.y) {
+            float acc = bias[c];
+            int r = 0;
             for (int p = 0; p < T; ++p) {
-                for (int j = 0; j < F; ++j)
-                    if (rep[j] && act[j] == p && c < d) acc += wt[(int64_t)pred[j] * d + c];
-                if (c < d) gate[((int64_t)b * T + p) * d + c] = acc;
+                while (r < n && ord_act[r] <= p) { acc += wt[(int64_t)ord_pred[r] * d + c]; ++r; }
+                gate[((int64_t)b * T + p) * d + c] = acc;
             }
         }
     }
@@ -273,9 +291,10 @@ extern "C" int ick_context_indicators(const int64_t* captions, const int64_t* fa
     ICK_CHECK_ARG(captions && facts && eib && B > 0 && L > 0 && K > 0 && F > 0);
     ICK_CHECK_ARG((mode == 0 && T == L) || (mode == 1 && T == 1));
     if (gate) ICK_CHECK_ARG(fc_pred_wt && fc_pred_b && num_pred > 0 && d > 0);
-    const size_t smem = (size_t)(K + 3 * F) * sizeof(int);
+    const size_t smem = (size_t)(K + 5 * F + 1) * sizeof(int);
     ICK_CHECK_ARG(smem <= 64 * 1024);
-    hipLaunchKernelGGL(context_indicators_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, captions, facts,
+    const int csplit = gate ? std::max(1, std::min(4, ceil_div(d, 256))) : 1;   // workgroups per sample (gate columns)
+    hipLaunchKernelGGL(context_indicators_kernel, dim3(B, csplit), dim3(256), smem, (hipStream_t)stream, captions, facts,
                        fc_pred_wt, fc_pred_b, eib, gate, L, T, K, F, V, num_pred, d, mode);
     ICK_LAUNCH_RET();
 }
