@@ -28,7 +28,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CONV1_HBM_BYTES = 154.8e6   # measured, see profiles/r01_e_pmc_conv1.txt
+CONV1_HBM_BYTES = 154.8e6   # measured, see profiles/r01_f_pmc_conv1.txt
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_GBS = 8000.0
 
@@ -238,7 +238,7 @@ def main():
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          # HBM bytes per launch from the PMC counters of this kernel on this workload (separate
                          # rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes;
-                         # tools/pmc_conv1.sh -> profiles/r01_e_pmc_conv1.txt); algorithmic 120.3 MB
+                         # tools/pmc_conv1.sh -> profiles/r01_f_pmc_conv1.txt); algorithmic 120.3 MB
                          "traffic": CONV1_HBM_BYTES if dom_shape == (64 * 196, 300, 2048) else None,
                          "kernel": "gemm_kernel<2,2,2,2,A k-major,B k-contig,vec> (Encoder.conv1: [%d x %d] x [%d x %d])"
                                    % (dom_shape[0], dom_shape[2], dom_shape[2], dom_shape[1]),
