@@ -240,7 +240,7 @@ def main():
                          # rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes;
                          # tools/pmc_conv1.sh -> profiles/r01_f_pmc_conv1.txt); algorithmic 120.3 MB
                          "traffic": CONV1_HBM_BYTES if dom_shape == (64 * 196, 300, 2048) else None,
-                         "kernel": "gemm_kernel<2,2,2,2,A k-major,B k-contig,vec> (Encoder.conv1: [%d x %d] x [%d x %d])"
+                         "kernel": "gemm_kernel<4,2,2,2,A k-major,B k-contig,vec> 128x64 tiles, 8 waves (Encoder.conv1: [%d x %d] x [%d x %d])"
                                    % (dom_shape[0], dom_shape[2], dom_shape[2], dom_shape[1]),
                          "kernel_ms": kern_ms, "flops_per_launch": flops, "launches_timed": len(events)},
         }
