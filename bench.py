@@ -28,7 +28,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CONV1_HBM_BYTES = 154.8e6   # measured, see profiles/r01_f_pmc_conv1.txt
+CONV1_HBM_BYTES = 161.9e6   # measured, see profiles/r01_f_pmc_conv1.txt
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_GBS = 8000.0
 
