@@ -244,6 +244,15 @@ def main():
                                    % (dom_shape[0], dom_shape[2], dom_shape[2], dom_shape[1]),
                          "kernel_ms": kern_ms, "flops_per_launch": flops, "launches_timed": len(events)},
         }
+        # whole-pass view: measured decode-steps/s against the bound of the pass's algorithmic work
+        # at the same peaks -- teacher-forced passes are MFMA-bound (a train step is ~3x the forward FLOPs), the
+        # KV-cached greedy decode is HBM-bound
+        bounds = {("cfg2", "forward"): 3.96e6, ("cfg2", "train"): 3.96e6 / 3, ("cfg4", "forward"): 1.99e6,
+                  ("cfg4", "train"): 1.99e6 / 3, ("cfg5", "greedy"): 3.39e6}
+        bnd = bounds.get((cfgname, args.mode))
+        if bnd is not None:
+            out["roofline"]["pass_bound_steps_per_s"] = bnd * world
+            out["roofline"]["pass_frac"] = out["value"] / (bnd * world)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, seed, args.cpu_seconds, args.mode if args.mode == "train" else "forward")
         print(json.dumps(out), flush=True)
