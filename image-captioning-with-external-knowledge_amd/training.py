@@ -151,26 +151,31 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     if dec.has_facts:
         tape.enc_layers["facts"] = []
 
-    def context_chain():
+    def entity_chain():
         ops.stamp("side: context chain starts")
         ctx_e = _context_encoder_fwd(dec, dec.transformer_encoder_entities, ee, tape.enc_layers["entities"], ds)
         mem[:, P:P + K].copy_(ctx_e)
         ops.project_heads(ctx_e, wkv, bkv, nseg, H, S, out=kv, s0=P, grp=K)
-        if dec.has_facts:
-            ctx_f = _context_encoder_fwd(dec, dec.transformer_encoder_facts, fe, tape.enc_layers["facts"], ds)
-            mem[:, P + K:].copy_(ctx_f)
-            ops.project_heads(ctx_f, wkv, bkv, nseg, H, S, out=kv, s0=P + K, grp=Fn)
         ops.stamp("side: context chain done")
+
+    def fact_chain():
+        ctx_f = _context_encoder_fwd(dec, dec.transformer_encoder_facts, fe, tape.enc_layers["facts"], ds)
+        mem[:, P + K:].copy_(ctx_f)
+        ops.project_heads(ctx_f, wkv, bkv, nseg, H, S, out=kv, s0=P + K, grp=Fn)
 
     side = ops.SideStream(priority=-1) if overlap else None
     img = enc_tok.index_select(0, gmap.long()) if gmap is not None else enc_tok
     if side is not None:
-        side.submit(context_chain, ee, fe, mem, kv, wkv, bkv, img)
+        side.submit(entity_chain, ee, fe, mem, kv, wkv, bkv, img)
     else:
-        context_chain()
+        entity_chain()
     mem[:, :P].copy_(img)
     if side is not None:
         side.flush()     # enqueued after the main stream's next kernel (see SideStream)
+    if dec.has_facts:
+        # on the main stream, beside the entity chain on the side stream: two chains of small kernels overlap well
+        # (a chain beside the large projection below does not)
+        fact_chain()
     # One GEMM for the image rows of every layer.  Projecting the later layers' rows on the side stream after the
     # chain was measured (device time stamps): the chain ends 70 us earlier, the first decoder layer 90 us later --
     # a 5000-workgroup GEMM beside a chain of small kernels delays the chain by about its own duration either way.
