@@ -243,17 +243,47 @@ __global__ __launch_bounds__(256) void packed_ce_rows_kernel(const float* __rest
         }
         return;
     }
-    float m = -INFINITY;
-    for (int i = tid; i < Vx; i += 256) m = fmaxf(m, r[i]);
+    // Long rows (knowledge vocabulary: 50 071 columns): max and sum of exponentials in ONE pass with a running pair
+    // (m, s) per thread, rescaled when the maximum moves; the pairs are merged through the block maximum.  Two reads of
+    // the row instead of three.
+    float m = -INFINITY, s = 0.f;
+    for (int i0 = 0; i0 < Vx; i0 += 256 * 8) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = i0 + tid + 256 * j;
+            x[j] = i < Vx ? r[i] : -INFINITY;
+        }
+        float bm = m;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bm = fmaxf(bm, x[j]);
+        if (bm > -INFINITY) {
+            s *= __expf(m - bm);            // m = -inf: s is 0 and stays 0
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += __expf(x[j] - bm);   // exp(-inf) = 0 for the tail
+            m = bm;
+        }
+    }
+    const float mt = m;
     m = block_max<4>(m, red);
-    float s = 0.f;
-    for (int i = tid; i < Vx; i += 256) s += __expf(r[i] - m);
-    s = block_sum<4>(s, red);
+    s = block_sum<4>(mt > -INFINITY ? s * __expf(mt - m) : 0.f, red);
     const float lse = m + __logf(s);
     if (tid == 0) row_loss[row] = lse - r[target];
     if (dr) {
         const float inv = 1.f / s;
-        for (int i = tid; i < Vx; i += 256) dr[i] = __expf(r[i] - m) * inv - (i == target ? 1.f : 0.f);
+        for (int i0 = 0; i0 < Vx; i0 += 256 * 8) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + tid + 256 * j;
+                x[j] = i < Vx ? r[i] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + tid + 256 * j;
+                if (i < Vx) dr[i] = __expf(x[j] - m) * inv - (i == target ? 1.f : 0.f);
+            }
+        }
     }
 }
 

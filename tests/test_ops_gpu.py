@@ -468,8 +468,9 @@ def test_greedy_update_matches_reference_cleanup(ops):
     assert fin.cpu().tolist() == [int(f) for f in ref_fin]
 
 
-def test_packed_ce(ops):
-    B, Lc, Vx, pad = 6, 9, 1020, 0
+@pytest.mark.parametrize("Vx", [1020, 1021, 12001])   # register-resident rows / odd width / longer than the registers hold
+def test_packed_ce(ops, Vx):
+    B, Lc, pad = 6, 9, 0
     sc = rnd(B, Lc, Vx, seed=3, scale=3.0)
     caps = torch.randint(1, Vx, (B, Lc), generator=torch.Generator().manual_seed(1))
     lens = torch.tensor([9, 8, 8, 6, 5, 3])
