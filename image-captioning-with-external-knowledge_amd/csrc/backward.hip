@@ -196,10 +196,23 @@ __global__ __launch_bounds__(256) void pointer_bwd_dh_kernel(const float* __rest
     const float* dsr = ds + ((int64_t)b * T + t) * ds_ld + col0;
     for (int c = threadIdx.x; c < d; c += 256) {
         float acc = 0.f;
-        for (int k = 0; k < Kc; ++k) {
+        const float* cc = ctx + (int64_t)b * Kc * d + c;
+        int k = 0;
+        for (; k + 8 <= Kc; k += 8) {        // eight context rows in flight
+            float v[8], g[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                v[q] = cc[(int64_t)(k + q) * d];
+                g[q] = dsr[k + q];
+                if (ind) g[q] *= ind[((int64_t)b * T + t) * Kc + k + q];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc = fmaf(g[q], v[q], acc);
+        }
+        for (; k < Kc; ++k) {
             float g = dsr[k];
             if (ind) g *= ind[((int64_t)b * T + t) * Kc + k];
-            acc = fmaf(g, ctx[((int64_t)b * Kc + k) * d + c], acc);
+            acc = fmaf(g, cc[(int64_t)k * d], acc);
         }
         dh[((int64_t)b * T + t) * d + c] += acc * w[c];
     }

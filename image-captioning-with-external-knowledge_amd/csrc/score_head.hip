@@ -13,18 +13,21 @@ namespace {
 
 constexpr int kMaxPerLane = 16;
 
-// one workgroup per (b, t) row of h; each wave walks context rows k = wave, wave+4, ...
+// one workgroup per (b, t) row of h; each wave walks context rows k = wave, wave+4, ... in batches of KB rows
+// whose loads are all issued before the first reduction (one memory round trip per batch, not per row)
+template <int NJ>
 __global__ __launch_bounds__(256) void pointer_scores_kernel(const float* __restrict__ h, const float* __restrict__ ctx,
                                                              const float* __restrict__ w, const float* __restrict__ bias,
                                                              const float* __restrict__ ind, float* __restrict__ out,
                                                              int T, int Kc, int d, int64_t out_ld, int col0,
                                                              const int32_t* __restrict__ out_gmap) {
+    constexpr int KB = 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y, t = blockIdx.x;
     const float* hr = h + ((int64_t)b * T + t) * d;
-    float hv[kMaxPerLane], wv[kMaxPerLane];
+    float hv[NJ], wv[NJ];
 #pragma unroll
-    for (int j = 0; j < kMaxPerLane; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int c = lane + 64 * j;
         hv[j] = c < d ? hr[c] : 0.f;
         wv[j] = c < d ? w[c] : 0.f;
@@ -32,24 +35,34 @@ __global__ __launch_bounds__(256) void pointer_scores_kernel(const float* __rest
     const int ob = out_gmap ? out_gmap[b] : b;
     float* orow = out + ((int64_t)ob * T + t) * out_ld + col0;
     const float bs = bias[0];
-    for (int k = wave; k < Kc; k += 4) {
-        const float* cr = ctx + ((int64_t)b * Kc + k) * d;
-        float acc = 0.f;
+    for (int k0 = wave; k0 < Kc; k0 += 4 * KB) {
+        float cv[KB][NJ];
 #pragma unroll
-        for (int j = 0; j < kMaxPerLane; ++j) {
-            const int c = lane + 64 * j;
-            if (c < d) acc = fmaf(__fmul_rn(hv[j], cr[c]), wv[j], acc);
+        for (int q = 0; q < KB; ++q) {
+            const int k = k0 + 4 * q;
+            const float* cr = ctx + ((int64_t)b * Kc + (k < Kc ? k : 0)) * d;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int c = lane + 64 * j;
+                cv[q][j] = (k < Kc && c < d) ? cr[c] : 0.f;
+            }
         }
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            const float f = ind ? ind[((int64_t)b * T + t) * Kc + k] : 1.f;
-            orow[k] = acc * f + bs;
+#pragma unroll
+        for (int q = 0; q < KB; ++q) {
+            const int k = k0 + 4 * q;
+            if (k >= Kc) break;      // wave-uniform
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc = fmaf(__fmul_rn(hv[j], cv[q][j]), wv[j], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) {
+                const float f = ind ? ind[((int64_t)b * T + t) * Kc + k] : 1.f;
+                orow[k] = acc * f + bs;
+            }
         }
     }
 }
 
-// argmax and runner-up of each score row (softmax is monotonic, so predict()'s
-// softmax -> argmax / topk(2) select the same indices; ties resolve to the lower index).
 struct Top2 {
     float v1, v2;
     int i1, i2;
@@ -310,8 +323,16 @@ extern "C" int ick_pointer_scores(const float* h, const float* ctx, const float*
     using namespace ick;
     ICK_CHECK_ARG(h && ctx && w && bias && out && B > 0 && T > 0 && Kc > 0 && d > 0 && d <= 64 * kMaxPerLane);
     ICK_CHECK_ARG(B <= 65535 && col0 >= 0 && out_ld >= col0 + Kc);
-    hipLaunchKernelGGL(pointer_scores_kernel, dim3(T, B), dim3(256), 0, (hipStream_t)stream, h, ctx, w, bias, ind, out,
-                       T, Kc, d, out_ld, col0, out_gmap);
+    hipStream_t s = (hipStream_t)stream;
+    if (d <= 320)
+        hipLaunchKernelGGL(pointer_scores_kernel<5>, dim3(T, B), dim3(256), 0, s, h, ctx, w, bias, ind, out, T, Kc, d,
+                           out_ld, col0, out_gmap);
+    else if (d <= 512)
+        hipLaunchKernelGGL(pointer_scores_kernel<8>, dim3(T, B), dim3(256), 0, s, h, ctx, w, bias, ind, out, T, Kc, d,
+                           out_ld, col0, out_gmap);
+    else
+        hipLaunchKernelGGL(pointer_scores_kernel<kMaxPerLane>, dim3(T, B), dim3(256), 0, s, h, ctx, w, bias, ind, out, T,
+                           Kc, d, out_ld, col0, out_gmap);
     ICK_LAUNCH_RET();
 }
 
