@@ -178,7 +178,9 @@ __global__ __launch_bounds__(256) void caption_embed_bwd_kernel(const float* __r
     for (int c = lane; c < d; c += 64) {
         float v = src[c] * scale;
         if (drop.on()) v *= drop.mask((uint32_t)row * (uint32_t)d + (uint32_t)c);   // PositionEncoder dropout
-        atomicAdd(dst + c, v);
+        // positions past the caption's end carry exactly zero gradient (nothing after them is in the loss) and all
+        // point at the <pad> row: skipping zero addends removes a ~400-way atomic pile-up on that row
+        if (v != 0.f) atomicAdd(dst + c, v);
     }
 }
 
