@@ -365,16 +365,20 @@ __global__ __launch_bounds__(256) void context_gate_bwd_kernel(const int64_t* __
         rep[j] = r;
     }
     __syncthreads();
-    for (int c = tid; c < d; c += 256) {
-        // suffix sums of dgate over positions: a predicate active from position a gets sum_{p >= a}
-        float tot = 0.f;
-        for (int p = 0; p < T; ++p) tot += dgate[((int64_t)b * T + p) * d + c];
-        atomicAdd(dbias + c, tot);
+    // suffix sums of dgate over positions, once per column (registers walk p = T-1 .. 0, LDS keeps suf[p]): a predicate
+    // active from position a gets suf[a] = sum_{p >= a} dgate[b,p,c]  (was: T loads per (fact, column) pair)
+    float* suf = reinterpret_cast<float*>(rep + F);     // T * 256 floats
+    const int c = blockIdx.y * 256 + tid;
+    if (c < d) {
+        float run = 0.f;
+        for (int p = T - 1; p >= 0; --p) {
+            run += dgate[((int64_t)b * T + p) * d + c];
+            suf[p * 256 + tid] = run;
+        }
+        atomicAdd(dbias + c, run);
         for (int j = 0; j < F; ++j) {
             if (!rep[j] || act[j] >= T) continue;
-            float s = 0.f;
-            for (int p = act[j]; p < T; ++p) s += dgate[((int64_t)b * T + p) * d + c];
-            atomicAdd(dw + (int64_t)c * num_pred + pred[j], s);  // fc_predicate.weight is (d, num_pred)
+            atomicAdd(dw + (int64_t)c * num_pred + pred[j], suf[act[j] * 256 + tid]);  // fc_predicate.weight is (d, num_pred)
         }
     }
 }
@@ -512,9 +516,10 @@ extern "C" int ick_context_gate_bwd(const int64_t* captions, const int64_t* fact
                                     int32_t num_pred, int32_t d, int32_t mode, void* stream) {
     ICK_CHECK_ARG(captions && facts && dgate && dw && dbias && B > 0 && L > 0 && K > 0 && F > 0);
     ICK_CHECK_ARG((mode == 0 && T == L) || (mode == 1 && T == 1));
-    const size_t smem = (size_t)(K + 3 * F) * sizeof(int);
-    hipLaunchKernelGGL(context_gate_bwd_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, captions, facts, dgate,
-                       dw, dbias, L, T, K, F, V, num_pred, d, mode);
+    const size_t smem = (size_t)(K + 3 * F) * sizeof(int) + (size_t)T * 256 * sizeof(float);
+    ICK_CHECK_ARG(smem <= 64 * 1024);
+    hipLaunchKernelGGL(context_gate_bwd_kernel, dim3(B, ceil_div(d, 256)), dim3(256), smem, (hipStream_t)stream, captions,
+                       facts, dgate, dw, dbias, L, T, K, F, V, num_pred, d, mode);
     ICK_LAUNCH_RET();
 }
 
