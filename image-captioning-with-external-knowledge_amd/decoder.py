@@ -66,7 +66,9 @@ def copy_inputs(static, inputs):
     on the critical path here: forward() has just synchronised for the length sort)."""
     dst = [d for d, s in zip(static, inputs) if d is not None]
     src = [s for d, s in zip(static, inputs) if d is not None]
-    if all(s.is_cuda and s.shape == d.shape for d, s in zip(dst, src)):
+    if all(s.is_cuda and s.shape == d.shape and s.dtype == d.dtype and s.is_contiguous() for d, s in zip(dst, src)):
+        ops.copy_batch(dst, src)          # one launch for all of them
+    elif all(s.is_cuda and s.shape == d.shape for d, s in zip(dst, src)):
         torch._foreach_copy_(dst, src, non_blocking=True)
     else:
         for d, s in zip(dst, src):

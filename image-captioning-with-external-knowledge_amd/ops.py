@@ -446,6 +446,17 @@ def stamps_report():
     return sorted(((n, (x - t0) / 100.0) for n, x in zip(STAMPS["names"], t)), key=lambda p: p[1])
 
 
+def copy_batch(dst, src):
+    """dst[i].copy_(src[i]) for up to 8 pairs of contiguous same-sized device tensors per launch (ick_copy_batch)."""
+    for i in range(0, len(dst), 8):
+        d, s_ = dst[i:i + 8], src[i:i + 8]
+        n = len(d)
+        sp = (C.c_void_p * n)(*[t.data_ptr() for t in s_])
+        dp = (C.c_void_p * n)(*[t.data_ptr() for t in d])
+        nb = (C.c_longlong * n)(*[t.numel() * t.element_size() for t in d])
+        L.check(L.load().ick_copy_batch(sp, dp, nb, n, _stream()), "ick_copy_batch")
+
+
 class SideStream:
     """Second HIP stream for work that is off the critical path: in the backward pass the weight and bias
     gradients of a Linear only feed the optimizer, while the data gradient feeds the next layer's backward.

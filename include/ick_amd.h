@@ -278,6 +278,8 @@ int ick_adam_clamp(float* p, float* g, float* m, float* v, int64_t n, float gsca
                    const float* gscale_den, void* stream);
 /* *counter += inc on the stream (step / dropout-epoch counter of captured training graphs). */
 int ick_counter_add(uint32_t* counter, uint32_t inc, void* stream);
+/* n <= 8 device-to-device copies (src[i] -> dst[i], bytes[i]) in one launch; host arrays of device pointers. */
+int ick_copy_batch(const void* const* src, void* const* dst, const long long* bytes, int n, void* stream);
 /* Diagnostic: *out = device wall clock (100 MHz ticks) when the stream reaches this point. */
 int ick_timestamp(unsigned long long* out, void* stream);
 /* x *= num[0] / den[0] with device-resident scalars (token-mean normalisation without a host sync). */

@@ -485,3 +485,14 @@ def test_packed_ce(ops, Vx):
     assert cnt.item() == float(dl.sum())
     assert abs(ls.item() / cnt.item() - loss_ref.item()) < 1e-5
     close(dsc / cnt, sc_ref.grad, 1e-6, "dscores")
+
+
+def test_copy_batch(ops):
+    """ick_copy_batch: several device-to-device copies of different sizes / dtypes / alignments in one launch."""
+    src = [dev(rnd(64, 20, seed=1)), torch.arange(1280, device="cuda"), dev(rnd(3, seed=2)), dev(rnd(64, 196, 300, seed=3)),
+           torch.arange(7, device="cuda", dtype=torch.int32), dev(rnd(1025, seed=4))[1:]]
+    dst = [torch.empty_like(s) for s in src]
+    dst[5] = torch.zeros(1030, device="cuda")[3:1027]      # unaligned destination
+    ops.copy_batch(dst, [s.contiguous() for s in src])
+    for d, s in zip(dst, src):
+        assert torch.equal(d, s)
