@@ -307,13 +307,14 @@ def greedy_update(best, second, output, hist, finished, next_token, next_mask, s
             "ick_greedy_update")
 
 
-def packed_ce(scores, captions_sorted, decode_len, pad_token, want_grad=False):
-    """Returns (loss_sum (1,), count (1,), dscores or None): token-mean loss = loss_sum / count."""
+def packed_ce(scores, captions_sorted, decode_len, pad_token, want_grad=False, out_sum=None, out_count=None):
+    """Returns (loss_sum (1,), count (1,), dscores or None): token-mean loss = loss_sum / count.  out_sum / out_count:
+    one-element float tensors to receive the two scalars (the tail of TrainStep's gradient bucket)."""
     B, Lc, Vx = scores.shape
     dev = scores.device
     row_loss = torch.empty(B * Lc, device=dev, dtype=torch.float32)
-    loss_sum = torch.empty(1, device=dev, dtype=torch.float32)
-    count = torch.empty(1, device=dev, dtype=torch.float32)
+    loss_sum = out_sum if out_sum is not None else torch.empty(1, device=dev, dtype=torch.float32)
+    count = out_count if out_count is not None else torch.empty(1, device=dev, dtype=torch.float32)
     dscores = None
     if want_grad:     # same (possibly padded) row stride as the scores: the kernel takes one leading dimension
         dscores = torch.empty(B, Lc, scores.stride(1), device=dev, dtype=torch.float32)[:, :, :Vx]

@@ -554,12 +554,13 @@ class TrainStep:
                                          seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
                                          overlap=self.use_graph)
         ops.stamp("fwd: scores done")
-        loss_sum, count, dscores = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True)
+        # the two scalars of the loss go straight into the tail of the gradient bucket (it was zeroed above; nothing else
+        # touches those two floats)
+        _, _, dscores = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True,
+                                      out_sum=self.flat_g[self.n:self.n + 1], out_count=self.flat_g[self.n + 1:])
         ops.stamp("CE done")
         backward_from_tape(dec, tape, dscores, self.grads,
                            overlap=self.use_graph and not os.environ.get("ICK_NO_BWD_OVERLAP"))
-        self.flat_g[self.n:self.n + 1].copy_(loss_sum)
-        self.flat_g[self.n + 1:].copy_(count)
         ops.stamp("A: end (after join)")
         return self.flat_g
 
@@ -570,7 +571,8 @@ class TrainStep:
         scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gmap,
                                          seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
                                          overlap=self.use_graph)
-        self._loss = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True)
+        self._loss = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True,
+                                   out_sum=self.flat_g[self.n:self.n + 1], out_count=self.flat_g[self.n + 1:])
         self._bp = BackwardPass(dec, tape, self._loss[2], self.grads,
                                 overlap=self.use_graph and not os.environ.get("ICK_NO_BWD_OVERLAP"))
         self._bp.early(join=True)
@@ -578,8 +580,6 @@ class TrainStep:
 
     def _part_a2(self):
         self._bp.late()
-        self.flat_g[self.n:self.n + 1].copy_(self._loss[0])
-        self.flat_g[self.n + 1:].copy_(self._loss[1])
         return self.flat_g
 
     def _part_b(self):
