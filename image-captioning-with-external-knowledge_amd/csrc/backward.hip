@@ -395,7 +395,12 @@ __global__ __launch_bounds__(256) void adam_clamp_kernel(float* __restrict__ p, 
                                                          float eps, int step0, const uint32_t* step_ptr,
                                                          const float* __restrict__ gscale_den) {
     const int64_t stride = (int64_t)gridDim.x * 256;
-    if (gscale_den) gscale = gscale / gscale_den[0];
+    if (gscale_den) {
+        // a (global) batch without a single contributing token has no mean loss: leave parameters and moments alone
+        // instead of spreading 0 * inf = NaN over every weight
+        if (!(gscale_den[0] > 0.f)) return;
+        gscale = gscale / gscale_den[0];
+    }
     const float t = (float)(step0 + (step_ptr ? (int)*step_ptr : 0));
     const float bc1 = 1.f - powf(b1, t);
     const float bc2_sqrt = sqrtf(1.f - powf(b2, t));

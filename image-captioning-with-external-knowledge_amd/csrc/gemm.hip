@@ -543,6 +543,18 @@ extern "C" int ick_gemm(const ick_gemm_args* in, void* stream) {
     return launch_plan(pl, (hipStream_t)stream);
 }
 
+extern "C" int ick_gemm_plan(const ick_gemm_args* in, ick_gemm_plan_info* out) {
+    using namespace ick;
+    if (!out) return ICK_EINVAL;
+    Plan pl;
+    if (int rc = make_plan(in, pl)) return rc;
+    const int bmn = pl.big ? 64 : 32;
+    out->tile_m = pl.wide ? 128 : bmn; out->tile_n = bmn; out->waves = pl.wide ? 8 : 4;
+    out->tiles_m = pl.tiles_m; out->tiles_n = pl.tiles_n; out->split_k = pl.split;
+    out->a_kmajor = pl.akm; out->b_kmajor = pl.bkm; out->vec = pl.vec;
+    return ICK_OK;
+}
+
 extern "C" int ick_gemm_grouped(const ick_gemm_args* problems, int32_t count, void* stream) {
     using namespace ick;
     if (!problems || count <= 0 || count > 64) return ICK_EINVAL;

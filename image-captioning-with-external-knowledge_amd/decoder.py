@@ -228,7 +228,7 @@ class DecoderTransformer(nn.Module):
         writes the flat bucket directly): drops the packed cross-K/V weights, the transposed predicate
         weights and every captured graph."""
         self.__dict__["_param_epoch"] = self.__dict__.get("_param_epoch", 0) + 1
-        for k in ("_kv_pack", "_pred_wt_cache", "_graphs", "_plist"):
+        for k in ("_kv_pack", "_pred_wt_cache", "_graphs", "_plist", "_dec_pack"):
             self.__dict__.pop(k, None)
 
     def _token_major(self, encoder_out):
@@ -468,8 +468,13 @@ class DecoderTransformer(nn.Module):
             pidx = self.__dict__.get("_idx_pin")
             if pidx is None or pidx.shape != sort_ind.shape:
                 pidx = self.__dict__["_idx_pin"] = torch.empty(sort_ind.shape, dtype=torch.int64, pin_memory=True)
+            prev = self.__dict__.get("_pin_ev")
+            if prev is not None:
+                prev.synchronize()    # the previous call's asynchronous copy out of this pinned buffer has executed
             pidx.copy_(sort_ind)
             sort_dev = pidx.to(dev, non_blocking=True)
+            prev = self.__dict__["_pin_ev"] = torch.cuda.Event()
+            prev.record()
             return scores_raw.index_select(0, sort_dev), captions.index_select(0, sort_dev), (lengths - 1).tolist()
         # length sort on the host, like the reference's CPU path (the result feeds a Python list anyway)
         lengths, sort_ind = caption_lengths.detach().reshape(-1).cpu().sort(dim=0, descending=True)

@@ -12,13 +12,14 @@ import torch.distributed as dist
 
 
 def init_from_env(backend=None):
-    """Initialise torch.distributed from torchrun's environment (no-op for a single process)."""
+    """Initialise torch.distributed from torchrun's environment (no-op for a single process).  Backend: the
+    argument, else $ICK_DP_BACKEND, else "nccl" (= RCCL) with a GPU and "gloo" without."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1 or dist.is_initialized():
         return world
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("ICK_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     kw = {}
     if backend == "nccl":
         kw["device_id"] = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
@@ -40,6 +41,50 @@ def allreduce_bucket(flat, group=None, async_op=False):
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         return work if async_op else flat
     return None if async_op else flat
+
+
+def world_size(group=None):
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank(group=None):
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
+def backend_name(group=None):
+    """The collective backend in use ("nccl" is RCCL on ROCm), or "none" for a single process."""
+    return dist.get_backend(group) if dist.is_available() and dist.is_initialized() else "none"
+
+
+def broadcast_bucket(flat, group=None, src=0):
+    """Every rank takes rank `src`'s copy of a flat bucket (initial parameters), in place."""
+    if world_size(group) > 1:
+        dist.broadcast(flat, src=src, group=group)
+    return flat
+
+
+def replicas_agree(flat, group=None):
+    """True when every rank holds bit-identical `flat` (compares all-reduced MIN and MAX of a 64-bit checksum of the
+    raw bits; cheap enough to call once per epoch)."""
+    if world_size(group) <= 1:
+        return True
+    bits = flat.detach().contiguous().view(torch.int32).to(torch.int64)
+    w = torch.arange(1, bits.numel() + 1, device=bits.device, dtype=torch.int64) % 1000003
+    cs = (bits * w).sum().view(1)
+    lo, hi = cs.clone(), cs.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return bool((lo == hi).item())
+
+
+def reduce_sum_count(loss_sum, count, device=None, group=None):
+    """Global (sum, count) of a weighted mean held as per-rank partial sums (validation loss): every rank gets the
+    same two numbers, so every rank takes the same lr-decay / early-stop / best-checkpoint decision."""
+    if world_size(group) <= 1:
+        return float(loss_sum), float(count)
+    t = torch.tensor([float(loss_sum), float(count)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return float(t[0]), float(t[1])
 
 
 def normalise_bucket(flat, n):

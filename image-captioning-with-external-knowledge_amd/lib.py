@@ -35,6 +35,11 @@ class GemmArgs(C.Structure):
     ]
 
 
+class GemmPlanInfo(C.Structure):
+    _fields_ = [(n, i32) for n in ("tile_m", "tile_n", "waves", "tiles_m", "tiles_n", "split_k", "a_kmajor", "b_kmajor",
+                                   "vec")]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [
         ("Q", vp), ("K", vp), ("V", vp), ("O", vp), ("lse", vp),
@@ -63,6 +68,7 @@ SIGNATURES = {
     "ick_version": [],
     "ick_device_info": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int],
     "ick_gemm": [C.POINTER(GemmArgs), vp],
+    "ick_gemm_plan": [C.POINTER(GemmArgs), C.POINTER(GemmPlanInfo)],
     "ick_add_layernorm": [vp, vp, vp, vp, vp, i64, i32, f32, i64, i64, i64, vp, vp, f32, u32, u32, vp, vp],
     "ick_attention": [C.POINTER(AttnArgs), vp],
     "ick_entity_encode": [i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp],

@@ -48,6 +48,7 @@ class Config:
     fused: bool = True
     out_dir: str = "."
     max_batches: int = 0                               # >0: stop an epoch early (smoke runs)
+    seed: int = 0                                      # shuffling seed shared by all ranks (torchrun)
 
 
 def _batch_to_device(batch, device, has_facts):
@@ -99,6 +100,9 @@ def train(loader, encoder, decoder, criterion, decoder_optimizer, step, epoch, c
 
 
 def validate(loader, encoder, decoder, criterion, cfg, device):
+    """Token-weighted mean loss over the validation split (geo-aware/train.py:317-386).  Under torchrun every rank
+    scores its own shard and the (sum, count) pair is all-reduced, so all ranks return the same number and take the
+    same best-checkpoint / lr-decay / early-stop decisions."""
     decoder.eval()
     encoder.eval()
     losses = ut.AverageMeter()
@@ -111,13 +115,51 @@ def validate(loader, encoder, decoder, criterion, cfg, device):
             losses.update(packed_loss(criterion, scores, caps_sorted, dl).item(), sum(dl))
             if cfg.max_batches and i + 1 >= cfg.max_batches:
                 break
-    return losses.avg
+    total, count = dp.reduce_sum_count(losses.sum, losses.count, device=device)
+    return total / max(count, 1.0)
+
+
+class ShardSampler(torch.utils.data.Sampler):
+    """Rank r of w takes every w-th index of the split, in order, WITHOUT padding (validation: no sample may be
+    counted twice; the shards may differ in length by one because no collective runs inside the loop)."""
+
+    def __init__(self, n, rank, world):
+        self.idx = list(range(rank, n, world))
+
+    def __iter__(self):
+        return iter(self.idx)
+
+    def __len__(self):
+        return len(self.idx)
+
+
+def make_loaders(cfg, rank, world):
+    """TRAIN: one permutation per epoch shared by all ranks (seed + epoch), dealt out in disjoint equal shards --
+    DistributedSampler pads by wrapping around so that every rank runs the same number of steps (each step holds a
+    collective).  The global batch is cfg.batch_size * world samples.  VAL: disjoint unpadded shards."""
+    data = {s: CaptionDataset(cfg.data_dir, cfg.data_name, s) for s in ("TRAIN", "VAL")}
+    samplers = {"TRAIN": None, "VAL": None}
+    if world > 1:
+        samplers["TRAIN"] = torch.utils.data.distributed.DistributedSampler(
+            data["TRAIN"], num_replicas=world, rank=rank, shuffle=True, seed=cfg.seed, drop_last=False)
+        samplers["VAL"] = ShardSampler(len(data["VAL"]), rank, world)
+    gen = torch.Generator()
+    gen.manual_seed(cfg.seed)
+    loaders = {
+        "TRAIN": torch.utils.data.DataLoader(data["TRAIN"], batch_size=cfg.batch_size, shuffle=samplers["TRAIN"] is None,
+                                             sampler=samplers["TRAIN"], num_workers=cfg.workers, pin_memory=True,
+                                             generator=gen),
+        "VAL": torch.utils.data.DataLoader(data["VAL"], batch_size=cfg.batch_size, shuffle=False,
+                                           sampler=samplers["VAL"], num_workers=cfg.workers, pin_memory=True)}
+    return loaders, samplers, gen
 
 
 def main(cfg=None):
     cfg = cfg or Config()
-    dp.init_from_env()
+    world = dp.init_from_env()
     rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and not cfg.fused:
+        raise ValueError("data-parallel training needs fused=True (TrainStep owns the gradient all-reduce)")
     device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(device)
     models = load_models(cfg.variant)
@@ -143,32 +185,44 @@ def main(cfg=None):
     encoder.to(device)
     step = None
     if cfg.fused:
-        step = TrainStep(decoder, lr=cfg.decoder_lr, grad_clip=cfg.grad_clip, seed=rank)
+        # seed: the dropout stream, one per rank (the ranks hold different samples); the constructor broadcasts rank
+        # 0's weights, so a decoder that was randomly initialised per process starts identical everywhere
+        step = TrainStep(decoder, lr=cfg.decoder_lr, grad_clip=cfg.grad_clip, seed=cfg.seed * 1000 + rank)
+        if decoder_optimizer is not None:
+            # resume: Adam moments, step count (bias correction + dropout stream position) and the decayed lr come
+            # back from the pickled optimizer (ours or one written by the reference, geo-aware/utils.py:32-46)
+            step.load_state_dict(decoder_optimizer.state_dict())
+            decoder_optimizer = None
     elif decoder_optimizer is None:
         decoder_optimizer = torch.optim.Adam([p for p in decoder.parameters() if p.requires_grad], lr=cfg.decoder_lr)
     criterion = nn.CrossEntropyLoss(ignore_index=word_map["<pad>"]).to(device)
-    loaders = {s: torch.utils.data.DataLoader(CaptionDataset(cfg.data_dir, cfg.data_name, s), batch_size=cfg.batch_size,
-                                               shuffle=True, num_workers=cfg.workers, pin_memory=True)
-               for s in ("TRAIN", "VAL")}
+    loaders, samplers, shuffle_gen = make_loaders(cfg, rank, world)
     history = []
     for epoch in range(start_epoch, cfg.epochs):
         if epochs_since_improvement == cfg.max_epochs_since_improvement:
             break
         if epochs_since_improvement > 0 and epochs_since_improvement % 8 == 0:
             if step is not None:
-                step.lr *= 0.8
-                step._graphs.clear()          # the learning rate is baked into the captured optimizer graph
+                step.set_lr(step.lr * 0.8)
             else:
                 ut.adjust_learning_rate(decoder_optimizer, 0.8)
+        # the epoch's permutation depends on (seed, epoch) only, so a resumed run sees the batches the interrupted
+        # one would have seen
+        shuffle_gen.manual_seed(cfg.seed * 100003 + epoch)
+        if samplers["TRAIN"] is not None:
+            samplers["TRAIN"].set_epoch(epoch)
         tr = train(loaders["TRAIN"], encoder, decoder, criterion, decoder_optimizer, step, epoch, cfg, device)
-        last_loss = validate(loaders["VAL"], encoder, decoder, criterion, cfg, device)
+        last_loss = validate(loaders["VAL"], encoder, decoder, criterion, cfg, device)   # identical on every rank
         is_best = last_loss < best_loss
         best_loss = min(last_loss, best_loss)
         epochs_since_improvement = 0 if is_best else epochs_since_improvement + 1
         history.append((tr, last_loss))
+        if step is not None and world > 1 and not dp.replicas_agree(step.flat_p):
+            raise RuntimeError("data-parallel replicas diverged (epoch %d): parameters differ between ranks" % epoch)
         if rank == 0:
+            opt = step.as_torch_optimizer() if step is not None else decoder_optimizer
             ut.save_checkpoint(cfg.data_name, epoch, epochs_since_improvement, encoder, decoder, None,
-                               decoder_optimizer, last_loss, is_best, out_dir=cfg.out_dir)
+                               opt, last_loss, is_best, out_dir=cfg.out_dir)
     return history
 
 

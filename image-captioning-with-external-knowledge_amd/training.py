@@ -539,6 +539,9 @@ class TrainStep:
                 off += pad(k)
         self.params = params
         self._graphs = {}
+        # several ranks: every replica starts from rank 0's weights (a freshly built decoder is randomly initialised
+        # per process; the reference has a single process, geo-aware/train.py:16-18).  One broadcast of the bucket.
+        dp.broadcast_bucket(self.flat_p, self.pg)
         # ICK_SPLIT_ALLREDUCE=1: the step as two graphs around two all-reduces (the early half of the bucket travels
         # while the late half is computed).  Measured on one GPU the split itself costs ~130 us (a join in the middle
         # of the backward pass, one more graph launch) and hides ~half of the collective, so it pays off only when
@@ -623,8 +626,92 @@ class TrainStep:
             self._part_a2()
         return g1, static, g2
 
+    # ---- optimizer state in torch.optim.Adam's layout ------------------------------------------
+    def _adam_order(self):
+        """Trainable parameters in the order the reference hands them to torch.optim.Adam
+        (geo-aware/train.py:85-88: filter(requires_grad, decoder.parameters()))."""
+        mine = {id(p) for p in self.params}
+        return [p for p in unique_parameters(self.dec) if id(p) in mine]
+
+    def _slot(self, flat, p):
+        off = (p.data_ptr() - self.flat_p.data_ptr()) // 4
+        return flat[off:off + p.numel()].view(p.shape)
+
+    def state_dict(self):
+        """The optimizer state as torch.optim.Adam.state_dict() would report it (exp_avg / exp_avg_sq / step per
+        parameter, one param group), so checkpoints interchange with the reference's `decoder_optimizer`
+        (geo-aware/utils.py:32-46) and with the fused=False path.  Tensors are copies."""
+        self._check_views()
+        order = self._adam_order()
+        step = float(int(self.counter.item()) & 0xFFFFFFFF)
+        state = {}
+        if step > 0:
+            for i, p in enumerate(order):
+                state[i] = {"step": torch.tensor(step), "exp_avg": self._slot(self.flat_m, p).clone(),
+                            "exp_avg_sq": self._slot(self.flat_v, p).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "params": list(range(len(order)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        """Restore Adam moments, step count (which also positions the dropout stream) and learning rate from a
+        torch.optim.Adam-layout state dict: ours, the reference's, or the fused=False path's."""
+        self._check_views()
+        order = self._adam_order()
+        groups = sd["param_groups"]
+        ids = [i for g in groups for i in g["params"]]
+        if len(ids) != len(order):
+            raise IckError("optimizer state holds %d parameters, the decoder has %d trainable ones" %
+                           (len(ids), len(order)))
+        steps = set()
+        with torch.no_grad():
+            self.flat_m.zero_()
+            self.flat_v.zero_()
+            for pos, i in enumerate(ids):
+                st = sd["state"].get(i)
+                if not st:
+                    continue
+                p = order[pos]
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise IckError("optimizer state %d has shape %s, parameter has %s" %
+                                   (i, tuple(st["exp_avg"].shape), tuple(p.shape)))
+                self._slot(self.flat_m, p).copy_(st["exp_avg"])
+                self._slot(self.flat_v, p).copy_(st["exp_avg_sq"])
+                steps.add(int(float(st["step"])))
+            if len(steps) > 1:
+                raise IckError("per-parameter Adam step counts differ (%s): not representable in the fused step" % steps)
+            self.counter.fill_(steps.pop() if steps else 0)
+        self.lr = float(groups[0]["lr"])
+        self.betas = tuple(groups[0].get("betas", self.betas))
+        self.eps = float(groups[0].get("eps", self.eps))
+        self._graphs.clear()          # lr / betas / eps are baked into the captured optimizer graph
+        self.dec.invalidate_caches()
+
+    def as_torch_optimizer(self):
+        """A live torch.optim.Adam over the decoder's parameters carrying this step's state: what goes into the
+        checkpoint under 'decoder_optimizer', exactly the kind of object the reference pickles there."""
+        opt = torch.optim.Adam(self._adam_order(), lr=self.lr, betas=tuple(self.betas), eps=self.eps)
+        opt.load_state_dict(self.state_dict())
+        return opt
+
+    def set_lr(self, lr):
+        self.lr = float(lr)
+        self._graphs.clear()          # baked into the captured optimizer graph
+
+    def _check_views(self):
+        """The decoder's parameters must still be views of the flat bucket: decoder.to() / .cuda() /
+        load_pretrained_embeddings() re-allocate them and the step would then update memory the module no longer
+        reads (silently).  Two pointer compares per call."""
+        first, last = self.params[0], self.params[-1]
+        lo, hi = self.flat_p.data_ptr(), self.flat_p.data_ptr() + 4 * self.n
+        if first.data_ptr() != lo or not (lo <= last.data_ptr() and last.data_ptr() + 4 * last.numel() <= hi):
+            raise IckError("the decoder's parameters no longer live in TrainStep's bucket (module moved or a "
+                           "Parameter was replaced after TrainStep was built): build a new TrainStep")
+
     def __call__(self, captions, encoder_out, caption_masks, caption_lengths, entities, facts=None):
         dec = self.dec
+        self._check_views()
         encoder_out, entities, facts = dec._prepare_inputs(encoder_out, entities, facts)
         dev = encoder_out.device
         # No length sort and no host round trip here: the loss is a sum over tokens, so the batch order does

@@ -22,7 +22,8 @@ def save_checkpoint(data_name, epoch, epochs_since_improvement, encoder, decoder
     state = dict(epoch=epoch, epochs_since_improvement=epochs_since_improvement, loss=loss, encoder=encoder,
                  decoder=decoder, encoder_optimizer=encoder_optimizer, decoder_optimizer=decoder_optimizer)
     if hasattr(decoder, "__dict__"):
-        for k in ("_graphs", "_kv_pack", "_pred_wt_cache"):      # device-side caches are not part of a checkpoint
+        # device-side caches and pinned staging buffers are not part of a checkpoint
+        for k in ("_graphs", "_kv_pack", "_pred_wt_cache", "_len_pin", "_idx_pin", "_plist", "_pin_ev"):
             decoder.__dict__.pop(k, None)
     name = checkpoint_name(data_name, epoch)
     torch.save(state, os.path.join(out_dir, name))

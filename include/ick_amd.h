@@ -82,6 +82,13 @@ typedef struct {
                                     column sums (LayerNorm gamma/beta partials) ride in an ick_gemm_grouped launch */
 
 int ick_gemm(const ick_gemm_args* args, void* stream);
+/* The kernel configuration ick_gemm would launch for `args` (nothing is launched): workgroup tile, waves per
+ * workgroup, tile grid, K split, operand layouts, 16-byte vector staging.  The parity tests assert through it that
+ * the instantiation a benchmark quotes is the one they compared with the oracle. */
+typedef struct {
+    int32_t tile_m, tile_n, waves, tiles_m, tiles_n, split_k, a_kmajor, b_kmajor, vec;
+} ick_gemm_plan_info;
+int ick_gemm_plan(const ick_gemm_args* args, ick_gemm_plan_info* out);
 /* `count` (<= 64) independent problems; those that select the same kernel configuration share one launch (up to 8
  * per launch).  Used for the weight-gradient GEMMs of a layer (geo-aware/train.py:284 `loss.backward()`), each of
  * which alone is a latency-bound launch of a few hundred workgroups. */

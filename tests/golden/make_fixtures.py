@@ -65,10 +65,12 @@ GRAD_KEYS = [
 ]
 
 
-def forward_case(name, variant, B, L, K, V, Fn, seed, with_stages, with_grads):
+def forward_case(name, variant, B, L, K, V, Fn, seed, with_stages, with_grads, with_enc_grad=False):
     dec, P, wm = build_reference_decoder(variant, V, seed)
     batch = synth.make_batch(variant, B, L, K, V, Fn, seed)
     enc_out = synth.make_enc_out(B, seed)
+    if with_enc_grad:      # fine_tune_encoder=True: the loss gradient reaches Encoder.conv1 through encoder_out
+        enc_out.requires_grad_(True)
     stages = {}
 
     def hook(key):
@@ -120,6 +122,8 @@ def forward_case(name, variant, B, L, K, V, Fn, seed, with_stages, with_grads):
         for k in GRAD_KEYS:
             if k in names and names[k].grad is not None:
                 out["grad::" + k] = names[k].grad.numpy()
+        if with_enc_grad:
+            out["encoder_out_grad"] = enc_out.grad.numpy()       # (B, d, 196), caller's batch order
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print("wrote", name, "scores", scores.shape, "loss" if with_grads else "", out.get("loss"))
 
@@ -157,9 +161,22 @@ def predict_case(name, variant, K, V, Fn, seeds, max_len):
                         seeds=np.array(seeds), max_len=max_len, **res)
 
 
+def round2_cases():
+    """Added in round 2 (the round-1 fixtures are left untouched): a mid-size news case and the gradient that
+    fine_tune_encoder=True sends into the image rows (geo-aware/train.py:93-100,282-294)."""
+    forward_case("fwd_mid_news", "news", B=6, L=14, K=21, V=400, Fn=31, seed=13, with_stages=True, with_grads=True)
+    forward_case("fwd_encgrad_geo", "geo", B=3, L=9, K=7, V=120, Fn=0, seed=17, with_stages=False, with_grads=True,
+                 with_enc_grad=True)
+    forward_case("fwd_encgrad_knowledge", "knowledge", B=2, L=8, K=6, V=90, Fn=7, seed=19, with_stages=False,
+                 with_grads=True, with_enc_grad=True)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(4)
+    if "--round2" in sys.argv:
+        round2_cases()
+        sys.exit(0)
     for v in synth.VARIANTS:
         Fn = 0 if v == "geo" else 5
         forward_case("fwd_tiny_" + v, v, B=4, L=7, K=6, V=50, Fn=Fn, seed=11, with_stages=True, with_grads=True)

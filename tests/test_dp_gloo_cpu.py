@@ -91,3 +91,106 @@ def test_shard_covers_batch():
             spans = [dp.shard(B, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == B
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
+# ----------------------------------------------------------------------------------------------------------
+# train.py's data-parallel plumbing (no HIP kernel involved: buckets, samplers and collectives on the CPU)
+# ----------------------------------------------------------------------------------------------------------
+def _small_decoder(seed):
+    sys.path.insert(0, ROOT)
+    import ick_amd
+    import ick_amd.synth as synth
+    torch.manual_seed(seed)
+    m = ick_amd.load_models("knowledge")
+    return m.DecoderTransformer(synth.make_word_map(40), 300, 512, 512, 10, 1)
+
+
+def _plumbing_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    import ick_amd.dp as dp
+    from ick_amd.training import TrainStep
+    from ick_amd import train as tr
+    dp.init_from_env(backend="gloo")
+    dec = _small_decoder(seed=100 + rank)          # every process draws its own random initialisation
+    before = torch.cat([p.detach().reshape(-1) for p in dec.parameters()]).clone()
+    ts = TrainStep(dec, use_graph=False)            # broadcasts rank 0's bucket
+    after = torch.cat([p.detach().reshape(-1) for p in dec.parameters()])
+    agree = dp.replicas_agree(ts.flat_p)
+    ts.flat_p[5] += float(rank)                     # make the replicas differ
+    disagree = not dp.replicas_agree(ts.flat_p)
+    # samplers: disjoint shards, same number of TRAIN steps on every rank, no VAL sample counted twice
+    ds = list(range(23))
+    samp = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, seed=7)
+    samp.set_epoch(3)
+    mine = list(samp)
+    val = list(tr.ShardSampler(23, rank, world))
+    tot, cnt = dp.reduce_sum_count(10.0 * (rank + 1), 4 + rank)
+    torch.save({"changed": not torch.equal(before, after), "params": after, "agree": agree, "disagree": disagree,
+                "train_idx": mine, "val_idx": val, "tot": tot, "cnt": cnt}, "%s.%d" % (out, rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_broadcast_samplers_and_validation_reduce(tmp_path):
+    out = str(tmp_path / "plumb")
+    mp.spawn(_plumbing_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(r0["params"], r1["params"])            # identical replicas after TrainStep.__init__
+    assert not r0["changed"] and r1["changed"]                # rank 1 took rank 0's weights
+    assert r0["agree"] and r1["agree"] and r0["disagree"] and r1["disagree"]
+    assert len(r0["train_idx"]) == len(r1["train_idx"]) == 12  # equal step counts (padded by wrap-around)
+    assert set(r0["train_idx"]) | set(r1["train_idx"]) == set(range(23))
+    assert len(set(r0["train_idx"]) & set(r1["train_idx"])) <= 1
+    assert sorted(r0["val_idx"] + r1["val_idx"]) == list(range(23))   # disjoint and complete, no padding
+    assert (r0["tot"], r0["cnt"]) == (r1["tot"], r1["cnt"]) == (30.0, 9.0)
+
+
+def test_fused_step_state_is_torch_adam_layout():
+    """TrainStep.state_dict() loads into torch.optim.Adam over the reference's parameter order (and back): the
+    checkpoint's `decoder_optimizer` interchanges between the fused step, the fused=False path and the reference."""
+    sys.path.insert(0, ROOT)
+    from ick_amd.training import TrainStep
+    dec = _small_decoder(seed=1)
+    dec.fine_tune_embeddings(False)      # a frozen parameter must not shift the indices
+    ts = TrainStep(dec, lr=3e-4, use_graph=False)
+    g = torch.Generator().manual_seed(0)
+    ts.flat_m.copy_(torch.randn(ts.n, generator=g))
+    ts.flat_v.copy_(torch.rand(ts.n, generator=g))
+    ts.counter.fill_(7)
+    sd = ts.state_dict()
+    params = [p for p in dec.parameters() if p.requires_grad]      # geo-aware/train.py:85-88
+    opt = torch.optim.Adam(params, lr=1.0)
+    opt.load_state_dict(sd)
+    assert opt.param_groups[0]["lr"] == 3e-4
+    for p in params:
+        st = opt.state[p]
+        assert float(st["step"]) == 7.0 and st["exp_avg"].shape == p.shape
+        assert torch.equal(st["exp_avg"], ts._slot(ts.flat_m, p)) and torch.equal(st["exp_avg_sq"], ts._slot(ts.flat_v, p))
+    # and back, from an optimizer that really stepped (what a reference-written checkpoint holds)
+    for p in params:
+        p.grad = torch.randn(p.shape, generator=g)
+    opt2 = torch.optim.Adam(params, lr=2e-4)
+    snapshot = [p.detach().clone() for p in params]
+    opt2.step(); opt2.step()
+    with torch.no_grad():
+        for p, s0 in zip(params, snapshot):
+            p.copy_(s0)
+    ts2 = TrainStep(dec, use_graph=False)
+    ts2.load_state_dict(opt2.state_dict())
+    assert ts2.lr == 2e-4 and int(ts2.counter.item()) == 2
+    params2 = [p for p in dec.parameters() if p.requires_grad]
+    for p_old, p in zip(params, params2):
+        assert torch.equal(ts2._slot(ts2.flat_m, p), opt2.state[p_old]["exp_avg"])
+    opt3 = ts2.as_torch_optimizer()
+    assert opt3.state_dict()["param_groups"][0]["lr"] == 2e-4
+    # moving the module away from the bucket is detected
+    import pytest
+    from ick_amd.lib import IckError
+    dec.word_embedding.weight = torch.nn.Parameter(dec.word_embedding.weight.detach().clone())
+    dec.fc_vocab.weight = torch.nn.Parameter(dec.fc_vocab.weight.detach().clone())
+    p0 = ts2.params[0]
+    p0.data = p0.data.clone()
+    with pytest.raises(IckError):
+        ts2._check_views()

@@ -8,7 +8,8 @@ from helpers import case_from_golden, load_golden, t
 import ick_amd.synth as synth
 from oracle import restatement as R
 
-FWD = ["fwd_tiny_geo", "fwd_tiny_knowledge", "fwd_tiny_news", "fwd_cfg1_geo", "fwd_mid_geo", "fwd_mid_knowledge"]
+FWD = ["fwd_tiny_geo", "fwd_tiny_knowledge", "fwd_tiny_news", "fwd_cfg1_geo", "fwd_mid_geo", "fwd_mid_knowledge",
+       "fwd_mid_news", "fwd_encgrad_geo", "fwd_encgrad_knowledge"]
 TOL = 2e-5  # fp32, different summation order only
 
 
@@ -39,10 +40,12 @@ def test_forward_scores(name):
 
 
 @pytest.mark.parametrize("name", ["fwd_tiny_geo", "fwd_tiny_knowledge", "fwd_tiny_news", "fwd_mid_geo",
-                                  "fwd_mid_knowledge"])
+                                  "fwd_mid_knowledge", "fwd_mid_news", "fwd_encgrad_geo", "fwd_encgrad_knowledge"])
 def test_loss_and_grads(name):
     g = load_golden(name)
     cfg, P, wm, batch, enc_out = case_from_golden(g)
+    if "encoder_out_grad" in g:
+        enc_out.requires_grad_(True)
     P = {k: v.clone().requires_grad_(True) for k, v in P.items() if not k.startswith("fact_encoder.")}
     if cfg.has_facts:
         P["fact_encoder.predicate_embedding.weight"] = P["predicate_embedding.weight"]
@@ -62,6 +65,9 @@ def test_loss_and_grads(name):
         if k.startswith("grad::"):
             ref = t(g[k])
             assert (P[k[6:]].grad - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item()), k
+    if "encoder_out_grad" in g:      # what fine_tune_encoder=True back-propagates into Encoder.conv1
+        ref = t(g["encoder_out_grad"])
+        assert (enc_out.grad - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
 
 
 def test_conv1():
