@@ -148,6 +148,7 @@ class Encoder(nn.Module):
 class DecoderTransformer(nn.Module):
     variant = "geo"
     use_hip_graphs = True   # inference forward / predict replay a captured hipGraph per input shape
+    fused_decode = True     # predict(): fused per-block decode kernels (csrc/decode.hip) when the sizes allow
 
     def __init__(self, word_map, emb_dim, decoder_dim, encoder_dim, num_heads, num_layers, dropout_dec=0.5,
                  dropout_enc=0.5, dropout_pos=0.1):
@@ -491,12 +492,121 @@ class DecoderTransformer(nn.Module):
             decode_lengths
 
     # ------------------------------------------------------------------ greedy decode (KV cached)
+    def _decode_pack(self):
+        """Transposed out_proj / linear2 weights of the decoder layers for the fused decode kernels (one input
+        feature per row, so a workgroup's slice of the out-projection is read coalesced); cached until a parameter
+        changes."""
+        layers = self.transformer_decoder.layers
+        src = [w for l in layers for w in (l.self_attn.out_proj.weight, l.multihead_attn.out_proj.weight, l.linear2.weight)]
+        key = tuple(w._version for w in src) + tuple(w.data_ptr() for w in src)
+        cache = self.__dict__.get("_dec_pack")
+        if cache is None or cache[0] != key:
+            cache = (key, [w.detach().t().contiguous() for w in src])
+            self.__dict__["_dec_pack"] = cache
+        return cache[1]
+
+    def _decode_ctx(self, kv, ee, fe, rows_per_sample, max_len, S, anc=None, want_scores=False):
+        """lib.DecodeCtx over freshly allocated state buffers for R = B * rows_per_sample rows (+ the tensors, kept
+        alive by the caller).  See include/ick_amd.h (ick_decode_ctx)."""
+        from . import lib as L
+        dev = kv.device
+        d, H, V = self.emb_dim, self.num_heads, self.vocab_size
+        layers = self.transformer_decoder.layers
+        nl = len(layers)
+        B, K = ee.shape[0], ee.shape[1]
+        Fn = fe.shape[1] if fe is not None else 0
+        R = B * rows_per_sample
+        FF = layers[0].linear1.out_features
+        nch = (FF + 63) // 64
+        ntiles = (V + 15) // 16
+        f32 = dict(device=dev, dtype=torch.float32)
+        t = {"x0": torch.empty(R, d, **f32), "xa": torch.empty(R, d, **f32), "xb": torch.empty(R, d, **f32),
+             "xc": torch.empty(R, d, **f32), "p1": torch.empty(R, H, d, **f32), "p2": torch.empty(R, H, d, **f32),
+             "p3": torch.empty(R, nch, d, **f32), "hfin": torch.empty(R, d, **f32), "hv": torch.empty(R, d, **f32),
+             "ptr": torch.empty(R, K + Fn, **f32), "cand": torch.empty(R, ntiles, 4, **f32),
+             "self_kv": torch.empty(nl, 2, R, H, max_len, ops.DHP, **f32),
+             "output": torch.full((R, max_len), self.word_map["<pad>"], dtype=torch.long, device=dev),
+             "hist": torch.zeros(R, max_len, dtype=torch.int32, device=dev),
+             "finished": torch.zeros(R, dtype=torch.int32, device=dev),
+             "n_done": torch.zeros(1, dtype=torch.int32, device=dev),
+             "next_token": torch.zeros(R, dtype=torch.long, device=dev),
+             "next_mask": torch.zeros(R, dtype=torch.long, device=dev),
+             "pack": self._decode_pack(), "kv": kv, "ee": ee, "fe": fe, "anc": anc}
+        if want_scores:
+            t["scores"] = torch.empty(R, V, **f32)
+        if self.has_facts:
+            t["gate"] = torch.empty(R, 1, d, **f32)
+            t["eib"] = torch.empty(R, 1, Fn, **f32)
+            t["cap_buf"] = torch.full((R, max_len), self.word_map["<start>"], dtype=torch.long, device=dev)
+        c = L.DecodeCtx()
+        c.R, c.rows_per_sample, c.d, c.H, c.FF, c.layers, c.S, c.max_len = R, rows_per_sample, d, H, FF, nl, S, max_len
+        c.V, c.K, c.F = V, K, Fn
+        c.end_token, c.pad_token = self.word_map["<end>"], self.word_map["<pad>"]
+        c.ln_eps, c.emb_scale = layers[0].norm1.eps, math.sqrt(d)
+        c.kv_bs = kv.stride(0)
+        seg = H * S * ops.DHP * 4      # bytes per (segment) of the memory projection
+        pk = t["pack"]
+        for li, l in enumerate(layers):
+            w = c.layer[li]
+            w.sa_in_w, w.sa_in_b = l.self_attn.in_proj_weight.data_ptr(), l.self_attn.in_proj_bias.data_ptr()
+            w.sa_out_wt, w.sa_out_b = pk[3 * li].data_ptr(), l.self_attn.out_proj.bias.data_ptr()
+            w.n1_g, w.n1_b = l.norm1.weight.data_ptr(), l.norm1.bias.data_ptr()
+            w.ca_in_w, w.ca_in_b = l.multihead_attn.in_proj_weight.data_ptr(), l.multihead_attn.in_proj_bias.data_ptr()
+            w.ca_out_wt, w.ca_out_b = pk[3 * li + 1].data_ptr(), l.multihead_attn.out_proj.bias.data_ptr()
+            w.n2_g, w.n2_b = l.norm2.weight.data_ptr(), l.norm2.bias.data_ptr()
+            w.w1, w.b1 = l.linear1.weight.data_ptr(), l.linear1.bias.data_ptr()
+            w.w2t, w.b2 = pk[3 * li + 2].data_ptr(), l.linear2.bias.data_ptr()
+            w.n3_g, w.n3_b = l.norm3.weight.data_ptr(), l.norm3.bias.data_ptr()
+            w.self_k, w.self_v = t["self_kv"][li, 0].data_ptr(), t["self_kv"][li, 1].data_ptr()
+            w.cross_k, w.cross_v = kv.data_ptr() + 2 * li * seg, kv.data_ptr() + (2 * li + 1) * seg
+        c.anc = None if anc is None else anc.data_ptr()
+        c.wv, c.bv = self.fc_vocab.weight.data_ptr(), self.fc_vocab.bias.data_ptr()
+        c.we, c.be = self.fc_entity.weight.data_ptr(), self.fc_entity.bias.data_ptr()
+        if self.has_facts:
+            c.wf, c.bf = self.fc_fact.weight.data_ptr(), self.fc_fact.bias.data_ptr()
+            c.fe, c.gate, c.eib, c.cap_buf = fe.data_ptr(), t["gate"].data_ptr(), t["eib"].data_ptr(), t["cap_buf"].data_ptr()
+        c.ee = ee.data_ptr()
+        c.word_emb, c.pe = self.word_embedding.weight.data_ptr(), self.pos_encoder.pe.data_ptr()
+        for name in ("x0", "xa", "xb", "xc", "p1", "p2", "p3", "hfin", "hv", "ptr", "cand", "output", "hist", "finished",
+                     "n_done", "next_token", "next_mask"):
+            setattr(c, name, t[name].data_ptr())
+        if want_scores:
+            c.scores, c.scores_ld = t["scores"].data_ptr(), V
+        return c, t
+
+    def _predict_fused(self, enc_tok, entities, facts, max_pred_len):
+        """predict() on the fused decode kernels (csrc/decode.hip): 12 launches per token (13 with facts)."""
+        B = enc_tok.shape[0]
+        d, V, K = self.emb_dim, self.vocab_size, entities.shape[1]
+        ee, fe, kv, _, side = self._encode_context(enc_tok, entities, facts, None)
+        side.join()
+        S = kv.shape[3]
+        c, t = self._decode_ctx(kv, ee, fe, 1, max_pred_len, S)
+        dev = enc_tok.device
+        tok = torch.full((B, 1), self.word_map["<start>"], dtype=torch.long, device=dev)
+        msk = torch.zeros(B, 1, dtype=torch.long, device=dev)
+        pe = self.pos_encoder.pe.view(-1, d)
+        x0 = ops.caption_embed(tok, msk, self.word_embedding.weight.detach(), ee, fe, pe, V, self.word_map["<pad>"],
+                               math.sqrt(d), pos0=0)
+        t["x0"].copy_(x0.view(B, d))
+        for i in range(max_pred_len):
+            if self.has_facts:
+                ops.context_indicators(t["cap_buf"], facts, K, V, self._pred_wt(), self.fc_predicate.bias.detach(),
+                                       mode=1, eib=t["eib"], gate=t["gate"])
+            ops.decode_layers(c, i)
+            ops.decode_select_greedy(c, i)
+        return t["output"]
+
     def _predict_device(self, enc_tok, entities, facts, max_pred_len):
         """Whole greedy decode on the device: every step's token choice, clean-up and stop flag are computed
         by kernels (no host round trip), so the loop can be captured as one hipGraph."""
         dev = enc_tok.device
         B = enc_tok.shape[0]
         d, V, K = self.emb_dim, self.vocab_size, entities.shape[1]
+        S_all = enc_tok.shape[1] + K + (facts.shape[1] if facts is not None else 0)
+        FF = self.transformer_decoder.layers[0].linear1.out_features
+        if self.fused_decode and ops.decode_supported(d, self.num_heads, FF, S_all, max_pred_len):
+            return self._predict_fused(enc_tok, entities, facts, max_pred_len)
         ee, fe, kv, _, side = self._encode_context(enc_tok, entities, facts, None)
         side.join()
         S = kv.shape[3]

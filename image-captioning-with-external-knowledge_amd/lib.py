@@ -63,6 +63,30 @@ class AttnBwdArgs(C.Structure):
     ]
 
 
+class DecodeLayer(C.Structure):
+    _fields_ = [(n, vp) for n in ("sa_in_w", "sa_in_b", "sa_out_wt", "sa_out_b", "n1_g", "n1_b",
+                                  "ca_in_w", "ca_in_b", "ca_out_wt", "ca_out_b", "n2_g", "n2_b",
+                                  "w1", "b1", "w2t", "b2", "n3_g", "n3_b", "self_k", "self_v", "cross_k", "cross_v")]
+
+
+MAX_LAYERS = 8
+
+
+class DecodeCtx(C.Structure):
+    _fields_ = ([(n, i32) for n in ("R", "rows_per_sample", "d", "H", "FF", "layers", "S", "max_len", "V", "K", "F",
+                                    "end_token", "pad_token")] +
+                [("ln_eps", f32), ("emb_scale", f32), ("kv_bs", i64), ("scores_ld", i64),
+                 ("layer", DecodeLayer * MAX_LAYERS)] +
+                [(n, vp) for n in ("anc", "wv", "bv", "we", "be", "wf", "bf", "ee", "fe", "gate", "eib", "word_emb", "pe",
+                                   "x0", "xa", "xb", "xc", "p1", "p2", "p3", "hfin", "hv", "ptr", "cand", "scores",
+                                   "output", "hist", "finished", "n_done", "next_token", "next_mask", "cap_buf")])
+
+
+class BeamState(C.Structure):
+    _fields_ = [(n, vp) for n in ("cum", "fin", "seq_in", "seq_out", "anc_in", "anc_out", "cap_in", "cap_out")] + \
+               [("start_token", i32)]
+
+
 # name -> argtypes; every entry returns int (0 ok, <0 ICK_E*, >0 hipError_t)
 SIGNATURES = {
     "ick_version": [],
@@ -83,6 +107,10 @@ SIGNATURES = {
     "ick_greedy_update": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "ick_greedy_select": [vp, i64, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "ick_packed_ce": [vp, i64, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp],
+    "ick_decode_supported": [i32, i32, i32, i32, i32],
+    "ick_decode_layers": [C.POINTER(DecodeCtx), i32, vp],
+    "ick_decode_select_greedy": [C.POINTER(DecodeCtx), i32, vp],
+    "ick_decode_select_beam": [C.POINTER(DecodeCtx), C.POINTER(BeamState), i32, vp],
     "ick_attention_bwd": [C.POINTER(AttnBwdArgs), vp],
     "ick_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, f32, u32, u32, vp, vp, vp],
     "ick_layernorm_bwd_rows_per_block": [],
@@ -103,6 +131,8 @@ SIGNATURES = {
 }
 
 _lib = None
+PROFILE = None     # profiling.start() / stop(): list of (class, work, unit, event, event) while enabled
+_proxy = None
 
 
 class IckError(RuntimeError):
@@ -110,7 +140,12 @@ class IckError(RuntimeError):
 
 
 def load():
-    """Load (once) and return the shared library; raises if it has not been built."""
+    """The shared library (loaded on first use); raises if it has not been built.  While profiling.start() is in
+    effect a proxy that brackets every launch with HIP events is returned instead."""
+    return _proxy if _proxy is not None else load_raw()
+
+
+def load_raw():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):

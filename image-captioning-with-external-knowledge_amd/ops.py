@@ -273,16 +273,17 @@ def caption_embed(captions, masks, word_emb, entities_encoded, facts_encoded, pe
     return (out, emb) if want_emb else out
 
 
-def context_indicators(captions, facts, K, V, fc_pred_wt=None, fc_pred_b=None, mode=0):
+def context_indicators(captions, facts, K, V, fc_pred_wt=None, fc_pred_b=None, mode=0, eib=None, gate=None):
     B, Lc = captions.shape
     F = facts.shape[1]
     T = Lc if mode == 0 else 1
-    eib = torch.empty(B, T, F, device=captions.device, dtype=torch.float32)
-    gate = None
+    if eib is None:
+        eib = torch.empty(B, T, F, device=captions.device, dtype=torch.float32)
     num_pred = d = 0
     if fc_pred_wt is not None:
         num_pred, d = fc_pred_wt.shape
-        gate = torch.empty(B, T, d, device=captions.device, dtype=torch.float32)
+        if gate is None:
+            gate = torch.empty(B, T, d, device=captions.device, dtype=torch.float32)
     L.check(L.load().ick_context_indicators(_p(captions), _p(facts), _p(fc_pred_wt), _p(fc_pred_b), _p(eib),
                                             _p(gate), B, Lc, T, K, F, V, num_pred, d, mode, _stream()),
             "ick_context_indicators")
@@ -325,6 +326,19 @@ def greedy_update(best, second, output, hist, finished, next_token, next_mask, s
     L.check(L.load().ick_greedy_update(_p(best), _p(second), _p(output), _p(hist), _p(finished), _p(next_token),
                                        _p(next_mask), B, step, max_len, V, K, int(has_facts), end_token, _stream()),
             "ick_greedy_update")
+
+
+def decode_supported(d, H, FF, S, max_len):
+    return bool(L.load().ick_decode_supported(d, H, FF, S, max_len))
+
+
+def decode_layers(ctx, pos):
+    """Decoder stack + score head of one KV-cached decode step (ick_decode_layers); ctx: lib.DecodeCtx."""
+    L.check(L.load().ick_decode_layers(C.byref(ctx), pos, _stream()), "ick_decode_layers")
+
+
+def decode_select_greedy(ctx, pos):
+    L.check(L.load().ick_decode_select_greedy(C.byref(ctx), pos, _stream()), "ick_decode_select_greedy")
 
 
 def packed_ce(scores, captions_sorted, decode_len, pad_token, want_grad=False, out_sum=None, out_count=None):

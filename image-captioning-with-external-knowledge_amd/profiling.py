@@ -1,0 +1,126 @@
+"""Per-entry-point timing of the C ABI with HIP events (bench.py's `roofline.by_kernel`, tools/).
+
+While `lib.PROFILE` is a list, every ick_* call that takes a stream is bracketed by two events recorded on torch's
+current stream -- the stream the kernels are launched on -- and classified by `classify()` into a kernel class
+with its ALGORITHMIC work (FLOP for matrix-core kernels, bytes for streaming kernels).  Meant for eager passes on
+one stream (hipGraph replays do not go through the Python wrappers); `summarise()` turns the records into rows
+{name, launches_per_step, avg_us, us_per_step, work_per_launch, unit, achieved, peak, frac, bound}."""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
+PEAK_HBM_GBS = 8000.0             # HBM3E spec
+
+
+def _struct(arg):
+    return arg._obj if hasattr(arg, "_obj") else arg
+
+
+def _gemm_label(a):
+    lay = ("A k-major" if (a.a_rs == 1 and a.a_ks != 1) else "A row-major") + ", " + \
+          ("B k-major" if (a.b_rs == 1 and a.b_ks != 1) else "B row-major")
+    return "%dx%dx%d (%s%s)" % (a.M, a.N, a.K, lay, ", split-K %d" % a.split_k if a.split_k > 1 else "")
+
+
+def classify(name, args):
+    """-> (class label, work per launch, 'flop' | 'byte' | None)."""
+    if name == "ick_gemm":
+        a = _struct(args[0])
+        fl = 2.0 * a.M * a.N * a.K
+        if fl >= 2e9:
+            return "GEMM " + _gemm_label(a), fl, "flop"
+        return "chain GEMMs (< 2 GFLOP each: projections, FFN, their data gradients)", fl, "flop"
+    if name == "ick_gemm_grouped":
+        arr, n = args[0], args[1]
+        fl = 0.0
+        for i in range(n):
+            a = arr[i]
+            if not (a.flags & L.GEMM_COLSUM_ONLY):
+                fl += 2.0 * a.M * a.N * a.K
+        return "grouped weight-gradient GEMMs", fl, "flop"
+    if name == "ick_attention":
+        a = _struct(args[0])
+        return "attention forward (T=%d)" % a.T if a.T > 1 else "attention decode step", 4.0 * a.B * a.H * a.T * a.S * a.dh, "flop"
+    if name == "ick_attention_bwd":
+        a = _struct(args[0])
+        return "attention backward", 10.0 * a.B * a.H * a.T * a.S * a.dh, "flop"
+    if name == "ick_add_layernorm":
+        rows, d = args[5], args[6]
+        return "residual + LayerNorm", 4.0 * rows * d * 3, "byte"
+    if name == "ick_layernorm_bwd":
+        rows, d = args[9], args[10]
+        return "LayerNorm backward", 4.0 * rows * d * 5, "byte"
+    if name == "ick_packed_ce":
+        B, Lc, Vx = args[4], args[5], args[6]
+        return "packed cross entropy (+ gradient)", 4.0 * B * Lc * Vx * (2 if args[11] else 1), "byte"
+    if name == "ick_adam_clamp":
+        return "clamp + Adam", 4.0 * args[4] * 7, "byte"
+    if name == "ick_decode_layers":
+        c = _struct(args[0])
+        kv = 4.0 * c.R * c.layers * 2 * c.H * c.S * 32
+        w = 4.0 * (c.layers * (4 * c.d * c.d + 2 * c.d * c.d + 2 * c.d * c.FF) + c.V * c.d)
+        return "fused decode step (3 kernels / layer + head + vocabulary)", kv + w, "byte"
+    if name == "ick_decode_select_greedy":
+        return "greedy selection + next-token embedding", None, None
+    return name[4:].replace("_", " "), None, None
+
+
+class _Profiled:
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        argtypes = L.SIGNATURES.get(name)
+        if L.PROFILE is None or not argtypes or argtypes[-1] is not L.vp:      # only entries that take a stream
+            return fn
+
+        def timed(*args):
+            label, work, unit = classify(name, args)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            L.PROFILE.append((label, work, unit, e0, e1))
+            return rc
+        return timed
+
+
+def start():
+    L.PROFILE = []
+    L._proxy = _Profiled(L.load_raw())
+
+
+def stop():
+    rec, L.PROFILE = L.PROFILE, None
+    L._proxy = None
+    return rec
+
+
+def summarise(records, steps):
+    torch.cuda.synchronize()
+    rows = {}
+    for label, work, unit, e0, e1 in records:
+        r = rows.setdefault(label, {"name": label, "launches": 0, "us": 0.0, "work": 0.0, "unit": unit})
+        r["launches"] += 1
+        r["us"] += e0.elapsed_time(e1) * 1e3
+        if work is not None:
+            r["work"] += work
+    out = []
+    for r in rows.values():
+        n = r["launches"]
+        row = {"name": r["name"], "launches_per_step": n / steps, "avg_us": r["us"] / n, "us_per_step": r["us"] / steps}
+        if r["unit"] == "flop" and r["us"] > 0:
+            ach = r["work"] / (r["us"] * 1e-6) / 1e12
+            row.update(work_per_launch=r["work"] / n, unit="TFLOP/s", achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS,
+                       frac=ach / PEAK_FP32_MFMA_TFLOPS, bound="mfma")
+        elif r["unit"] == "byte" and r["us"] > 0:
+            ach = r["work"] / (r["us"] * 1e-6) / 1e9
+            row.update(work_per_launch=r["work"] / n, unit="GB/s", achieved=ach, peak=PEAK_HBM_GBS,
+                       frac=ach / PEAK_HBM_GBS, bound="hbm")
+        out.append(row)
+    out.sort(key=lambda x: -x["us_per_step"])
+    return out

@@ -23,7 +23,7 @@ def save_checkpoint(data_name, epoch, epochs_since_improvement, encoder, decoder
                  decoder=decoder, encoder_optimizer=encoder_optimizer, decoder_optimizer=decoder_optimizer)
     if hasattr(decoder, "__dict__"):
         # device-side caches and pinned staging buffers are not part of a checkpoint
-        for k in ("_graphs", "_kv_pack", "_pred_wt_cache", "_len_pin", "_idx_pin", "_plist", "_pin_ev"):
+        for k in ("_graphs", "_kv_pack", "_pred_wt_cache", "_len_pin", "_idx_pin", "_plist", "_pin_ev", "_dec_pack"):
             decoder.__dict__.pop(k, None)
     name = checkpoint_name(data_name, epoch)
     torch.save(state, os.path.join(out_dir, name))

@@ -204,6 +204,69 @@ int ick_greedy_select(const float* scores, int64_t ld, int32_t B, int32_t Vx, in
                       int32_t* finished, int64_t* next_token, int64_t* next_mask, int32_t step, int32_t max_len,
                       int32_t V, int32_t K, int32_t has_facts, int32_t end_token, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused decode step of predict() (geo-aware/models.py:389-443; knowledge-aware/models.py:545-608): one token
+ * for R independent rows (R = captions x rows_per_sample; rows_per_sample > 1 = beams sharing their caption's
+ * memory) in 3 launches per decoder layer + 2 (ick_decode_layers) + 1 (ick_decode_select_*), KV-cached.
+ * A block's closing residual + LayerNorm is applied by the NEXT kernel while it loads its input row (see
+ * csrc/decode.hip); partial out-projection rows travel through p1 / p2 / p3.  out_wt / w2t are the TRANSPOSED
+ * out_proj / linear2 weights ((in_features, d) row-major).  All buffers are caller-owned device memory. */
+typedef struct {
+    const float *sa_in_w, *sa_in_b, *sa_out_wt, *sa_out_b, *n1_g, *n1_b;   /* self_attn, norm1 */
+    const float *ca_in_w, *ca_in_b, *ca_out_wt, *ca_out_b, *n2_g, *n2_b;   /* multihead_attn (q rows used), norm2 */
+    const float *w1, *b1, *w2t, *b2, *n3_g, *n3_b;                         /* linear1, linear2, norm3 */
+    float *self_k, *self_v;           /* (R, H, max_len, 32) key / value cache of the caption positions */
+    const float *cross_k, *cross_v;   /* this layer's key / value segment of the (B, 2*layers, H, S, 32) memory projection */
+} ick_decode_layer;
+
+typedef struct {
+    int32_t R, rows_per_sample, d, H, FF, layers, S, max_len, V, K, F;
+    int32_t end_token, pad_token;
+    float ln_eps, emb_scale;          /* LayerNorm eps; sqrt(emb_dim) */
+    int64_t kv_bs, scores_ld;         /* sample stride of the memory projection; row stride of `scores` */
+    ick_decode_layer layer[ICK_MAX_LAYERS];
+    const int32_t* anc;               /* optional (R, max_len): cache row holding position p of row r (beam search) */
+    const float *wv, *bv, *we, *be, *wf, *bf;   /* fc_vocab, fc_entity, fc_fact (wf / bf NULL without facts) */
+    const float *ee, *fe;             /* entities_encoded (B, K, d), facts_encoded (B, F, d) */
+    const float *gate, *eib;          /* knowledge variants: (R, d) predicate gate and (R, F) indicator of this step */
+    const float *word_emb, *pe;       /* word embedding (V, d), sinusoid table (>= max_len, d) */
+    float *x0;                        /* (R, d) embedded input token of this step; select writes the next one */
+    float *xa, *xb, *xc;              /* (R, d) residual rows between the blocks */
+    float *p1, *p2, *p3;              /* (R, H, d), (R, H, d), (R, ceil(FF/64), d) partial out-projections */
+    float *hfin, *hv;                 /* (R, d) decoder output h and h * gate */
+    float *ptr;                       /* (R, K+F) pointer scores */
+    float *cand;                      /* (R, ceil(V/16), 4) per-tile top-2 candidates {v1, idx1, v2, idx2} */
+    float *scores;                    /* optional (R, scores_ld) vocabulary logits */
+    int64_t *output;                  /* (R, max_len) generated tokens, pre-filled with <pad> */
+    int32_t *hist, *finished, *n_done;/* (R, max_len) runner-ups; (R) ended flags; (1) number of ended rows */
+    int64_t *next_token, *next_mask;  /* (R) */
+    int64_t *cap_buf;                 /* optional (R, max_len) caption buffer read by ick_context_indicators */
+} ick_decode_ctx;
+
+/* 1 when the fused path handles these sizes (d % 4 == 0, 64 <= d <= 320, head width <= 32, S <= 1024,
+ * max_len <= 128); callers fall back to the per-op launches otherwise. */
+int ick_decode_supported(int32_t d, int32_t H, int32_t FF, int32_t S, int32_t max_len);
+/* Decoder stack + score head for position `pos`: reads x0, leaves ptr / cand (/ scores / hfin). */
+int ick_decode_layers(const ick_decode_ctx* ctx, int32_t pos, void* stream);
+/* Greedy selection + predict()'s bookkeeping + embedding of the next input token into x0 (models.py:410-442). */
+int ick_decode_select_greedy(const ick_decode_ctx* ctx, int32_t pos, void* stream);
+
+/* Beam selection of one step (beam = ctx->rows_per_sample <= 8 hypotheses per caption, rows b*beam..): every live
+ * hypothesis offers log_softmax(scores) + its cumulative log-probability for each of the V+K+F tokens, an ended one
+ * offers itself unchanged; the best `beam` candidates of a caption (ties: lower hypothesis, lower token) become its
+ * new rows.  Token histories, caption buffers and the cache-ancestry table (which cache row holds position p of row
+ * r: ick_decode_ctx.anc of the NEXT step) are copied from the chosen parents (double buffered).  Needs ctx->scores.
+ * The reference has no beam search (geo-aware/eval.py:61,83 decodes greedily): parity-unpinned; beam 1 is routed
+ * to the pinned greedy path by the Python caller. */
+typedef struct {
+    float* cum; int32_t* fin;                       /* (R) cumulative log-probability (-inf: unused slot), ended flag */
+    const int64_t* seq_in; int64_t* seq_out;        /* (R, max_len) */
+    const int32_t* anc_in; int32_t* anc_out;        /* (R, max_len) */
+    const int64_t* cap_in; int64_t* cap_out;        /* optional (R, max_len) */
+    int32_t start_token;
+} ick_beam_state;
+int ick_decode_select_beam(const ick_decode_ctx* ctx, const ick_beam_state* beam, int32_t pos, void* stream);
+
 /* fused token-mean cross entropy over the packed rows of train.py
  * (pack_padded_sequence + CrossEntropyLoss(ignore_index=<pad>), geo-aware/train.py:275-281):
  * rows (b,t) with t < decode_len[b] and target != pad contribute.  Writes loss_sum[0] (sum of

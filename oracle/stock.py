@@ -93,3 +93,48 @@ class StockDecoder(nn.Module):
         if cfg.has_facts:
             outs.append(self.fc_fact(h.unsqueeze(2) * fe.unsqueeze(0) * eib.permute(1, 0, 2).unsqueeze(3)).squeeze(3))
         return torch.cat(outs, dim=2).permute(1, 0, 2), captions, decode_lengths
+
+    @torch.no_grad()
+    def predict(self, enc_out, max_pred_len, entities, facts=None):
+        """Greedy decode with the reference's structure (geo-aware/models.py:363-443): batch 1, NO KV cache -- the
+        whole decoder stack runs over all max_pred_len positions at every step -- softmax, argmax, runner-up,
+        n-gram clean-up.  This is what bench.py times as the CPU baseline of the greedy mode."""
+        cfg = self.cfg
+        assert enc_out.shape[0] == 1
+        V, K = cfg.vocab_size, entities.shape[1]
+        P = self._params()
+        ee = R.entity_encode(cfg, P, entities, facts)
+        fe = R.fact_encode(P, facts, ee) if cfg.has_facts else None
+        parts = [enc_out.permute(2, 0, 1), self.transformer_encoder_entities(ee.permute(1, 0, 2))]
+        if cfg.has_facts:
+            parts.append(self.transformer_encoder_facts(fe.permute(1, 0, 2)))
+        mem = torch.cat(parts)
+        captions = torch.full((1, max_pred_len), cfg.start, dtype=torch.long)
+        masks = torch.zeros(1, max_pred_len, dtype=torch.long)
+        output = [cfg.pad] * max_pred_len
+        prev_top_two = []
+        mask = torch.full((max_pred_len, max_pred_len), float("-inf")).triu(1)
+        for i in range(max_pred_len):
+            emb = R.caption_embed(cfg, P, captions, masks, ee, fe)
+            x = emb.permute(1, 0, 2) * math.sqrt(cfg.emb_dim) + self.pe[:max_pred_len].unsqueeze(1)
+            h = self.transformer_decoder(x, mem, mask)[i:i + 1]           # (1, 1, d)
+            if cfg.has_facts:
+                eib, pi = R.context_indicators(cfg, captions, facts, K, 1)
+                vocab = self.fc_vocab(h * self.fc_predicate(pi).permute(1, 0, 2))
+            else:
+                vocab = self.fc_vocab(h)
+            outs = [vocab, self.fc_entity(h.unsqueeze(2) * ee.unsqueeze(0)).squeeze(3)]
+            if cfg.has_facts:
+                outs.append(self.fc_fact(h.unsqueeze(2) * fe.unsqueeze(0) * eib.permute(1, 0, 2).unsqueeze(3)).squeeze(3))
+            prob = torch.cat(outs, dim=2)[0, 0].softmax(dim=-1)
+            out = int(prob.argmax())
+            output[i] = out
+            if out == cfg.end:
+                break
+            prev_top_two.append(int(prob.topk(2).indices[1]))
+            R.loop_cleanup(output, prev_top_two, i)
+            out = output[i]
+            if i < max_pred_len - 1:
+                captions[0, i + 1] = out
+                masks[0, i + 1] = 2 if (cfg.has_facts and out >= V + K) else (1 if out >= V else 0)
+        return torch.tensor(output, dtype=torch.long).view(max_pred_len, 1)

@@ -1,0 +1,95 @@
+"""The fused decode step (csrc/decode.hip: 3 launches per decoder layer + 3 for the score head) against the CPU
+oracle's full-recompute predict() (geo-aware/models.py:389-443): per-step scores within 2e-4, tokens identical;
+and against the per-op launch sequence it replaces."""
+import math
+
+import pytest
+import torch
+
+import ick_amd
+import ick_amd.synth as synth
+from oracle import restatement as R
+from test_forward_gpu import build_decoder
+
+pytestmark = pytest.mark.gpu
+
+
+def fused_steps(dec, enc_out, ents, facts, max_len):
+    """Drive ick_decode_layers / ick_decode_select_greedy step by step, keeping every step's score row."""
+    import ick_amd.ops as ops
+    enc_out, ents, facts = dec._prepare_inputs(enc_out, ents, facts)
+    enc_tok = dec._token_major(enc_out).contiguous()
+    B, d, V, K = enc_tok.shape[0], dec.emb_dim, dec.vocab_size, ents.shape[1]
+    ee, fe, kv, _, side = dec._encode_context(enc_tok, ents.contiguous(), facts, None)
+    side.join()
+    c, t = dec._decode_ctx(kv, ee, fe, 1, max_len, kv.shape[3], want_scores=True)
+    tok = torch.full((B, 1), dec.word_map["<start>"], dtype=torch.long, device="cuda")
+    x0 = ops.caption_embed(tok, torch.zeros_like(tok), dec.word_embedding.weight.detach(), ee, fe,
+                           dec.pos_encoder.pe.view(-1, d), V, dec.word_map["<pad>"], math.sqrt(d), pos0=0)
+    t["x0"].copy_(x0.view(B, d))
+    rows = []
+    for i in range(max_len):
+        if dec.has_facts:
+            ops.context_indicators(t["cap_buf"], facts, K, V, dec._pred_wt(), dec.fc_predicate.bias.detach(), mode=1,
+                                   eib=t["eib"], gate=t["gate"])
+        ops.decode_layers(c, i)
+        rows.append(torch.cat([t["scores"], t["ptr"]], dim=1).clone())
+        ops.decode_select_greedy(c, i)
+    return t["output"].clone(), torch.stack(rows, dim=1), t     # (B, max_len), (B, max_len, Vx)
+
+
+@pytest.mark.parametrize("variant,K,V,Fn,max_len,seed", [("geo", 6, 50, 0, 12, 3), ("knowledge", 6, 50, 5, 12, 1),
+                                                         ("news", 7, 90, 6, 10, 2), ("geo", 20, 1000, 0, 20, 5),
+                                                         ("knowledge", 20, 3000, 51, 33, 7)])
+def test_fused_decode_scores_and_tokens_vs_oracle(variant, K, V, Fn, max_len, seed):
+    B = 3
+    P = synth.make_params(variant, V, seed)
+    dec = build_decoder(variant, V, P)
+    ents = synth.make_entities(variant, B, K, V, seed)
+    facts = synth.make_facts(variant, B, Fn, K, seed) if variant != "geo" else None
+    enc_out = synth.make_enc_out(B, seed)
+    out, scores, t = fused_steps(dec, enc_out.cuda(), ents, None if facts is None else facts.cuda(), max_len)
+    cfg = R.config_from_word_map(variant, synth.make_word_map(V))
+    for b in range(B):
+        with torch.no_grad():
+            seq, ref = R.predict(cfg, P, enc_out[b:b + 1], max_len, ents[b:b + 1], None if facts is None else facts[b:b + 1],
+                                 return_scores=True)
+        n = ref.shape[0]                     # the oracle stops at <end>
+        err = (scores[b, :n].cpu() - ref).abs().max().item()
+        assert err < 2e-4, (variant, b, err)
+        assert out[b].cpu().tolist() == seq.view(-1).tolist(), (variant, b)
+    # every kernel of a step after the last caption ended returns at once: the ended-row counter says so
+    assert int(t["n_done"].item()) == int(t["finished"].sum().item())
+
+
+def test_fused_decode_equals_per_op_path_and_graph_replay():
+    variant, B, K, V, Fn, max_len, seed = "knowledge", 5, 9, 300, 11, 14, 4
+    P = synth.make_params(variant, V, seed)
+    dec = build_decoder(variant, V, P)
+    ents = synth.make_entities(variant, B, K, V, seed)
+    facts = synth.make_facts(variant, B, Fn, K, seed).cuda()
+    enc = synth.make_enc_out(B, seed).cuda()
+    res = {}
+    for fused in (False, True):
+        for graphs in (False, True):
+            dec.fused_decode, dec.use_hip_graphs = fused, graphs
+            res[(fused, graphs)] = dec.predict(enc, max_len, ents, facts).clone()
+            again = dec.predict(enc, max_len, ents, facts)                  # replay / second eager run
+            assert torch.equal(res[(fused, graphs)], again)
+    ref = res[(False, False)]
+    for k, v in res.items():
+        assert torch.equal(v, ref), k
+    dec.fused_decode, dec.use_hip_graphs = True, True
+
+
+def test_fused_decode_early_exit_keeps_pad_after_end():
+    """A vocabulary bias that makes <end> the first choice: every caption ends at step 0, the remaining steps are
+    no-ops and the output keeps <pad> after <end> (geo-aware/models.py:386,414-416)."""
+    variant, B, K, V, max_len, seed = "geo", 4, 6, 50, 9, 2
+    P = synth.make_params(variant, V, seed)
+    P["fc_vocab.bias"] = P["fc_vocab.bias"].clone()
+    P["fc_vocab.bias"][V - 1] += 50.0
+    dec = build_decoder(variant, V, P)
+    seq = dec.predict(synth.make_enc_out(B, seed).cuda(), max_len, synth.make_entities(variant, B, K, V, seed))
+    assert seq.shape == (max_len, B)
+    assert (seq[0] == V - 1).all() and (seq[1:] == 0).all()

@@ -119,3 +119,19 @@ def test_stock_module_port_matches_reference(name):
                              batch["entities"], batch.get("facts"))
     assert dl == g["decode_lengths"].tolist()
     assert (scores - t(g["scores"])).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("name", ["predict_geo", "predict_knowledge"])
+def test_stock_module_predict_matches_reference(name):
+    """oracle/stock.py's full-recompute greedy decode (bench.py's CPU baseline of the greedy mode)."""
+    from oracle.stock import StockDecoder
+    g = load_golden(name)
+    variant = str(g["variant"])
+    K, V, Fn, max_len = int(g["K"]), int(g["V"]), int(g["F"]), int(g["max_len"])
+    wm = synth.make_word_map(V)
+    for seed in g["seeds"].tolist()[:4]:
+        m = StockDecoder(variant, wm).load_reference_params(synth.make_params(variant, V, seed)).eval()
+        ents = synth.make_entities(variant, 1, K, V, seed)
+        facts = synth.make_facts(variant, 1, Fn, K, seed) if variant != "geo" else None
+        seq = m.predict(synth.make_enc_out(1, seed), max_len, ents, facts)
+        assert seq.view(-1).tolist() == g["seq_%d" % seed].reshape(-1).tolist(), (name, seed)
