@@ -28,6 +28,21 @@
 // depend on it), so a kernel is ~3 memory round trips long.
 #include "common.h"
 
+// Diagnostic build (-DICK_DECODE_STAMPS, tools/debug/decode_stamps.py): workgroup (0, 0) of every decode kernel
+// records the shader clock at its phase boundaries.  Compiled out of the product library.
+#ifdef ICK_DECODE_STAMPS
+__device__ unsigned long long ick_stamps[8][16];
+#define ICK_STAMP(kern, i)                                                                          \
+    do {                                                                                            \
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) ick_stamps[kern][i] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+extern "C" int ick_debug_read_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ick_stamps), sizeof(ick_stamps));
+}
+#else
+#define ICK_STAMP(kern, i)
+#endif
+
 namespace ick {
 namespace {
 
@@ -49,32 +64,38 @@ struct RowSrc {
 };
 
 // x = LayerNorm(res + bias + sum partials) (or res itself) -> xs[0..kDMax) in LDS, zero beyond d.
+// Every load is issued before the first add (a `for (p < nparts)` load-add loop waits for each load in turn:
+// ten dependent L2 round trips per kernel); the partial rows are then summed in index order.
+constexpr int kPartsMax = 16;
 __device__ __forceinline__ void load_row(const RowSrc& s, int64_t row, int d, float* xs, float* red, bool writer) {
     const int tid = threadIdx.x;
     float v[2];
+    float pv[2][kPartsMax], bs[2] = {0.f, 0.f}, gm[2] = {0.f, 0.f}, bt[2] = {0.f, 0.f};
+    const int np = s.nparts;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        const int c = tid + 256 * e;
-        v[e] = 0.f;
-        if (c < d) {
-            float t = s.res[row * d + c];
-            if (s.nparts > 0) {
-                t += s.bias[c];
-                for (int p = 0; p < s.nparts; ++p) t += s.part[(row * s.nparts + p) * d + c];
-            }
-            v[e] = t;
+        const int c = min(tid + 256 * e, d - 1);
+        v[e] = s.res[row * d + c];
+        if (np > 0) {
+            bs[e] = s.bias[c]; gm[e] = s.gamma[c]; bt[e] = s.beta[c];
+#pragma unroll
+            for (int p = 0; p < kPartsMax; ++p) pv[e][p] = s.part[(row * np + min(p, np - 1)) * d + c];
         }
     }
-    if (s.nparts > 0) {
+    if (np > 0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float t = v[e] + bs[e];
+#pragma unroll
+            for (int p = 0; p < kPartsMax; ++p) t += p < np ? pv[e][p] : 0.f;
+            v[e] = tid + 256 * e < d ? t : 0.f;
+        }
         const float mean = block_sum<4>(v[0] + v[1], red) / (float)d;
         const float t0 = tid < d ? v[0] - mean : 0.f, t1 = tid + 256 < d ? v[1] - mean : 0.f;
         const float var = block_sum<4>(fmaf(t0, t0, t1 * t1), red) / (float)d;
         const float rstd = rsqrtf(var + s.eps);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int c = tid + 256 * e;
-            if (c < d) v[e] = (v[e] - mean) * rstd * s.gamma[c] + s.beta[c];
-        }
+        for (int e = 0; e < 2; ++e) v[e] = (v[e] - mean) * rstd * gm[e] + bt[e];
     }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -323,6 +344,7 @@ __global__ __launch_bounds__(256) void dec_cross_kernel(CrossArgs a) {
     const int64_t r = blockIdx.y;
     const int d = a.d, d4 = d >> 2, dh = a.dh, S = a.S;
     auto rowidx = [&](int rr) { return h * dh + rr; };
+    ICK_STAMP(1, 0);
     RowDot<2> qd;
     qd.load(a.w.in_w, d, rowidx, dh, d4);
     ColDot<11> od;
@@ -343,11 +365,14 @@ __global__ __launch_bounds__(256) void dec_cross_kernel(CrossArgs a) {
         const int p = min(32 * q + p8, S - 1);
         vreg[q] = *reinterpret_cast<const float4*>(Vb + (int64_t)p * kDhp + 4 * c);
     }
+    ICK_STAMP(1, 1);
     load_row(a.w.src, r, d, xs, red, h == 0);
+    ICK_STAMP(1, 2);
     if (tid < 32) { qs[tid] = 0.f; o[32 + tid] = 0.f; }
     __syncthreads();
     qd.run(xs, a.w.in_b, rowidx, dh, qs, a.scale);     // q * 1/sqrt(dh), as nn.MultiheadAttention scales it
     __syncthreads();
+    ICK_STAMP(1, 3);
     const float4 q4 = reinterpret_cast<const float4*>(qs)[c];   // pad entries are zero
     for (int s0 = 0; s0 < S; s0 += 32 * NP) {
         if (s0 > 0) {
@@ -368,6 +393,7 @@ __global__ __launch_bounds__(256) void dec_cross_kernel(CrossArgs a) {
         }
     }
     __syncthreads();
+    ICK_STAMP(1, 4);
     float m = -INFINITY;
     for (int p = tid; p < S; p += 256) m = fmaxf(m, sc[p]);
     m = block_max<4>(m, red);
@@ -375,6 +401,7 @@ __global__ __launch_bounds__(256) void dec_cross_kernel(CrossArgs a) {
     for (int p = tid; p < S; p += 256) { const float t = __expf(sc[p] - m); sc[p] = t; e += t; }
     const float denom = block_sum<4>(e, red);
     __syncthreads();
+    ICK_STAMP(1, 5);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s0 = 0; s0 < S; s0 += 32 * NP) {
         if (s0 > 0) {
@@ -409,7 +436,9 @@ __global__ __launch_bounds__(256) void dec_cross_kernel(CrossArgs a) {
         o[4 * tid + 2] = 4 * tid + 2 < dh ? t.z * inv : 0.f; o[4 * tid + 3] = 4 * tid + 3 < dh ? t.w * inv : 0.f;
     }
     __syncthreads();
+    ICK_STAMP(1, 6);
     od.run(o, d4, part, a.w.part + (r * a.H + h) * d);
+    ICK_STAMP(1, 7);
 }
 
 struct FfnArgs {
@@ -435,18 +464,23 @@ __global__ __launch_bounds__(256) void dec_ffn_kernel(FfnArgs a) {
     const int d = a.d, d4 = d >> 2;
     const int j0 = ch * 64, nj = min(64, a.FF - j0);
     auto rowidx = [&](int rr) { return j0 + rr; };
+    ICK_STAMP(2, 0);
     RowDot<4> fd;
     fd.load(a.w1, d, rowidx, nj, d4);
     ColDot<22> od;
     od.load(a.w2t, d, j0, nj, d4);
+    ICK_STAMP(2, 1);
     load_row(a.src, r, d, xs, red, ch == 0);
+    ICK_STAMP(2, 2);
     if (tid < 96) f[tid] = 0.f;
     __syncthreads();
     fd.run(xs, a.b1, rowidx, nj, f);
     __syncthreads();
+    ICK_STAMP(2, 3);
     if (tid < nj) f[tid] = fmaxf(f[tid], 0.f);
     __syncthreads();
     od.run(f, d4, part, a.part + (r * nch + ch) * d);
+    ICK_STAMP(2, 4);
 }
 
 struct HeadArgs {
@@ -623,81 +657,98 @@ struct SelectArgs {
     int n_total;
 };
 
-// predict()'s per-step bookkeeping for one caption (geo-aware/models.py:410-441).  Returns true when the caption
-// ended at this step.
-__device__ __forceinline__ bool greedy_update(const SelectArgs& a, int64_t r, int best, int second) {
-    int64_t* o = a.output + r * a.max_len;
-    int32_t* hs = a.hist + r * a.max_len;
-    const int i = a.step;
-    if (a.finished[r]) {
-        a.next_token[r] = 0;
-        a.next_mask[r] = 0;
-        return false;
+__device__ __forceinline__ Top2 top2_merge_wave(Top2 t) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        Top2 o;
+        o.v1 = __shfl_xor(t.v1, off, 64); o.i1 = __shfl_xor(t.i1, off, 64);
+        o.v2 = __shfl_xor(t.v2, off, 64); o.i2 = __shfl_xor(t.i2, off, 64);
+        if (o.i1 != kNone) top2_push(t, o.v1, o.i1);
+        if (o.i2 != kNone) top2_push(t, o.v2, o.i2);
     }
-    int64_t out = best;
-    o[i] = out;
-    if (out == a.end_token) {
-        a.finished[r] = 1;
-        a.next_token[r] = 0;
-        a.next_mask[r] = 0;
-        return true;
-    }
-    hs[i] = second;
-    for (int dupl = 0; dupl <= 4; dupl += 2) {          // repeated n-gram clean-up (geo-aware/models.py:421-435)
-        if (i > dupl) {
-            const int half = (dupl + 2) / 2;
-            bool same = true;
-            for (int j = 0; j < half; ++j) same = same && (o[i - j] == o[i - half - j]);
-            if (same) {
-                const int top = dupl == 0 ? 1 : dupl;
-                for (int q = 0; q < top; ++q) o[i - q] = hs[i - q];
-                break;
-            }
-        }
-    }
-    out = o[i];
-    a.next_token[r] = out;
-    a.next_mask[r] = (a.has_facts && out >= a.V + a.K) ? 2 : (out >= a.V ? 1 : 0);
-    return false;
+    return t;
 }
 
+// Selection + predict()'s per-step bookkeeping for one caption (geo-aware/models.py:410-441) + embedding of the
+// next input token.  Thread 0 fetches the caption's recent history while the workgroup scans the candidates, so the
+// n-gram clean-up runs on registers: the kernel is two memory round trips long (candidates, embedding row).
 __global__ __launch_bounds__(256) void dec_select_kernel(SelectArgs a) {
     if (*a.n_done >= a.n_total) return;
-    __shared__ Top2 sh[256];
+    __shared__ Top2 sh[4];
     __shared__ int64_t tok_sh[2];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, i = a.step;
     const int64_t r = blockIdx.x;
+    int64_t* o = a.output + r * a.max_len;
+    int32_t* hs = a.hist + r * a.max_len;
+    int64_t po[5] = {-1, -1, -1, -1, -1};     // output[i-1 .. i-5]
+    int ph[3] = {0, 0, 0};                    // runner-ups of steps i-1 .. i-3
+    int fin = 0;
+    if (tid == 0) {
+        fin = a.finished[r];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) po[q] = o[max(i - 1 - q, 0)];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) ph[q] = hs[max(i - 1 - q, 0)];
+    }
     Top2 s{-INFINITY, -INFINITY, kNone, kNone};
-    for (int t = tid; t < a.ntiles; t += 256) {
-        const float4 cd = a.cand[r * a.ntiles + t];
-        const int i1 = __float_as_int(cd.y), i2 = __float_as_int(cd.w);
-        if (i1 != kNone) top2_push(s, cd.x, i1);
-        if (i2 != kNone) top2_push(s, cd.z, i2);
+    constexpr int NC = 4;                      // 1024 candidate tiles (16 384 words) per sweep
+    for (int t0 = 0; t0 < a.ntiles; t0 += 256 * NC) {
+        float4 cd[NC];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) cd[q] = a.cand[r * a.ntiles + min(t0 + tid + 256 * q, a.ntiles - 1)];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            if (t0 + tid + 256 * q >= a.ntiles) continue;
+            const int i1 = __float_as_int(cd[q].y), i2 = __float_as_int(cd[q].w);
+            if (i1 != kNone) top2_push(s, cd[q].x, i1);
+            if (i2 != kNone) top2_push(s, cd[q].z, i2);
+        }
     }
     const int np = a.K + a.F;
     for (int k = tid; k < np; k += 256) top2_push(s, a.ptr[r * np + k], a.V + k);
-    sh[tid] = s;
+    s = top2_merge_wave(s);
+    if ((tid & 63) == 0) sh[tid >> 6] = s;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) {
-            Top2 x = sh[tid];
-            const Top2 y = sh[tid + o];
-            if (y.i1 != kNone) top2_push(x, y.v1, y.i1);
-            if (y.i2 != kNone) top2_push(x, y.v2, y.i2);
-            sh[tid] = x;
-        }
-        __syncthreads();
-    }
     if (tid == 0) {
-        const Top2 t = sh[0];
-        const bool ended = greedy_update(a, r, t.i1, t.i2 == kNone ? t.i1 : t.i2);
-        if (ended) atomicAdd(a.n_done, 1);
-        tok_sh[0] = a.next_token[r];
-        tok_sh[1] = a.next_mask[r];
-        if (a.cap_buf != nullptr && a.step + 1 < a.max_len) a.cap_buf[r * a.max_len + a.step + 1] = a.next_token[r];
+        Top2 t = sh[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            if (sh[w].i1 != kNone) top2_push(t, sh[w].v1, sh[w].i1);
+            if (sh[w].i2 != kNone) top2_push(t, sh[w].v2, sh[w].i2);
+        }
+        const int best = t.i1, second = t.i2 == kNone ? t.i1 : t.i2;
+        int64_t tok = 0, msk = 0;
+        if (!fin) {
+            if (best == a.end_token) {
+                o[i] = best;
+                a.finished[r] = 1;
+                atomicAdd(a.n_done, 1);
+            } else {
+                hs[i] = second;
+                int64_t cur = best;
+                // repeated n-gram clean-up (geo-aware/models.py:421-435) on the registers
+                if (i > 0 && cur == po[0]) {
+                    cur = second;
+                } else if (i > 2 && cur == po[1] && po[0] == po[2]) {
+                    cur = second;
+                    o[i - 1] = ph[0];
+                } else if (i > 4 && cur == po[2] && po[0] == po[3] && po[1] == po[4]) {
+                    cur = second;
+                    o[i - 1] = ph[0]; o[i - 2] = ph[1]; o[i - 3] = ph[2];
+                }
+                o[i] = cur;
+                tok = cur;
+                msk = (a.has_facts && cur >= a.V + a.K) ? 2 : (cur >= a.V ? 1 : 0);
+            }
+        }
+        a.next_token[r] = tok;
+        a.next_mask[r] = msk;
+        tok_sh[0] = tok;
+        tok_sh[1] = msk;
+        if (a.cap_buf != nullptr && i + 1 < a.max_len) a.cap_buf[r * a.max_len + i + 1] = tok;
     }
     __syncthreads();
-    if (a.step + 1 >= a.max_len) return;
+    if (i + 1 >= a.max_len) return;
     // CaptionEmbedder + sqrt(d) scale + PositionEncoder of the next input token (geo-aware/models.py:155-181,355-357)
     const int64_t tok = tok_sh[0], msk = tok_sh[1];
     const int64_t b = r / a.rows_per_sample;
@@ -713,7 +764,7 @@ __global__ __launch_bounds__(256) void dec_select_kernel(SelectArgs a) {
     } else {
         src = a.word_emb + (tok >= 0 && tok < a.V ? tok : (int64_t)a.pad_token) * a.d;
     }
-    const float* pe = a.pe + (int64_t)(a.step + 1) * a.d;
+    const float* pe = a.pe + (int64_t)(i + 1) * a.d;
     for (int c = tid; c < a.d; c += 256) a.x0[r * a.d + c] = fmaf(src[c], a.emb_scale, pe[c]);
 }
 
@@ -884,7 +935,8 @@ static RowSrc make_src(const ick_decode_ctx* c, const float* res, const float* p
 }
 
 extern "C" int ick_decode_supported(int32_t d, int32_t H, int32_t FF, int32_t S, int32_t max_len) {
-    return d > 0 && d % 4 == 0 && d <= kDMax && d >= 64 && H > 0 && d % H == 0 && d / H <= 32 && FF > 0 && FF % 4 == 0 &&
+    return d > 0 && d % 4 == 0 && d <= kDMax && d >= 64 && H > 0 && H <= kPartsMax && d % H == 0 && d / H <= 32 && FF > 0 &&
+           FF % 4 == 0 && FF <= 64 * kPartsMax &&
            S > 0 && S <= kSMax && max_len > 0 && max_len <= kMLMax;
 }
 
@@ -893,6 +945,7 @@ extern "C" int ick_decode_layers(const ick_decode_ctx* c, int32_t pos, void* str
     ICK_CHECK_ARG(ick_decode_supported(c->d, c->H, c->FF, c->S, c->max_len));
     ICK_CHECK_ARG(c->rows_per_sample > 0 && c->R % c->rows_per_sample == 0 && c->R <= 65535);
     ICK_CHECK_ARG(c->x0 && c->xa && c->xb && c->xc && c->p1 && c->p2 && c->p3 && c->hfin && c->hv && c->ptr && c->cand);
+    ICK_CHECK_ARG(c->H <= kPartsMax && ceil_div(c->FF, 64) <= kPartsMax);
     hipStream_t s = (hipStream_t)stream;
     const int d = c->d, H = c->H, dh = d / H, R = c->R;
     const int nch = ceil_div(c->FF, 64);

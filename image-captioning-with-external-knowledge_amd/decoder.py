@@ -108,31 +108,98 @@ class CaptionEmbedder(nn.Module):
         self.vocab_size = vocab_size
 
 
+class _Conv1Fn(torch.autograd.Function):
+    """Encoder.conv1 (1x1 convolution = GEMM over the NCHW map) with its backward on the same HIP GEMM:
+    dW = dY^T . X, db = column sums of dY (riding on that GEMM), dX = dY . W (only when the trunk is being
+    fine-tuned).  Used when gradients are wanted (fine_tune_encoder=True, geo-aware/train.py:93-100,282-294)."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, bias):
+        B, Cc, Hh, Ww = feats.shape
+        P, d = Hh * Ww, weight.shape[0]
+        out = torch.empty(B, P, d, device=feats.device, dtype=torch.float32)
+        ops.gemm_raw(feats, weight.view(d, Cc), out, B * P, d, Cc, 1, P, Cc, 1, d, bias=bias, a_grp=P, a_gs=Cc * P)
+        ctx.save_for_backward(feats, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feats, weight = ctx.saved_tensors
+        B, Cc, Hh, Ww = feats.shape
+        P, d = Hh * Ww, weight.shape[0]
+        dy = dout.contiguous().view(B * P, d)
+        dw = db = dx = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            # token-major copy of the map: the reduction index (sample, position) of dW needs one uniform stride
+            xt = feats.view(B, Cc, P).permute(0, 2, 1).contiguous().view(B * P, Cc)
+            dw = torch.zeros(d, Cc, device=feats.device, dtype=torch.float32)
+            db = torch.zeros(d, device=feats.device, dtype=torch.float32)
+            ops.gemm_raw(dy, xt, dw, d, Cc, B * P, 1, d, 1, Cc, Cc, atomic=True, split_k=ops.wgrad_split(B * P, d, Cc),
+                         colsum_a=db)
+            dw = dw.view_as(weight)
+        if ctx.needs_input_grad[0]:
+            dxt = torch.empty(B * P, Cc, device=feats.device, dtype=torch.float32)
+            w2 = weight.view(d, Cc)
+            ops.gemm_raw(dy, w2, dxt, B * P, Cc, d, d, 1, 1, Cc, Cc)           # dX = dY . W  (B k-major)
+            dx = dxt.view(B, P, Cc).permute(0, 2, 1).reshape(B, Cc, Hh, Ww)
+        return dx, dw, db
+
+
 class Encoder(nn.Module):
-    """Feature projection of the image encoder: conv1 (1x1, 2048 -> emb_dim) + view.
+    """Image encoder (geo-aware/models.py:9-60): [ResNet-101 trunk -> AdaptiveAvgPool2d(14)] -> conv1 (1x1,
+    2048 -> emb_dim) -> view (B, emb_dim, 196).
 
-    The hot path starts at the 14x14x2048 feature map (BASELINE configs use precomputed ResNet-101
-    features); the ResNet trunk itself is out of scope, so forward() takes the
-    (B, 2048, 14, 14) map.  Returns (B, emb_dim, 196) like the reference; the storage is token-major
-    (B, 196, emb_dim) -- the layout the decoder's cross-attention K/V projection streams -- exposed
-    through a permuted view, so the decoder consumes it without a copy."""
+    The hot path starts at the 14x14x2048 feature map (BASELINE configs use precomputed ResNet-101 features):
+    forward() takes either that map (B, 2048, H, W) -- conv1 runs as a HIP GEMM straight off the NCHW layout -- or
+    raw images (B, 3, H, W), which first go through the trunk (stock torch.nn / MIOpen, resnet.py; built on first
+    use or with with_trunk=True; there is no network here, so pretrained weights come from load_state_dict /
+    resnet.load_torchvision_state_dict).  Returns (B, emb_dim, 196) like the reference; the storage is token-major
+    (B, 196, emb_dim) -- the layout the decoder's cross-attention K/V projection streams -- exposed through a
+    permuted view, so the decoder consumes it without a copy."""
 
-    def __init__(self, encoded_image_size=14, emb_dim=300, encoder_dim=2048):
+    def __init__(self, encoded_image_size=14, emb_dim=300, encoder_dim=2048, with_trunk=None):
         super().__init__()
         self.emb_dim = emb_dim
         self.encoder_dim = encoder_dim
         self.encoded_image_size = encoded_image_size
+        self.with_trunk = with_trunk
+        if with_trunk:
+            self._build_trunk()
         self.conv1 = nn.Conv2d(encoder_dim, emb_dim, 1)
         self.fine_tune()
 
+    def _build_trunk(self):
+        from .resnet import resnet101_trunk
+        dev = self.conv1.weight.device if "conv1" in self._modules else None
+        self.resnet = resnet101_trunk()
+        self.adaptive_pool = nn.AdaptiveAvgPool2d((self.encoded_image_size, self.encoded_image_size))
+        if dev is not None:
+            self.resnet.to(dev)
+        for p in self.resnet.parameters():
+            p.requires_grad = False
+        self.resnet.train(self.training)
+
+    def features(self, images):
+        """images (B, 3, H, W) -> (B, 2048, 14, 14): trunk + adaptive pooling (geo-aware/models.py:42-43)."""
+        if "resnet" not in self._modules:
+            if self.with_trunk is False:
+                raise IckError("this Encoder was built with with_trunk=False: pass the (B, %d, H, W) feature map"
+                               % self.encoder_dim)
+            self._build_trunk()
+        return self.adaptive_pool(self.resnet(images))
+
     def forward(self, feats):
+        if feats.dim() == 4 and feats.shape[1] == 3 and self.encoder_dim != 3:
+            feats = self.features(feats)
         if feats.dim() != 4 or feats.shape[1] != self.encoder_dim:
-            raise IckError("Encoder.forward expects the (B, %d, H, W) ResNet feature map; the ResNet trunk is "
-                           "outside the accelerated path" % self.encoder_dim)
+            raise IckError("Encoder.forward expects images (B, 3, H, W) or the (B, %d, H, W) feature map"
+                           % self.encoder_dim)
         feats = feats.contiguous()
         B, Cc, Hh, Ww = feats.shape
         P = Hh * Ww
         d = self.emb_dim
+        if torch.is_grad_enabled() and (feats.requires_grad or self.conv1.weight.requires_grad):
+            return _Conv1Fn.apply(feats, self.conv1.weight, self.conv1.bias).permute(0, 2, 1)
         out = torch.empty(B, P, d, device=feats.device, dtype=torch.float32)
         w = self.conv1.weight.detach().view(d, Cc)
         ops.gemm_raw(feats, w, out, B * P, d, Cc, 1, P, Cc, 1, d, bias=self.conv1.bias.detach(),
@@ -140,9 +207,15 @@ class Encoder(nn.Module):
         return out.permute(0, 2, 1)
 
     def fine_tune(self, fine_tune=True):
-        """The reference toggles ResNet blocks 2-4 here (geo-aware/models.py:49-60); there is no trunk
-        in this module, and conv1 is left as it is there (trainable flag untouched)."""
-        return None
+        """Convolutional blocks 2-4 of the trunk train iff fine_tune (geo-aware/models.py:49-60); conv1 is left
+        as the reference leaves it (always requires_grad).  Without a trunk there is nothing to toggle."""
+        if "resnet" not in self._modules:
+            return
+        for p in self.resnet.parameters():
+            p.requires_grad = False
+        for c in list(self.resnet.children())[5:]:
+            for p in c.parameters():
+                p.requires_grad = fine_tune
 
 
 class DecoderTransformer(nn.Module):
@@ -485,8 +558,8 @@ class DecoderTransformer(nn.Module):
         if self._wants_grad() and stages is None:
             # autograd bridge: the HIP backward pass runs when the caller's loss.backward() reaches us
             from . import training
-            scores = training.DecoderGraphFn.apply(self, captions, caption_masks, entities, facts, enc_tok.detach(),
-                                                   gmap, *training.unique_parameters(self))
+            scores = training.DecoderGraphFn.apply(self, captions, caption_masks, entities, facts, enc_tok, gmap,
+                                                   *training.unique_parameters(self))
             return scores, captions, decode_lengths
         return self._forward_device(captions, caption_masks, entities, facts, enc_tok, gmap, stages), captions, \
             decode_lengths
@@ -596,6 +669,80 @@ class DecoderTransformer(nn.Module):
             ops.decode_layers(c, i)
             ops.decode_select_greedy(c, i)
         return t["output"]
+
+    def _predict_beam_device(self, enc_tok, entities, facts, max_pred_len, beam):
+        """Beam search on the fused decode kernels: R = B * beam rows share their caption's cross K/V; the
+        self-attention cache is never reordered -- an ancestry table says which cache row holds position p of a
+        hypothesis.  Returns (best sequence (B, max_len), its log-probability (B), all sequences, all scores)."""
+        from . import lib as L
+        B = enc_tok.shape[0]
+        d, V, K = self.emb_dim, self.vocab_size, entities.shape[1]
+        dev = enc_tok.device
+        ee, fe, kv, _, side = self._encode_context(enc_tok, entities, facts, None)
+        side.join()
+        S = kv.shape[3]
+        R = B * beam
+        anc = [torch.zeros(R, max_pred_len, dtype=torch.int32, device=dev) for _ in range(2)]
+        c, t = self._decode_ctx(kv, ee, fe, beam, max_pred_len, S, anc=anc[0], want_scores=True)
+        seq = [torch.full((R, max_pred_len), self.word_map["<pad>"], dtype=torch.long, device=dev) for _ in range(2)]
+        cum = torch.full((B, beam), float("-inf"), device=dev)
+        cum[:, 0] = 0.0                                   # one live hypothesis per caption at the start
+        fin = torch.zeros(R, dtype=torch.int32, device=dev)
+        t["n_done"].fill_(B * (beam - 1))                 # the unused slots count as ended
+        facts_r = cap = None
+        if self.has_facts:
+            facts_r = facts.repeat_interleave(beam, dim=0).contiguous()
+            cap = [torch.full((R, max_pred_len), self.word_map["<start>"], dtype=torch.long, device=dev)
+                   for _ in range(2)]
+        tok = torch.full((R, 1), self.word_map["<start>"], dtype=torch.long, device=dev)
+        x0 = ops.caption_embed(tok, torch.zeros_like(tok), self.word_embedding.weight.detach(),
+                               ee.repeat_interleave(beam, dim=0), None if fe is None else fe.repeat_interleave(beam, dim=0),
+                               self.pos_encoder.pe.view(-1, d), V, self.word_map["<pad>"], math.sqrt(d), pos0=0)
+        t["x0"].copy_(x0.view(R, d))
+        bs = L.BeamState()
+        bs.cum, bs.fin, bs.start_token = cum.data_ptr(), fin.data_ptr(), self.word_map["<start>"]
+        for i in range(max_pred_len):
+            cur, nxt = i & 1, (i + 1) & 1
+            c.anc = anc[cur].data_ptr()
+            if self.has_facts:
+                ops.context_indicators(cap[cur], facts_r, K, V, self._pred_wt(), self.fc_predicate.bias.detach(), mode=1,
+                                       eib=t["eib"], gate=t["gate"])
+                bs.cap_in, bs.cap_out = cap[cur].data_ptr(), cap[nxt].data_ptr()
+            ops.decode_layers(c, i)
+            bs.seq_in, bs.seq_out = seq[cur].data_ptr(), seq[nxt].data_ptr()
+            bs.anc_in, bs.anc_out = anc[cur].data_ptr(), anc[nxt].data_ptr()
+            ops.decode_select_beam(c, bs, i)
+        final = seq[max_pred_len & 1].view(B, beam, max_pred_len)
+        best = cum.argmax(dim=1)                          # ties: the lower hypothesis
+        out = final[torch.arange(B, device=dev), best]
+        return out, cum.gather(1, best.view(B, 1)).view(B), final, cum
+
+    @torch.no_grad()
+    def predict_beam(self, encoder_out, max_pred_len, entities, facts=None, beam_size=5, return_all=False):
+        """Beam-search decode (north_star cfg5: beam 5, batch 32).  The reference decodes greedily only
+        (geo-aware/eval.py:61,83), so beam > 1 has no reference output to pin against ("parity-unpinned"); the tests
+        check it against a CPU beam search written to the same rules.  beam_size == 1 IS predict(): the pinned greedy path with
+        its n-gram clean-up.  Hypotheses are scored by their summed log-probability (log_softmax over the V+K+F
+        scores); an ended hypothesis keeps competing with its final score; the best of the beam is returned as
+        LongTensor (max_pred_len, B), <pad> after <end>."""
+        if beam_size == 1:
+            return DecoderTransformer.predict(self, encoder_out, max_pred_len, entities, facts)
+        encoder_out, entities, facts = self._prepare_inputs(encoder_out, entities, facts)
+        entities = entities.contiguous()
+        enc_tok = self._token_major(encoder_out).contiguous()
+        FF = self.transformer_decoder.layers[0].linear1.out_features
+        S_all = enc_tok.shape[1] + entities.shape[1] + (facts.shape[1] if facts is not None else 0)
+        if not (1 < beam_size <= 8) or not ops.decode_supported(self.emb_dim, self.num_heads, FF, S_all, max_pred_len):
+            raise IckError("predict_beam needs 1 <= beam_size <= 8 and sizes the fused decode kernels support")
+        if self.use_hip_graphs:
+            key = (tuple(enc_tok.shape), tuple(entities.shape), None if facts is None else tuple(facts.shape),
+                   max_pred_len, beam_size)
+            res = self._graphed("beam", key, lambda t, e, f: self._predict_beam_device(t, e, f, max_pred_len, beam_size),
+                                [enc_tok, entities, facts])
+        else:
+            res = self._predict_beam_device(enc_tok, entities, facts, max_pred_len, beam_size)
+        out = res[0].t().contiguous()
+        return (out, res[1], res[2], res[3]) if return_all else out
 
     def _predict_device(self, enc_tok, entities, facts, max_pred_len):
         """Whole greedy decode on the device: every step's token choice, clean-up and stop flag are computed

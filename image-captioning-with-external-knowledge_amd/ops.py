@@ -341,6 +341,10 @@ def decode_select_greedy(ctx, pos):
     L.check(L.load().ick_decode_select_greedy(C.byref(ctx), pos, _stream()), "ick_decode_select_greedy")
 
 
+def decode_select_beam(ctx, beam_state, pos):
+    L.check(L.load().ick_decode_select_beam(C.byref(ctx), C.byref(beam_state), pos, _stream()), "ick_decode_select_beam")
+
+
 def packed_ce(scores, captions_sorted, decode_len, pad_token, want_grad=False, out_sum=None, out_count=None):
     """Returns (loss_sum (1,), count (1,), dscores or None): token-mean loss = loss_sum / count.  out_sum / out_count:
     one-element float tensors to receive the two scalars (the tail of TrainStep's gradient bucket)."""

@@ -41,6 +41,8 @@ class Config:
     batch_size: int = 4                                # reference: 4 / 4 / 3 (geo / knowledge / news)
     workers: int = 1
     decoder_lr: float = 4e-4
+    encoder_lr: float = 1e-4                           # geo-aware/train.py:47
+    fine_tune_encoder: bool = False                    # geo-aware/train.py:52; True trains conv1 (+ trunk blocks 2-4)
     grad_clip: float = 5.0
     print_freq: int = 100
     checkpoint: str = ""
@@ -65,7 +67,7 @@ def packed_loss(criterion, scores, caps_sorted, decode_lengths):
     return criterion(s, t)
 
 
-def train(loader, encoder, decoder, criterion, decoder_optimizer, step, epoch, cfg, device):
+def train(loader, encoder, decoder, criterion, decoder_optimizer, step, epoch, cfg, device, encoder_optimizer=None):
     decoder.train()
     encoder.train()
     batch_time, losses = ut.AverageMeter(), ut.AverageMeter()
@@ -74,8 +76,11 @@ def train(loader, encoder, decoder, criterion, decoder_optimizer, step, epoch, c
     for i, batch in enumerate(loader):
         imgs, caps, caplens, capmasks, ent, facts = _batch_to_device(batch, device, has_facts)
         extra = (facts,) if has_facts else ()
-        with torch.no_grad():
-            enc = encoder(imgs)
+        if encoder_optimizer is not None:
+            enc = encoder(imgs)                     # fine_tune_encoder: the loss back-propagates into the encoder
+        else:
+            with torch.no_grad():
+                enc = encoder(imgs)
         n_tok = int((caplens - 1).sum())
         if step is not None:                                             # fused HIP step
             loss = step(caps, enc, capmasks, caplens, ent, *extra).item()
@@ -83,10 +88,16 @@ def train(loader, encoder, decoder, criterion, decoder_optimizer, step, epoch, c
             scores, caps_sorted, dl = decoder(caps, enc, capmasks, caplens, ent, *extra)
             loss_t = packed_loss(criterion, scores, caps_sorted, dl)
             decoder_optimizer.zero_grad()
+            if encoder_optimizer is not None:
+                encoder_optimizer.zero_grad()
             loss_t.backward()
             if cfg.grad_clip is not None:
                 ut.clip_gradient(decoder_optimizer, cfg.grad_clip)
+                if encoder_optimizer is not None:
+                    ut.clip_gradient(encoder_optimizer, cfg.grad_clip)
             decoder_optimizer.step()
+            if encoder_optimizer is not None:
+                encoder_optimizer.step()
             loss = loss_t.item()
         losses.update(loss, n_tok)
         batch_time.update(time.time() - start)
@@ -158,9 +169,12 @@ def main(cfg=None):
     cfg = cfg or Config()
     world = dp.init_from_env()
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1 and not cfg.fused:
-        raise ValueError("data-parallel training needs fused=True (TrainStep owns the gradient all-reduce)")
-    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    if world > 1 and (not cfg.fused or cfg.fine_tune_encoder):
+        raise ValueError("data-parallel training needs fused=True and fine_tune_encoder=False (TrainStep owns the "
+                         "gradient all-reduce; the encoder's gradients are not part of its bucket)")
+    fused = cfg.fused and not cfg.fine_tune_encoder     # fine-tuning the encoder takes the reference's statement
+                                                        # sequence: loss.backward() through the HIP autograd bridge
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
     models = load_models(cfg.variant)
     with open(os.path.join(cfg.data_dir, "WORDMAP_" + cfg.data_name + ".json")) as f:
@@ -174,17 +188,23 @@ def main(cfg=None):
             decoder.load_pretrained_embeddings(ut.load_embeddings(cfg.pretrained_word_embeddings_file, word_map))
         decoder.fine_tune_embeddings(True)
         encoder = models.Encoder(emb_dim=cfg.emb_dim)
-        decoder_optimizer = None
+        decoder_optimizer = encoder_optimizer = None
     else:
         ck = ut.load_checkpoint(cfg.checkpoint, map_location=device)
         decoder, encoder = ck["decoder"], ck["encoder"]
         decoder_optimizer = None if cfg.zero_out_epochs_since_improvement else ck["decoder_optimizer"]
+        encoder_optimizer = None if cfg.zero_out_epochs_since_improvement else ck.get("encoder_optimizer")
         if not cfg.zero_out_epochs_since_improvement:
             start_epoch, epochs_since_improvement, best_loss = ck["epoch"] + 1, ck["epochs_since_improvement"], ck["loss"]
     decoder.to(device)
     encoder.to(device)
+    encoder.fine_tune(cfg.fine_tune_encoder)
+    if cfg.fine_tune_encoder and encoder_optimizer is None:
+        encoder_optimizer = torch.optim.Adam([p for p in encoder.parameters() if p.requires_grad], lr=cfg.encoder_lr)
+    if not cfg.fine_tune_encoder:
+        encoder_optimizer = None
     step = None
-    if cfg.fused:
+    if fused:
         # seed: the dropout stream, one per rank (the ranks hold different samples); the constructor broadcasts rank
         # 0's weights, so a decoder that was randomly initialised per process starts identical everywhere
         step = TrainStep(decoder, lr=cfg.decoder_lr, grad_clip=cfg.grad_clip, seed=cfg.seed * 1000 + rank)
@@ -206,12 +226,15 @@ def main(cfg=None):
                 step.set_lr(step.lr * 0.8)
             else:
                 ut.adjust_learning_rate(decoder_optimizer, 0.8)
+            if encoder_optimizer is not None:
+                ut.adjust_learning_rate(encoder_optimizer, 0.8)
         # the epoch's permutation depends on (seed, epoch) only, so a resumed run sees the batches the interrupted
         # one would have seen
         shuffle_gen.manual_seed(cfg.seed * 100003 + epoch)
         if samplers["TRAIN"] is not None:
             samplers["TRAIN"].set_epoch(epoch)
-        tr = train(loaders["TRAIN"], encoder, decoder, criterion, decoder_optimizer, step, epoch, cfg, device)
+        tr = train(loaders["TRAIN"], encoder, decoder, criterion, decoder_optimizer, step, epoch, cfg, device,
+                   encoder_optimizer)
         last_loss = validate(loaders["VAL"], encoder, decoder, criterion, cfg, device)   # identical on every rank
         is_best = last_loss < best_loss
         best_loss = min(last_loss, best_loss)
@@ -221,7 +244,7 @@ def main(cfg=None):
             raise RuntimeError("data-parallel replicas diverged (epoch %d): parameters differ between ranks" % epoch)
         if rank == 0:
             opt = step.as_torch_optimizer() if step is not None else decoder_optimizer
-            ut.save_checkpoint(cfg.data_name, epoch, epochs_since_improvement, encoder, decoder, None,
+            ut.save_checkpoint(cfg.data_name, epoch, epochs_since_improvement, encoder, decoder, encoder_optimizer,
                                opt, last_loss, is_best, out_dir=cfg.out_dir)
     return history
 

@@ -316,13 +316,17 @@ def _kv_proj_param_grads(layer, li, dkv_rows, mem2, grads, d):
         ops.colsum(sl, gb[d:])
 
 
-def backward_from_tape(dec, tape, dscores, grads, overlap=True):
+def backward_from_tape(dec, tape, dscores, grads, overlap=True, want_image_grad=False):
     """Accumulate parameter gradients of `dec` into `grads` (dict id(param) -> zero-initialised
     tensor shaped like the parameter; frozen parameters are simply absent).  With `overlap` the weight /
-    bias gradients of the Linear layers run on a second HIP stream beside the data-gradient chain."""
-    bp = BackwardPass(dec, tape, dscores, grads, overlap)
+    bias gradients of the Linear layers run on a second HIP stream beside the data-gradient chain.
+    want_image_grad: also return the gradient of the (length-sorted) image memory rows (B, P, d) -- what
+    fine_tune_encoder=True back-propagates into Encoder.conv1; the default step skips that 13.5 GFLOP GEMM because
+    the reference never uses the result (geo-aware/train.py:93-100,283-284)."""
+    bp = BackwardPass(dec, tape, dscores, grads, overlap, want_image_grad)
     bp.early(join=False)     # one pass: the side stream is only joined at the very end
     bp.late()
+    return tape.misc.get("d_img")
 
 
 def early_parameters(dec):
@@ -347,9 +351,9 @@ class BackwardPass:
     early() = score head + decoder stack, with the side stream joined at its end; late() = context encoders and
     embeddings.  The two phases may be captured into two hipGraphs."""
 
-    def __init__(self, dec, tape, dscores, grads, overlap=True):
+    def __init__(self, dec, tape, dscores, grads, overlap=True, want_image_grad=False):
         self.side = ops.SideStream() if overlap else None
-        self.gen = _backward_phases(dec, tape, dscores, grads)
+        self.gen = _backward_phases(dec, tape, dscores, grads, want_image_grad)
 
     def _run(self, join):
         ops.SIDE = self.side
@@ -373,7 +377,7 @@ class BackwardPass:
         self._run(True)
 
 
-def _backward_phases(dec, tape, dscores, grads):
+def _backward_phases(dec, tape, dscores, grads, want_image_grad=False):
     m = tape.misc
     d, V, H = dec.emb_dim, dec.vocab_size, dec.num_heads
     h, ee, fe = m["h"], m["ee"], m["fe"]
@@ -432,6 +436,11 @@ def _backward_phases(dec, tape, dscores, grads):
     dctx = (torch.zeros if ksplit > 1 else torch.empty)(B, nctx, d, device=dev, dtype=torch.float32)
     ops.gemm_raw(dkv_rows[:, P:], m["wkv"], dctx, B * nctx, d, nseg * d, nseg * d, 1, 1, d, d, a_grp=nctx,
                  a_gs=S * nseg * d, atomic=ksplit > 1, split_k=ksplit)
+    if want_image_grad:
+        # image rows: d mem[:, :P] = dK/dV rows @ packed K/V weight (the data gradient of the all-layer projection)
+        d_img = torch.empty(B, P, d, device=dev, dtype=torch.float32)
+        ops.gemm_raw(dkv_rows, m["wkv"], d_img, B * P, d, nseg * d, nseg * d, 1, 1, d, d, a_grp=P, a_gs=S * nseg * d)
+        m["d_img"] = d_img
     # ---- context encoders
     ops.stamp("bwd: context gradient ready")
     dee_enc = _context_encoder_bwd(dec, dec.transformer_encoder_entities, tape.enc_layers["entities"],
@@ -461,16 +470,22 @@ class DecoderGraphFn(torch.autograd.Function):
     def forward(ctx, dec, captions, masks, entities, facts, enc_tok, gmap, *params):
         dec.__dict__["_drop_step"] = dec.__dict__.get("_drop_step", 0) + 1
         seed = (dec.__dict__.get("_drop_seed", 0x1234567) * 2654435761 + dec.__dict__["_drop_step"]) & 0xFFFFFFFF
-        scores, tape = forward_with_tape(dec, captions, masks, entities, facts, enc_tok, gmap, seed=seed)
-        ctx.dec, ctx.tape, ctx.params = dec, tape, params
+        scores, tape = forward_with_tape(dec, captions, masks, entities, facts, enc_tok.detach(), gmap, seed=seed)
+        ctx.dec, ctx.tape, ctx.params, ctx.gmap = dec, tape, params, gmap
+        ctx.enc_shape = enc_tok.shape
         return scores
 
     @staticmethod
     def backward(ctx, dscores):
         dec, params = ctx.dec, ctx.params
         grads = {id(p): torch.zeros_like(p) for p in params if p.requires_grad}
-        backward_from_tape(dec, ctx.tape, dscores.contiguous(), grads)
-        return (None,) * 7 + tuple(grads.get(id(p)) for p in params)
+        want_img = ctx.needs_input_grad[5]      # fine_tune_encoder=True: the loss reaches Encoder.conv1 through enc_tok
+        d_img = backward_from_tape(dec, ctx.tape, dscores.contiguous(), grads, want_image_grad=want_img)
+        d_enc = None
+        if want_img:                            # the forward gathered the samples into length order through gmap
+            d_enc = torch.empty(ctx.enc_shape, device=d_img.device, dtype=torch.float32)
+            d_enc.index_copy_(0, ctx.gmap.long(), d_img) if ctx.gmap is not None else d_enc.copy_(d_img)
+        return (None,) * 5 + (d_enc, None) + tuple(grads.get(id(p)) for p in params)
 
 
 def unique_parameters(dec):

@@ -409,3 +409,90 @@ def predict(cfg, P, enc_out, max_pred_len, entities, facts=None, return_scores=F
     if return_scores:
         return res, torch.stack(all_scores)
     return res
+
+
+# ----------------------------------------------------------------------------------------
+# Beam search (north_star cfg5).  NOT in the reference (geo-aware/eval.py:61,83 decodes greedily): this CPU
+# restatement only pins the build's own device beam search ("parity-unpinned" against the reference).
+# Rules: hypotheses are scored by their summed log_softmax; an ended hypothesis competes with its final score;
+# candidates are ranked by (score desc, hypothesis index asc, token asc); full recompute per step, no clean-up.
+# ----------------------------------------------------------------------------------------
+def predict_beam(cfg, P, enc_out, max_pred_len, entities, facts=None, beam_size=5):
+    """enc_out (1,d,196) -> (best sequence LongTensor (max_pred_len,), its log-probability, all (seq, score))."""
+    assert enc_out.shape[0] == 1
+    V, K = cfg.vocab_size, entities.shape[1]
+    ee = entity_encode(cfg, P, entities, facts)
+    fe = fact_encode(P, facts, ee) if cfg.has_facts else None
+    mem = build_memory(cfg, P, enc_out, ee, fe)
+    pe = pe_table(max_pred_len, cfg.emb_dim).unsqueeze(0)
+    Vx = V + K + (facts.shape[1] if facts is not None else 0)
+    hyps = [dict(seq=[], score=0.0, fin=False)] + [None] * (beam_size - 1)
+    for i in range(max_pred_len):
+        cands = []
+        for j, h in enumerate(hyps):
+            if h is None:
+                continue
+            if h["fin"]:
+                cands.append((h["score"], j, 0, None))
+                continue
+            captions = [cfg.start] + h["seq"] + [cfg.start] * (max_pred_len - 1 - len(h["seq"]))
+            masks = [0] + [2 if (cfg.has_facts and t >= V + K) else (1 if t >= V else 0) for t in h["seq"]]
+            masks = masks + [0] * (max_pred_len - len(masks))
+            cap_t = torch.tensor([captions[:max_pred_len]])
+            emb = caption_embed(cfg, P, cap_t, torch.tensor([masks[:max_pred_len]]), ee, fe)
+            x = emb * math.sqrt(cfg.emb_dim) + pe
+            hh = decoder_stack(cfg, P, x, mem)[:, i : i + 1]
+            if cfg.has_facts:
+                eib, pi = context_indicators(cfg, cap_t, facts, K, 1)
+                sc = get_scores(cfg, P, hh, ee, fe, eib, pi)
+            else:
+                sc = get_scores(cfg, P, hh, ee)
+            logp = sc[0, 0].log_softmax(dim=-1)
+            top = logp.topk(min(beam_size, Vx))
+            for v, idx in zip(top.values.tolist(), top.indices.tolist()):
+                cands.append((h["score"] + v, j, idx, logp))
+        cands.sort(key=lambda c: (-c[0], c[1], c[2]))
+        new = []
+        for score, j, tok, _ in cands[:beam_size]:
+            h = hyps[j]
+            if h["fin"]:
+                new.append(dict(seq=list(h["seq"]), score=h["score"], fin=True))
+            else:
+                new.append(dict(seq=h["seq"] + [tok], score=score, fin=tok == cfg.end))
+        hyps = new + [None] * (beam_size - len(new))
+        if all(h is None or h["fin"] for h in hyps):
+            break
+    live = [h for h in hyps if h is not None]
+    best = max(range(len(live)), key=lambda q: (live[q]["score"], -q))
+    seq = live[best]["seq"] + [cfg.pad] * (max_pred_len - len(live[best]["seq"]))
+    return torch.tensor(seq[:max_pred_len], dtype=torch.long), live[best]["score"], [(h["seq"], h["score"]) for h in live]
+
+
+def sequence_logprob(cfg, P, enc_out, entities, facts, seq, max_pred_len):
+    """Summed log-probability the (teacher-forced) model gives the token sequence `seq` (up to and including <end>)."""
+    V, K = cfg.vocab_size, entities.shape[1]
+    ee = entity_encode(cfg, P, entities, facts)
+    fe = fact_encode(P, facts, ee) if cfg.has_facts else None
+    mem = build_memory(cfg, P, enc_out, ee, fe)
+    pe = pe_table(max_pred_len, cfg.emb_dim).unsqueeze(0)
+    toks = []
+    for t in seq:
+        toks.append(int(t))
+        if int(t) == cfg.end:
+            break
+    total = 0.0
+    for i, t in enumerate(toks):
+        prev = toks[:i]
+        captions = [cfg.start] + prev + [cfg.start] * (max_pred_len - 1 - len(prev))
+        masks = [0] + [2 if (cfg.has_facts and q >= V + K) else (1 if q >= V else 0) for q in prev]
+        masks = masks + [0] * (max_pred_len - len(masks))
+        cap_t = torch.tensor([captions[:max_pred_len]])
+        emb = caption_embed(cfg, P, cap_t, torch.tensor([masks[:max_pred_len]]), ee, fe)
+        hh = decoder_stack(cfg, P, emb * math.sqrt(cfg.emb_dim) + pe, mem)[:, i : i + 1]
+        if cfg.has_facts:
+            eib, pi = context_indicators(cfg, cap_t, facts, K, 1)
+            sc = get_scores(cfg, P, hh, ee, fe, eib, pi)
+        else:
+            sc = get_scores(cfg, P, hh, ee)
+        total += float(sc[0, 0].log_softmax(dim=-1)[t])
+    return total

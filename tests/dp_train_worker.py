@@ -21,6 +21,14 @@ if __name__ == "__main__":
         return orig(batch, device, has_facts)
 
     tr._batch_to_device = spy
+    steps = []
+
+    class Recording(tr.TrainStep):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            steps.append(self)
+
+    tr.TrainStep = Recording
     cfg = tr.Config(variant="knowledge", data_dir=data_dir, data_name="toy", epochs=2, batch_size=4, workers=0,
                     print_freq=1000, fused=True, out_dir=out_dir if rank == 0 else os.path.join(out_dir, "r%d" % rank),
                     seed=5)
@@ -31,11 +39,6 @@ if __name__ == "__main__":
     # every rank reports its final weights (through rank 0's checkpoint for rank 0, directly for the others)
     torch.save({"hist": hist, "seen": torch.cat(seen)}, os.path.join(out_dir, "rank%d.pt" % rank))
     import torch.distributed as dist
-    import gc
-    flat = None
-    for obj in gc.get_objects():
-        if isinstance(obj, tr.TrainStep):
-            flat = obj.flat_p.detach().cpu().clone()
-    torch.save(flat, os.path.join(out_dir, "flat%d.pt" % rank))
+    torch.save(steps[-1].flat_p.detach().cpu().clone(), os.path.join(out_dir, "flat%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()

@@ -65,3 +65,24 @@ def test_reference_checkpoint_unpickles_into_drop_in(tmp_path, variant):
     fresh = ours.DecoderTransformer(wm, 300, 512, 512, 10, 3)
     assert list(fresh.state_dict().keys()) == list(ref_sd.keys())
     fresh.load_state_dict(ref_sd, strict=True)
+
+
+def test_resnet_trunk_layout_matches_torchvision_keys():
+    """The trunk reproduces the module tree of `nn.Sequential(*list(torchvision.models.resnet101().children())[:-2])`
+    (geo-aware/models.py:24-27): same state_dict keys / shapes, so reference encoder weights load unchanged."""
+    import torch
+    from ick_amd.resnet import load_torchvision_state_dict, resnet101_trunk
+    trunk = resnet101_trunk()
+    sd = {k: v.clone() for k, v in trunk.state_dict().items()}
+    assert sum(p.numel() for p in trunk.parameters()) == 44549160 - 2049000     # resnet101 minus its fc layer
+    assert sd["0.weight"].shape == (64, 3, 7, 7) and sd["1.running_var"].shape == (64,)
+    assert sd["4.0.downsample.0.weight"].shape == (256, 64, 1, 1) and "4.1.downsample.0.weight" not in sd
+    assert sd["5.0.conv2.weight"].shape == (128, 128, 3, 3) and trunk[5][0].conv2.stride == (2, 2)
+    assert sd["6.22.bn3.weight"].shape == (1024,) and "6.23.conv1.weight" not in sd
+    assert sd["7.2.conv3.weight"].shape == (2048, 512, 1, 1)
+    # a torchvision-style state dict (children named conv1 / bn1 / layer1..4 / fc) maps onto it
+    names = {"0": "conv1", "1": "bn1", "4": "layer1", "5": "layer2", "6": "layer3", "7": "layer4"}
+    tv = {names[k.split(".")[0]] + k[k.index("."):]: v + 1 for k, v in sd.items()}
+    tv["fc.weight"], tv["fc.bias"] = torch.zeros(1000, 2048), torch.zeros(1000)
+    load_torchvision_state_dict(trunk, tv)
+    assert torch.equal(trunk.state_dict()["7.2.conv3.weight"], sd["7.2.conv3.weight"] + 1)

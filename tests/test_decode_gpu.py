@@ -93,3 +93,51 @@ def test_fused_decode_early_exit_keeps_pad_after_end():
     seq = dec.predict(synth.make_enc_out(B, seed).cuda(), max_len, synth.make_entities(variant, B, K, V, seed))
     assert seq.shape == (max_len, B)
     assert (seq[0] == V - 1).all() and (seq[1:] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------------ beam search
+@pytest.mark.parametrize("variant,K,V,Fn,max_len,beam,seeds", [("geo", 6, 50, 0, 10, 3, (0, 1, 2, 3)),
+                                                               ("knowledge", 6, 50, 5, 10, 5, (0, 1, 2)),
+                                                               ("geo", 20, 1000, 0, 12, 5, (4, 5))])
+def test_beam_search_vs_cpu_beam_reference(variant, K, V, Fn, max_len, beam, seeds):
+    """Device beam search against the oracle's CPU beam search (full recompute per step).  PARITY-UNPINNED against
+    the reference, which has no beam search (geo-aware/eval.py:61,83).  Sequences must be identical; where fp32
+    rounding flips a near-tie the device's sequence must score (under the oracle) within 1e-3 of the oracle's best."""
+    cfg = R.config_from_word_map(variant, synth.make_word_map(V))
+    exact = 0
+    for seed in seeds:
+        P = synth.make_params(variant, V, seed)
+        dec = build_decoder(variant, V, P)
+        ents = synth.make_entities(variant, 1, K, V, seed)
+        facts = synth.make_facts(variant, 1, Fn, K, seed) if variant != "geo" else None
+        enc = synth.make_enc_out(1, seed)
+        args = [enc.cuda(), max_len, ents] + ([facts.cuda()] if facts is not None else [])
+        seq, score, allseq, allscore = dec.predict_beam(*args, beam_size=beam, return_all=True)
+        with torch.no_grad():
+            ref_seq, ref_score, _ = R.predict_beam(cfg, P, enc, max_len, ents, facts, beam)
+        mine = seq[:, 0].cpu().tolist()
+        assert abs(score.item() - R.sequence_logprob(cfg, P, enc, ents, facts, mine, max_len)) < 1e-3   # its own score is right
+        if mine == ref_seq.tolist():
+            exact += 1
+            assert abs(score.item() - ref_score) < 1e-3
+        else:
+            assert R.sequence_logprob(cfg, P, enc, ents, facts, mine, max_len) > ref_score - 1e-3, (seed, mine, ref_seq.tolist())
+    assert exact >= len(seeds) - 1
+
+
+def test_beam_one_is_greedy_and_batch_is_independent():
+    variant, B, K, V, max_len, seed = "geo", 4, 8, 200, 12, 9
+    P = synth.make_params(variant, V, seed)
+    dec = build_decoder(variant, V, P)
+    ents = synth.make_entities(variant, B, K, V, seed)
+    enc = synth.make_enc_out(B, seed).cuda()
+    assert torch.equal(dec.predict_beam(enc, max_len, ents, beam_size=1), dec.predict(enc, max_len, ents))
+    full = dec.predict_beam(enc, max_len, ents, beam_size=5)
+    assert full.shape == (max_len, B)
+    for b in range(B):
+        one = dec.predict_beam(enc[b:b + 1], max_len, ents[b:b + 1], beam_size=5)
+        assert torch.equal(one[:, 0], full[:, b])
+    again = dec.predict_beam(enc, max_len, ents, beam_size=5)          # graph replay
+    assert torch.equal(again, full)
+    with pytest.raises(ick_amd.lib.IckError):
+        dec.predict_beam(enc, max_len, ents, beam_size=9)

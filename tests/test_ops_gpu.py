@@ -4,6 +4,8 @@ import math
 import pytest
 import torch
 
+import torch.nn.functional as F
+
 import ick_amd.synth as synth
 from oracle import restatement as R
 
