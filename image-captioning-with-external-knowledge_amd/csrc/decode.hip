@@ -64,47 +64,74 @@ struct RowSrc {
 };
 
 // x = LayerNorm(res + bias + sum partials) (or res itself) -> xs[0..kDMax) in LDS, zero beyond d.
-// Every load is issued before the first add (a `for (p < nparts)` load-add loop waits for each load in turn:
-// ten dependent L2 round trips per kernel); the partial rows are then summed in index order.
+// issue() only starts the loads; the kernels issue them FIRST and their large weight / K / V streams afterwards:
+// vector-memory results return in issue order, so the row is normalised (finish()) and projected while the streams
+// are still arriving.  Every partial row is loaded before the first add (a `for (p < nparts)` load-add loop would wait
+// for each load in turn: ten dependent L2 round trips); the partial rows are then summed in index order.
 constexpr int kPartsMax = 16;
-__device__ __forceinline__ void load_row(const RowSrc& s, int64_t row, int d, float* xs, float* red, bool writer) {
-    const int tid = threadIdx.x;
-    float v[2];
-    float pv[2][kPartsMax], bs[2] = {0.f, 0.f}, gm[2] = {0.f, 0.f}, bt[2] = {0.f, 0.f};
-    const int np = s.nparts;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int c = min(tid + 256 * e, d - 1);
-        v[e] = s.res[row * d + c];
+// The np + 2 rows to add (residual, bias, partials) are dealt out to G = min(4, 256 / (d/4)) thread groups as float4
+// columns: at most 6 + 2 sixteen-byte loads per thread (one dword per element would be 40 load instructions per thread
+// -- with the weight stream behind them more than the 63 a wave can keep in flight, which stalls the issue itself).
+struct RowIn {
+    float4 acc, gm, bt;
+    float4 pv[6];
+    __device__ __forceinline__ void issue(const RowSrc& s, int64_t row, int d) {
+        const int tid = threadIdx.x, np = s.nparts, d4 = d >> 2;
+        const int G = min(256 / d4, 4);
+        const int g = min(tid / d4, G - 1), c4 = min(tid - g * d4, d4 - 1);
+        const int nrows = np > 0 ? np + 2 : 1;
+        gm = bt = make_float4(0.f, 0.f, 0.f, 0.f);
         if (np > 0) {
-            bs[e] = s.bias[c]; gm[e] = s.gamma[c]; bt[e] = s.beta[c];
+            gm = reinterpret_cast<const float4*>(s.gamma)[c4];
+            bt = reinterpret_cast<const float4*>(s.beta)[c4];
+        }
 #pragma unroll
-            for (int p = 0; p < kPartsMax; ++p) pv[e][p] = s.part[(row * np + min(p, np - 1)) * d + c];
+        for (int j = 0; j < 6; ++j) {
+            const int q = min(g + G * j, nrows - 1);          // row 0: residual, 1: bias, 2 + p: partial p
+            const float* src = q == 0 ? s.res + row * d : (q == 1 ? s.bias : s.part + (row * np + (q - 2)) * d);
+            pv[j] = reinterpret_cast<const float4*>(src)[c4];
         }
     }
-    if (np > 0) {
+    // scratch: LDS float4[4 * d/4] (the out-projection's exchange buffer, free at this point)
+    __device__ __forceinline__ void finish(const RowSrc& s, int64_t row, int d, float* xs, float* red, float4* scratch,
+                                           bool writer) {
+        const int tid = threadIdx.x, np = s.nparts, d4 = d >> 2;
+        const int G = min(256 / d4, 4);
+        const int g = tid / d4, c4 = tid - g * d4;
+        const int nrows = np > 0 ? np + 2 : 1;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g < G) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            float t = v[e] + bs[e];
-#pragma unroll
-            for (int p = 0; p < kPartsMax; ++p) t += p < np ? pv[e][p] : 0.f;
-            v[e] = tid + 256 * e < d ? t : 0.f;
+            for (int j = 0; j < 6; ++j) {
+                if (g + G * j < nrows) { t.x += pv[j].x; t.y += pv[j].y; t.z += pv[j].z; t.w += pv[j].w; }
+            }
+            scratch[g * d4 + c4] = t;
         }
-        const float mean = block_sum<4>(v[0] + v[1], red) / (float)d;
-        const float t0 = tid < d ? v[0] - mean : 0.f, t1 = tid + 256 < d ? v[1] - mean : 0.f;
-        const float var = block_sum<4>(fmaf(t0, t0, t1 * t1), red) / (float)d;
-        const float rstd = rsqrtf(var + s.eps);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) v[e] = (v[e] - mean) * rstd * gm[e] + bt[e];
+        __syncthreads();
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < d4) {
+            z = scratch[tid];
+            for (int gg = 1; gg < G; ++gg) {
+                const float4 u = scratch[gg * d4 + tid];
+                z.x += u.x; z.y += u.y; z.z += u.z; z.w += u.w;
+            }
+        }
+        if (np > 0) {
+            const float mean = block_sum<4>((z.x + z.y) + (z.z + z.w), red) / (float)d;
+            float v = 0.f;
+            if (tid < d4) {
+                v = fmaf(z.x - mean, z.x - mean, v); v = fmaf(z.y - mean, z.y - mean, v);
+                v = fmaf(z.z - mean, z.z - mean, v); v = fmaf(z.w - mean, z.w - mean, v);
+            }
+            const float rstd = rsqrtf(block_sum<4>(v, red) / (float)d + s.eps);
+            z.x = (z.x - mean) * rstd * gm.x + bt.x; z.y = (z.y - mean) * rstd * gm.y + bt.y;
+            z.z = (z.z - mean) * rstd * gm.z + bt.z; z.w = (z.w - mean) * rstd * gm.w + bt.w;
+        }
+        if (tid < kD4Max) reinterpret_cast<float4*>(xs)[tid] = tid < d4 ? z : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (writer && s.out != nullptr && tid < d4) reinterpret_cast<float4*>(s.out + row * d)[tid] = z;
+        __syncthreads();
     }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int c = tid + 256 * e;
-        if (c < kDMax) xs[c] = c < d ? v[e] : 0.f;
-        if (writer && s.out != nullptr && c < d) s.out[row * d + c] = v[e];
-    }
-    __syncthreads();
-}
+};
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
     return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
@@ -115,8 +142,10 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
 template <int NPASS>
 struct RowDot {
     float4 w[NPASS][5];
+    float bv[NPASS];
     template <typename RowIdx>
-    __device__ __forceinline__ void load(const float* __restrict__ W, int64_t ld, RowIdx rowidx, int nrows, int d4) {
+    __device__ __forceinline__ void load(const float* __restrict__ W, const float* __restrict__ bias, int64_t ld,
+                                         RowIdx rowidx, int nrows, int d4) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane >> 4, i = lane & 15;
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
@@ -124,12 +153,11 @@ struct RowDot {
             const float4* wr = reinterpret_cast<const float4*>(W + (int64_t)rowidx(r) * ld);
 #pragma unroll
             for (int it = 0; it < 5; ++it) w[p][it] = wr[min(i + 16 * it, d4 - 1)];   // beyond d: xs is zero there
+            bv[p] = bias ? bias[rowidx(r)] : 0.f;     // fetched with the weights: a load inside run() would stall it
         }
     }
-    // ys[r] = dot(W[rowidx(r)], xs) + bias[rowidx(r)]
-    template <typename RowIdx>
-    __device__ __forceinline__ void run(const float* xs, const float* __restrict__ bias, RowIdx rowidx, int nrows,
-                                        float* ys, float scale = 1.f) const {
+    // ys[r] = (dot(W[rowidx(r)], xs) + bias[rowidx(r)]) * scale
+    __device__ __forceinline__ void run(const float* xs, int nrows, float* ys, float scale = 1.f) const {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane >> 4, i = lane & 15;
         float4 xr[5];
 #pragma unroll
@@ -144,7 +172,7 @@ struct RowDot {
             acc += __shfl_xor(acc, 2, 64);
             acc += __shfl_xor(acc, 1, 64);
             const int r = 16 * p + 4 * wave + sub;
-            if (i == 0 && r < nrows) ys[r] = (acc + (bias ? bias[rowidx(r)] : 0.f)) * scale;
+            if (i == 0 && r < nrows) ys[r] = (acc + bv[p]) * scale;
         }
     }
 };
@@ -200,6 +228,60 @@ __device__ __forceinline__ float4 mask_cols(float4 v, int c, int dh) {   // zero
     return v;
 }
 
+// softmax(q . K^T) V for one (row, head) with the keys / values already in registers: thread (p8 = tid >> 3,
+// c = tid & 7) holds float4 c of positions p0 + 32 q + p8 (q < NP).  Scores never touch LDS; two exchanges between
+// the four waves (running maximum, then sum + weighted values) instead of one barrier per phase.  kreg / vreg must be
+// masked (pad columns zero).  Result: o[0 .. 31] in LDS (zero beyond dh), valid after the function returns.
+template <int NP>
+__device__ __forceinline__ void attend_regs(const float4 (&kreg)[NP], const float4 (&vreg)[NP], const float4& q4, int S,
+                                            int dh, float scale, float* red, float4* pvred, float* o) {
+    const int tid = threadIdx.x, p8 = tid >> 3, c = tid & 7, wave = tid >> 6;
+    float sc[NP];
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        float s = dot4(q4, kreg[q]);
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        sc[q] = 32 * q + p8 < S ? s * scale : -INFINITY;
+        m = fmaxf(m, sc[q]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 8, 64));
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    if ((tid & 63) == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float lsum = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const float e = sc[q] == -INFINITY ? 0.f : __expf(sc[q] - m);
+        lsum += e;
+        acc.x = fmaf(e, vreg[q].x, acc.x); acc.y = fmaf(e, vreg[q].y, acc.y);
+        acc.z = fmaf(e, vreg[q].z, acc.z); acc.w = fmaf(e, vreg[q].w, acc.w);
+    }
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+        lsum += __shfl_xor(lsum, off, 64);
+        acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
+        acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
+    }
+    if ((tid & 63) < 8) pvred[wave * 8 + c] = acc;
+    if ((tid & 63) == 0) red[4 + wave] = lsum;
+    __syncthreads();
+    if (tid < 8) {
+        float4 t = pvred[tid];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { const float4 u = pvred[w * 8 + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        const float inv = 1.f / ((red[4] + red[5]) + (red[6] + red[7]));
+        o[4 * tid + 0] = 4 * tid + 0 < dh ? t.x * inv : 0.f; o[4 * tid + 1] = 4 * tid + 1 < dh ? t.y * inv : 0.f;
+        o[4 * tid + 2] = 4 * tid + 2 < dh ? t.z * inv : 0.f; o[4 * tid + 3] = 4 * tid + 3 < dh ? t.w * inv : 0.f;
+    }
+    __syncthreads();
+}
+
 struct LayerW {
     const float *in_w, *in_b;      // self: (3d, d) packed in_proj; cross: its first d rows (q)
     const float *out_wt;           // (d, d) TRANSPOSED out_proj weight (row = input feature)
@@ -223,19 +305,19 @@ __global__ __launch_bounds__(256) void dec_self_kernel(SelfArgs a) {
     if (a.n_done != nullptr && *a.n_done >= a.n_total) return;     // every caption has ended (uniform)
     __shared__ __attribute__((aligned(16))) float xs[kDMax];
     __shared__ __attribute__((aligned(16))) float qkv[96 + 32];    // q | k | v of this head (3 x dh <= 96)
-    __shared__ __attribute__((aligned(16))) float sc[kMLMax];
     __shared__ __attribute__((aligned(16))) float o[64];
-    __shared__ __attribute__((aligned(16))) float4 part[3 * kD4Max + 16];
-    __shared__ float4 pvred[4][8];
+    __shared__ __attribute__((aligned(16))) float4 part[4 * kD4Max];
+    __shared__ float4 pvred[32];
     __shared__ float red[8];
     const int h = blockIdx.x, tid = threadIdx.x;
     const int64_t r = blockIdx.y;
     const int d = a.d, d4 = d >> 2, dh = a.dh, pos = a.pos, S = pos + 1;
     auto rowidx = [&](int rr) { const int seg = rr / dh; return seg * d + h * dh + (rr - seg * dh); };
+    ICK_STAMP(0, 0);
+    RowIn in;
+    in.issue(a.w.src, r, d);
     RowDot<6> qd;
-    qd.load(a.w.in_w, d, rowidx, 3 * dh, d4);
-    ColDot<11> od;
-    od.load(a.w.out_wt, d, h * dh, dh, d4);
+    qd.load(a.w.in_w, a.w.in_b, d, rowidx, 3 * dh, d4);
     // cached keys / values of positions < pos: 8 lanes per position (float4 each), 32 positions per pass
     const int p8 = tid >> 3, c = tid & 7;
     constexpr int NP = kMLMax / 32;
@@ -252,71 +334,36 @@ __global__ __launch_bounds__(256) void dec_self_kernel(SelfArgs a) {
             kreg[q] = vreg[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    load_row(a.w.src, r, d, xs, red, h == 0);
+    ColDot<11> od;
+    od.load(a.w.out_wt, d, h * dh, dh, d4);
+    ICK_STAMP(0, 1);
+    in.finish(a.w.src, r, d, xs, red, part, h == 0);
+    ICK_STAMP(0, 2);
     if (tid < 32) { qkv[96 + tid] = 0.f; o[32 + tid] = 0.f; }
-    qd.run(xs, a.w.in_b, rowidx, 3 * dh, qkv);
+    qd.run(xs, 3 * dh, qkv);
     __syncthreads();
+    ICK_STAMP(0, 3);
     // the new key / value row joins the cache (pad columns stay unwritten and are masked by every reader)
     if (tid < dh) a.kc[((r * a.H + h) * a.ML + pos) * kDhp + tid] = qkv[dh + tid];
     else if (tid >= 32 && tid < 32 + dh) a.vc[((r * a.H + h) * a.ML + pos) * kDhp + tid - 32] = qkv[2 * dh + tid - 32];
-    // scores
-    float4 q4;
+    // attention over positions 0 .. pos: cached rows from the registers, the new row from LDS
+    float4 q4, kn, vn;
     q4.x = 4 * c + 0 < dh ? qkv[4 * c + 0] : 0.f; q4.y = 4 * c + 1 < dh ? qkv[4 * c + 1] : 0.f;
     q4.z = 4 * c + 2 < dh ? qkv[4 * c + 2] : 0.f; q4.w = 4 * c + 3 < dh ? qkv[4 * c + 3] : 0.f;
+    kn.x = 4 * c + 0 < dh ? qkv[dh + 4 * c + 0] : 0.f; kn.y = 4 * c + 1 < dh ? qkv[dh + 4 * c + 1] : 0.f;
+    kn.z = 4 * c + 2 < dh ? qkv[dh + 4 * c + 2] : 0.f; kn.w = 4 * c + 3 < dh ? qkv[dh + 4 * c + 3] : 0.f;
+    vn.x = 4 * c + 0 < dh ? qkv[2 * dh + 4 * c + 0] : 0.f; vn.y = 4 * c + 1 < dh ? qkv[2 * dh + 4 * c + 1] : 0.f;
+    vn.z = 4 * c + 2 < dh ? qkv[2 * dh + 4 * c + 2] : 0.f; vn.w = 4 * c + 3 < dh ? qkv[2 * dh + 4 * c + 3] : 0.f;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const int p = 32 * q + p8;
-        if (32 * q >= S) break;
-        float4 kv4 = mask_cols(kreg[q], c, dh);
-        if (p == pos) {
-            kv4.x = 4 * c + 0 < dh ? qkv[dh + 4 * c + 0] : 0.f; kv4.y = 4 * c + 1 < dh ? qkv[dh + 4 * c + 1] : 0.f;
-            kv4.z = 4 * c + 2 < dh ? qkv[dh + 4 * c + 2] : 0.f; kv4.w = 4 * c + 3 < dh ? qkv[dh + 4 * c + 3] : 0.f;
-        }
-        float s = dot4(q4, kv4);
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
-        if (c == 0 && p < S) sc[p] = s * a.scale;
+        kreg[q] = p == pos ? kn : (p < pos ? mask_cols(kreg[q], c, dh) : make_float4(0.f, 0.f, 0.f, 0.f));
+        vreg[q] = p == pos ? vn : (p < pos ? mask_cols(vreg[q], c, dh) : make_float4(0.f, 0.f, 0.f, 0.f));
     }
-    __syncthreads();
-    float m = -INFINITY;
-    for (int p = tid; p < S; p += 256) m = fmaxf(m, sc[p]);
-    m = block_max<4>(m, red);
-    float e = 0.f;
-    for (int p = tid; p < S; p += 256) { const float t = __expf(sc[p] - m); sc[p] = t; e += t; }
-    const float denom = block_sum<4>(e, red);
-    __syncthreads();
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        const int p = 32 * q + p8;
-        if (32 * q >= S) break;
-        float4 v4 = mask_cols(vreg[q], c, dh);
-        if (p == pos) {
-            v4.x = 4 * c + 0 < dh ? qkv[2 * dh + 4 * c + 0] : 0.f; v4.y = 4 * c + 1 < dh ? qkv[2 * dh + 4 * c + 1] : 0.f;
-            v4.z = 4 * c + 2 < dh ? qkv[2 * dh + 4 * c + 2] : 0.f; v4.w = 4 * c + 3 < dh ? qkv[2 * dh + 4 * c + 3] : 0.f;
-        }
-        const float pr = p < S ? sc[p] : 0.f;
-        acc.x = fmaf(pr, v4.x, acc.x); acc.y = fmaf(pr, v4.y, acc.y);
-        acc.z = fmaf(pr, v4.z, acc.z); acc.w = fmaf(pr, v4.w, acc.w);
-    }
-#pragma unroll
-    for (int off = 8; off < 64; off <<= 1) {
-        acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
-        acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
-    }
-    if ((tid & 63) < 8) pvred[tid >> 6][c] = acc;
-    __syncthreads();
-    if (tid < 8) {
-        float4 t = pvred[0][tid];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) { const float4 u = pvred[w][tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-        const float inv = 1.f / denom;
-        o[4 * tid + 0] = 4 * tid + 0 < dh ? t.x * inv : 0.f; o[4 * tid + 1] = 4 * tid + 1 < dh ? t.y * inv : 0.f;
-        o[4 * tid + 2] = 4 * tid + 2 < dh ? t.z * inv : 0.f; o[4 * tid + 3] = 4 * tid + 3 < dh ? t.w * inv : 0.f;
-    }
-    __syncthreads();
+    attend_regs<NP>(kreg, vreg, q4, S, dh, a.scale, red, pvred, o);
+    ICK_STAMP(0, 4);
     od.run(o, d4, part, a.w.part + (r * a.H + h) * d);
+    ICK_STAMP(0, 5);
 }
 
 struct CrossArgs {
@@ -337,18 +384,18 @@ __global__ __launch_bounds__(256) void dec_cross_kernel(CrossArgs a) {
     __shared__ __attribute__((aligned(16))) float qs[32];
     __shared__ __attribute__((aligned(16))) float sc[kSMax];
     __shared__ __attribute__((aligned(16))) float o[64];
-    __shared__ __attribute__((aligned(16))) float4 part[3 * kD4Max + 16];
-    __shared__ float4 pvred[4][8];
+    __shared__ __attribute__((aligned(16))) float4 part[4 * kD4Max];
+    __shared__ float4 pvred[32];
     __shared__ float red[8];
     const int h = blockIdx.x, tid = threadIdx.x;
     const int64_t r = blockIdx.y;
     const int d = a.d, d4 = d >> 2, dh = a.dh, S = a.S;
     auto rowidx = [&](int rr) { return h * dh + rr; };
     ICK_STAMP(1, 0);
+    RowIn in;
+    in.issue(a.w.src, r, d);
     RowDot<2> qd;
-    qd.load(a.w.in_w, d, rowidx, dh, d4);
-    ColDot<11> od;
-    od.load(a.w.out_wt, d, h * dh, dh, d4);
+    qd.load(a.w.in_w, a.w.in_b, d, rowidx, dh, d4);
     const int p8 = tid >> 3, c = tid & 7;
     const int64_t b = r / a.rows_per_sample;
     const float* Kb = a.Kmem + b * a.kv_bs + (int64_t)h * S * kDhp;
@@ -365,77 +412,86 @@ __global__ __launch_bounds__(256) void dec_cross_kernel(CrossArgs a) {
         const int p = min(32 * q + p8, S - 1);
         vreg[q] = *reinterpret_cast<const float4*>(Vb + (int64_t)p * kDhp + 4 * c);
     }
+    ColDot<11> od;
+    od.load(a.w.out_wt, d, h * dh, dh, d4);
     ICK_STAMP(1, 1);
-    load_row(a.w.src, r, d, xs, red, h == 0);
+    in.finish(a.w.src, r, d, xs, red, part, h == 0);
     ICK_STAMP(1, 2);
     if (tid < 32) { qs[tid] = 0.f; o[32 + tid] = 0.f; }
     __syncthreads();
-    qd.run(xs, a.w.in_b, rowidx, dh, qs, a.scale);     // q * 1/sqrt(dh), as nn.MultiheadAttention scales it
+    qd.run(xs, dh, qs, a.scale);     // q * 1/sqrt(dh), as nn.MultiheadAttention scales it
     __syncthreads();
     ICK_STAMP(1, 3);
-    const float4 q4 = reinterpret_cast<const float4*>(qs)[c];   // pad entries are zero
-    for (int s0 = 0; s0 < S; s0 += 32 * NP) {
-        if (s0 > 0) {
+    const float4 q4 = reinterpret_cast<const float4*>(qs)[c];   // pad entries are zero; already scaled by 1/sqrt(dh)
+    if (S <= 32 * NP) {
+        // the whole memory is in the registers: scores, softmax and P.V without an LDS score buffer
 #pragma unroll
+        for (int q = 0; q < NP; ++q) { kreg[q] = mask_cols(kreg[q], c, dh); vreg[q] = mask_cols(vreg[q], c, dh); }
+        attend_regs<NP>(kreg, vreg, q4, S, dh, 1.f, red, pvred, o);
+    } else {
+        for (int s0 = 0; s0 < S; s0 += 32 * NP) {
+            if (s0 > 0) {
+    #pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const int p = min(s0 + 32 * q + p8, S - 1);
+                    kreg[q] = *reinterpret_cast<const float4*>(Kb + (int64_t)p * kDhp + 4 * c);
+                }
+            }
+    #pragma unroll
             for (int q = 0; q < NP; ++q) {
-                const int p = min(s0 + 32 * q + p8, S - 1);
-                kreg[q] = *reinterpret_cast<const float4*>(Kb + (int64_t)p * kDhp + 4 * c);
+                const int p = s0 + 32 * q + p8;
+                float s = dot4(q4, mask_cols(kreg[q], c, dh));
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                s += __shfl_xor(s, 4, 64);
+                if (c == 0 && p < S) sc[p] = s;
             }
         }
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const int p = s0 + 32 * q + p8;
-            float s = dot4(q4, mask_cols(kreg[q], c, dh));
-            s += __shfl_xor(s, 1, 64);
-            s += __shfl_xor(s, 2, 64);
-            s += __shfl_xor(s, 4, 64);
-            if (c == 0 && p < S) sc[p] = s;
-        }
-    }
-    __syncthreads();
-    ICK_STAMP(1, 4);
-    float m = -INFINITY;
-    for (int p = tid; p < S; p += 256) m = fmaxf(m, sc[p]);
-    m = block_max<4>(m, red);
-    float e = 0.f;
-    for (int p = tid; p < S; p += 256) { const float t = __expf(sc[p] - m); sc[p] = t; e += t; }
-    const float denom = block_sum<4>(e, red);
-    __syncthreads();
-    ICK_STAMP(1, 5);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s0 = 0; s0 < S; s0 += 32 * NP) {
-        if (s0 > 0) {
-#pragma unroll
+        __syncthreads();
+        ICK_STAMP(1, 4);
+        float m = -INFINITY;
+        for (int p = tid; p < S; p += 256) m = fmaxf(m, sc[p]);
+        m = block_max<4>(m, red);
+        float e = 0.f;
+        for (int p = tid; p < S; p += 256) { const float t = __expf(sc[p] - m); sc[p] = t; e += t; }
+        const float denom = block_sum<4>(e, red);
+        __syncthreads();
+        ICK_STAMP(1, 5);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s0 = 0; s0 < S; s0 += 32 * NP) {
+            if (s0 > 0) {
+    #pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const int p = min(s0 + 32 * q + p8, S - 1);
+                    vreg[q] = *reinterpret_cast<const float4*>(Vb + (int64_t)p * kDhp + 4 * c);
+                }
+            }
+    #pragma unroll
             for (int q = 0; q < NP; ++q) {
-                const int p = min(s0 + 32 * q + p8, S - 1);
-                vreg[q] = *reinterpret_cast<const float4*>(Vb + (int64_t)p * kDhp + 4 * c);
+                const int p = s0 + 32 * q + p8;
+                const float pr = p < S ? sc[p] : 0.f;
+                const float4 v4 = mask_cols(vreg[q], c, dh);
+                acc.x = fmaf(pr, v4.x, acc.x); acc.y = fmaf(pr, v4.y, acc.y);
+                acc.z = fmaf(pr, v4.z, acc.z); acc.w = fmaf(pr, v4.w, acc.w);
             }
         }
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const int p = s0 + 32 * q + p8;
-            const float pr = p < S ? sc[p] : 0.f;
-            const float4 v4 = mask_cols(vreg[q], c, dh);
-            acc.x = fmaf(pr, v4.x, acc.x); acc.y = fmaf(pr, v4.y, acc.y);
-            acc.z = fmaf(pr, v4.z, acc.z); acc.w = fmaf(pr, v4.w, acc.w);
+    #pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+            acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
+            acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
         }
+        if ((tid & 63) < 8) pvred[(tid >> 6) * 8 + c] = acc;
+        __syncthreads();
+        if (tid < 8) {
+            float4 t = pvred[tid];
+    #pragma unroll
+            for (int w = 1; w < 4; ++w) { const float4 u = pvred[w * 8 + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+            const float inv = 1.f / denom;
+            o[4 * tid + 0] = 4 * tid + 0 < dh ? t.x * inv : 0.f; o[4 * tid + 1] = 4 * tid + 1 < dh ? t.y * inv : 0.f;
+            o[4 * tid + 2] = 4 * tid + 2 < dh ? t.z * inv : 0.f; o[4 * tid + 3] = 4 * tid + 3 < dh ? t.w * inv : 0.f;
+        }
+        __syncthreads();
     }
-#pragma unroll
-    for (int off = 8; off < 64; off <<= 1) {
-        acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
-        acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
-    }
-    if ((tid & 63) < 8) pvred[tid >> 6][c] = acc;
-    __syncthreads();
-    if (tid < 8) {
-        float4 t = pvred[0][tid];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) { const float4 u = pvred[w][tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-        const float inv = 1.f / denom;
-        o[4 * tid + 0] = 4 * tid + 0 < dh ? t.x * inv : 0.f; o[4 * tid + 1] = 4 * tid + 1 < dh ? t.y * inv : 0.f;
-        o[4 * tid + 2] = 4 * tid + 2 < dh ? t.z * inv : 0.f; o[4 * tid + 3] = 4 * tid + 3 < dh ? t.w * inv : 0.f;
-    }
-    __syncthreads();
     ICK_STAMP(1, 6);
     od.run(o, d4, part, a.w.part + (r * a.H + h) * d);
     ICK_STAMP(1, 7);
@@ -457,7 +513,7 @@ __global__ __launch_bounds__(256) void dec_ffn_kernel(FfnArgs a) {
     if (a.n_done != nullptr && *a.n_done >= a.n_total) return;
     __shared__ __attribute__((aligned(16))) float xs[kDMax];
     __shared__ __attribute__((aligned(16))) float f[96];
-    __shared__ __attribute__((aligned(16))) float4 part[3 * kD4Max + 16];
+    __shared__ __attribute__((aligned(16))) float4 part[4 * kD4Max];
     __shared__ float red[8];
     const int ch = blockIdx.x, tid = threadIdx.x, nch = gridDim.x;
     const int64_t r = blockIdx.y;
@@ -465,16 +521,18 @@ __global__ __launch_bounds__(256) void dec_ffn_kernel(FfnArgs a) {
     const int j0 = ch * 64, nj = min(64, a.FF - j0);
     auto rowidx = [&](int rr) { return j0 + rr; };
     ICK_STAMP(2, 0);
+    RowIn in;
+    in.issue(a.src, r, d);
     RowDot<4> fd;
-    fd.load(a.w1, d, rowidx, nj, d4);
+    fd.load(a.w1, a.b1, d, rowidx, nj, d4);
     ColDot<22> od;
     od.load(a.w2t, d, j0, nj, d4);
     ICK_STAMP(2, 1);
-    load_row(a.src, r, d, xs, red, ch == 0);
+    in.finish(a.src, r, d, xs, red, part, ch == 0);
     ICK_STAMP(2, 2);
     if (tid < 96) f[tid] = 0.f;
     __syncthreads();
-    fd.run(xs, a.b1, rowidx, nj, f);
+    fd.run(xs, nj, f);
     __syncthreads();
     ICK_STAMP(2, 3);
     if (tid < nj) f[tid] = fmaxf(f[tid], 0.f);
@@ -498,12 +556,15 @@ struct HeadArgs {
 __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
     if (a.n_done != nullptr && *a.n_done >= a.n_total) return;
     __shared__ __attribute__((aligned(16))) float xs[kDMax];
+    __shared__ __attribute__((aligned(16))) float4 part[4 * kD4Max];
     __shared__ float red[8];
     const int tid = threadIdx.x;
     const int64_t r = blockIdx.x;
     const int d = a.d, d4 = d >> 2;
     const int64_t b = r / a.rows_per_sample;
-    load_row(a.src, r, d, xs, red, true);
+    RowIn in;
+    in.issue(a.src, r, d);
+    in.finish(a.src, r, d, xs, red, part, true);
     for (int c = tid; c < d; c += 256) a.hv[r * d + c] = a.gate ? xs[c] * a.gate[r * d + c] : xs[c];
     const int lane = tid & 63, wave = tid >> 6, sub = lane >> 4, i = lane & 15;
     for (int part = 0; part < 2; ++part) {
@@ -558,12 +619,16 @@ struct Top2 {
     float v1, v2;
     int i1, i2;
 };
+// branch-free: the merges run in every lane of a wave (nested ifs compile to exec-mask branches, ~20 per merge)
 __device__ __forceinline__ void top2_push(Top2& s, float v, int i) {
-    if (v > s.v1 || (v == s.v1 && i < s.i1)) {
-        s.v2 = s.v1; s.i2 = s.i1; s.v1 = v; s.i1 = i;
-    } else if (v > s.v2 || (v == s.v2 && i < s.i2)) {
-        s.v2 = v; s.i2 = i;
-    }
+    const bool b1 = v > s.v1 || (v == s.v1 && i < s.i1);
+    const bool b2 = v > s.v2 || (v == s.v2 && i < s.i2);
+    const float nv2 = b1 ? s.v1 : (b2 ? v : s.v2);
+    const int ni2 = b1 ? s.i1 : (b2 ? i : s.i2);
+    s.v1 = b1 ? v : s.v1;
+    s.i1 = b1 ? i : s.i1;
+    s.v2 = nv2;
+    s.i2 = ni2;
 }
 constexpr int kNone = 0x7fffffff;
 
@@ -582,6 +647,11 @@ __global__ __launch_bounds__(256) void dec_vocab_kernel(VocabArgs a) {
     const int c0 = wave * per, c1 = min(nchunk, c0 + per);
     const int64_t ra0 = (int64_t)min(m0 + fi, a.R - 1) * d, ra1 = (int64_t)min(m0 + 16 + fi, a.R - 1) * d;
     const int64_t rb = (int64_t)min(n0 + fi, a.V - 1) * d;
+    ICK_STAMP(3, 0);
+    const int row = tid >> 3, cp = tid & 7;          // epilogue role: one row, two columns
+    float bias2[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) bias2[e] = a.bv[min(n0 + 2 * cp + e, a.V - 1)];
     float4 av0[5], av1[5], bw[5];
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
@@ -593,6 +663,7 @@ __global__ __launch_bounds__(256) void dec_vocab_kernel(VocabArgs a) {
         bw[t] = *reinterpret_cast<const float4*>(a.wv + rb + kc);
         if (!ok) av0[t] = av1[t] = bw[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    ICK_STAMP(3, 1);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
@@ -611,9 +682,10 @@ __global__ __launch_bounds__(256) void dec_vocab_kernel(VocabArgs a) {
         red[wave][0][fq * 4 + rg][fi] = acc0[rg];
         red[wave][1][fq * 4 + rg][fi] = acc1[rg];
     }
+    ICK_STAMP(3, 2);
     __syncthreads();
+    ICK_STAMP(3, 3);
     // thread (row = tid >> 3, two columns): sum the four K slices in a fixed order, add the bias
-    const int row = tid >> 3, cp = tid & 7;
     const int gr = m0 + row;
     Top2 t2{-INFINITY, -INFINITY, kNone, kNone};
 #pragma unroll
@@ -622,7 +694,7 @@ __global__ __launch_bounds__(256) void dec_vocab_kernel(VocabArgs a) {
         float v = ((red[0][row >> 4][row & 15][col] + red[1][row >> 4][row & 15][col]) +
                    red[2][row >> 4][row & 15][col]) + red[3][row >> 4][row & 15][col];
         if (n < a.V) {
-            v += a.bv[n];
+            v += bias2[e];
             if (a.scores != nullptr && gr < a.R) a.scores[(int64_t)gr * a.ld + n] = v;
             top2_push(t2, v, n);
         }
@@ -632,12 +704,13 @@ __global__ __launch_bounds__(256) void dec_vocab_kernel(VocabArgs a) {
         Top2 o;
         o.v1 = __shfl_xor(t2.v1, off, 64); o.i1 = __shfl_xor(t2.i1, off, 64);
         o.v2 = __shfl_xor(t2.v2, off, 64); o.i2 = __shfl_xor(t2.i2, off, 64);
-        if (o.i1 != kNone) top2_push(t2, o.v1, o.i1);
-        if (o.i2 != kNone) top2_push(t2, o.v2, o.i2);
+        top2_push(t2, o.v1, o.i1);      // empty slots carry (-inf, kNone): they never displace anything
+        top2_push(t2, o.v2, o.i2);
     }
     if (cp == 0 && gr < a.R)
         a.cand[(int64_t)gr * a.ntiles + blockIdx.x] =
             make_float4(t2.v1, __int_as_float(t2.i1), t2.v2, __int_as_float(t2.i2));
+    ICK_STAMP(3, 4);
 }
 
 struct SelectArgs {
@@ -663,8 +736,8 @@ __device__ __forceinline__ Top2 top2_merge_wave(Top2 t) {
         Top2 o;
         o.v1 = __shfl_xor(t.v1, off, 64); o.i1 = __shfl_xor(t.i1, off, 64);
         o.v2 = __shfl_xor(t.v2, off, 64); o.i2 = __shfl_xor(t.i2, off, 64);
-        if (o.i1 != kNone) top2_push(t, o.v1, o.i1);
-        if (o.i2 != kNone) top2_push(t, o.v2, o.i2);
+        top2_push(t, o.v1, o.i1);
+        top2_push(t, o.v2, o.i2);
     }
     return t;
 }
@@ -700,8 +773,8 @@ __global__ __launch_bounds__(256) void dec_select_kernel(SelectArgs a) {
         for (int q = 0; q < NC; ++q) {
             if (t0 + tid + 256 * q >= a.ntiles) continue;
             const int i1 = __float_as_int(cd[q].y), i2 = __float_as_int(cd[q].w);
-            if (i1 != kNone) top2_push(s, cd[q].x, i1);
-            if (i2 != kNone) top2_push(s, cd[q].z, i2);
+            top2_push(s, cd[q].x, i1);
+            top2_push(s, cd[q].z, i2);
         }
     }
     const int np = a.K + a.F;
@@ -713,8 +786,8 @@ __global__ __launch_bounds__(256) void dec_select_kernel(SelectArgs a) {
         Top2 t = sh[0];
 #pragma unroll
         for (int w = 1; w < 4; ++w) {
-            if (sh[w].i1 != kNone) top2_push(t, sh[w].v1, sh[w].i1);
-            if (sh[w].i2 != kNone) top2_push(t, sh[w].v2, sh[w].i2);
+            top2_push(t, sh[w].v1, sh[w].i1);
+            top2_push(t, sh[w].v2, sh[w].i2);
         }
         const int best = t.i1, second = t.i2 == kNone ? t.i1 : t.i2;
         int64_t tok = 0, msk = 0;

@@ -37,7 +37,7 @@ if __name__ == "__main__":
     import ick_amd.utils as ut
     torch.cuda.synchronize()
     # every rank reports its final weights (through rank 0's checkpoint for rank 0, directly for the others)
-    torch.save({"hist": hist, "seen": torch.cat(seen)}, os.path.join(out_dir, "rank%d.pt" % rank))
+    torch.save({"hist": hist, "seen": seen}, os.path.join(out_dir, "rank%d.pt" % rank))
     import torch.distributed as dist
     torch.save(steps[-1].flat_p.detach().cpu().clone(), os.path.join(out_dir, "flat%d.pt" % rank))
     dist.barrier()

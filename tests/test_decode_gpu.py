@@ -40,7 +40,8 @@ def fused_steps(dec, enc_out, ents, facts, max_len):
 
 @pytest.mark.parametrize("variant,K,V,Fn,max_len,seed", [("geo", 6, 50, 0, 12, 3), ("knowledge", 6, 50, 5, 12, 1),
                                                          ("news", 7, 90, 6, 10, 2), ("geo", 20, 1000, 0, 20, 5),
-                                                         ("knowledge", 20, 3000, 51, 33, 7)])
+                                                         ("knowledge", 20, 3000, 51, 33, 7),
+                                                         ("news", 60, 90, 80, 6, 8)])     # S = 336 > 256: swept memory
 def test_fused_decode_scores_and_tokens_vs_oracle(variant, K, V, Fn, max_len, seed):
     B = 3
     P = synth.make_params(variant, V, seed)

@@ -136,7 +136,9 @@ def test_two_rank_train_main(tmp_path):
     assert f0 is not None and torch.equal(f0, f1)                                  # bit-identical replicas
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert r0["hist"] == r1["hist"] or all(abs(a[1] - b[1]) < 1e-9 for a, b in zip(r0["hist"], r1["hist"]))  # same val loss
-    s0 = {tuple(row.tolist()) for row in r0["seen"]}
-    s1 = {tuple(row.tolist()) for row in r1["seen"]}
-    assert len(s0 & s1) == 0                                                       # disjoint shards of every batch
+    assert len(r0["seen"]) == len(r1["seen"]) > 0                                  # same number of steps on both ranks
+    for b0, b1 in zip(r0["seen"], r1["seen"]):                                     # every global batch: disjoint shards
+        s0 = {tuple(row.tolist()) for row in b0}
+        s1 = {tuple(row.tolist()) for row in b1}
+        assert len(s0 & s1) == 0
     assert os.path.exists(tmp_path / "checkpoint_toy.pth.tar") and not os.path.exists(tmp_path / "r1" / "checkpoint_toy.pth.tar")

@@ -26,8 +26,10 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 128)()
 lib = ctypes.CDLL(dbg)
 assert lib.ick_debug_read_stamps(buf) == 0
-names = {1: ("cross", ["weights+KV loads issued", "load_row (LN on load)", "q GEMV", "scores", "softmax", "PV", "reduce o", "out-proj"]),
-         2: ("ffn", ["weight loads issued", "load_row", "linear1 GEMV", "relu+linear2"])}
+names = {0: ("self", ["loads issued", "LN on load", "qkv GEMV", "attention", "out-proj"]),
+         1: ("cross", ["loads issued", "LN on load", "q GEMV"]),
+         2: ("ffn", ["loads issued", "LN on load", "linear1 GEMV", "relu+linear2"]),
+         3: ("vocab", ["loads issued", "MFMA + LDS write", "barrier", "reduce + candidates"])}
 for k, (nm, ph) in names.items():
     t = [buf[k * 16 + i] for i in range(len(ph) + 1)]
-    print(nm, "total %.2f us:" % ((t[-1] - t[0]) / 100.0), ", ".join("%s %.2f" % (p, (t[i + 1] - t[i]) / 100.0) for i, p in enumerate(ph)))
+    print(nm, "total %d cycles:" % (t[-1] - t[0]), ", ".join("%s %d" % (p, t[i + 1] - t[i]) for i, p in enumerate(ph)))
