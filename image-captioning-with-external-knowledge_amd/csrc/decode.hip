@@ -640,77 +640,89 @@ __global__ __launch_bounds__(256) void dec_vocab_kernel(VocabArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4][2][16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fq = lane >> 4;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 32;
+    const int n0 = blockIdx.x * 16;
     const int d = a.d;
     const int nchunk = (d + 15) >> 4;                  // 16-wide k chunks; <= 20
     const int per = (nchunk + 3) >> 2;                 // chunks per wave; <= 5
     const int c0 = wave * per, c1 = min(nchunk, c0 + per);
-    const int64_t ra0 = (int64_t)min(m0 + fi, a.R - 1) * d, ra1 = (int64_t)min(m0 + 16 + fi, a.R - 1) * d;
     const int64_t rb = (int64_t)min(n0 + fi, a.V - 1) * d;
     ICK_STAMP(3, 0);
     const int row = tid >> 3, cp = tid & 7;          // epilogue role: one row, two columns
     float bias2[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) bias2[e] = a.bv[min(n0 + 2 * cp + e, a.V - 1)];
-    float4 av0[5], av1[5], bw[5];
+    // this wave's K slice of the 16 weight rows: fetched once, reused for every block of 32 rows (beam search
+    // decodes captions x beams rows; the vocabulary matrix is the large operand)
+    float4 bw[5];
+    int koff[5];
+    bool kok[5];
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
         const int k = 16 * (c0 + t) + 4 * fq;
-        const bool ok = c0 + t < c1 && k < d;          // d % 4 == 0: a float4 is entirely inside or outside
-        const int kc = ok ? k : 0;
-        av0[t] = *reinterpret_cast<const float4*>(a.hv + ra0 + kc);
-        av1[t] = *reinterpret_cast<const float4*>(a.hv + ra1 + kc);
-        bw[t] = *reinterpret_cast<const float4*>(a.wv + rb + kc);
-        if (!ok) av0[t] = av1[t] = bw[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        kok[t] = c0 + t < c1 && k < d;               // d % 4 == 0: a float4 is entirely inside or outside
+        koff[t] = kok[t] ? k : 0;
+        bw[t] = *reinterpret_cast<const float4*>(a.wv + rb + koff[t]);
+        if (!kok[t]) bw[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    ICK_STAMP(3, 1);
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int m0 = 0; m0 < a.R; m0 += 32) {
+        const int64_t ra0 = (int64_t)min(m0 + fi, a.R - 1) * d, ra1 = (int64_t)min(m0 + 16 + fi, a.R - 1) * d;
+        float4 av0[5], av1[5];
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t].x, bw[t].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t].x, bw[t].x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t].y, bw[t].y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t].y, bw[t].y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t].z, bw[t].z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t].z, bw[t].z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t].w, bw[t].w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t].w, bw[t].w, acc1, 0, 0, 0);
-    }
-    // C/D map: col = lane & 15, row = (lane >> 4) * 4 + reg
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-        red[wave][0][fq * 4 + rg][fi] = acc0[rg];
-        red[wave][1][fq * 4 + rg][fi] = acc1[rg];
-    }
-    ICK_STAMP(3, 2);
-    __syncthreads();
-    ICK_STAMP(3, 3);
-    // thread (row = tid >> 3, two columns): sum the four K slices in a fixed order, add the bias
-    const int gr = m0 + row;
-    Top2 t2{-INFINITY, -INFINITY, kNone, kNone};
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int col = 2 * cp + e, n = n0 + col;
-        float v = ((red[0][row >> 4][row & 15][col] + red[1][row >> 4][row & 15][col]) +
-                   red[2][row >> 4][row & 15][col]) + red[3][row >> 4][row & 15][col];
-        if (n < a.V) {
-            v += bias2[e];
-            if (a.scores != nullptr && gr < a.R) a.scores[(int64_t)gr * a.ld + n] = v;
-            top2_push(t2, v, n);
+        for (int t = 0; t < 5; ++t) {
+            av0[t] = *reinterpret_cast<const float4*>(a.hv + ra0 + koff[t]);
+            av1[t] = *reinterpret_cast<const float4*>(a.hv + ra1 + koff[t]);
+            if (!kok[t]) av0[t] = av1[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-    }
+        ICK_STAMP(3, 1);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int off = 1; off < 8; off <<= 1) {
-        Top2 o;
-        o.v1 = __shfl_xor(t2.v1, off, 64); o.i1 = __shfl_xor(t2.i1, off, 64);
-        o.v2 = __shfl_xor(t2.v2, off, 64); o.i2 = __shfl_xor(t2.i2, off, 64);
-        top2_push(t2, o.v1, o.i1);      // empty slots carry (-inf, kNone): they never displace anything
-        top2_push(t2, o.v2, o.i2);
+        for (int t = 0; t < 5; ++t) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t].x, bw[t].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t].x, bw[t].x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t].y, bw[t].y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t].y, bw[t].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t].z, bw[t].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t].z, bw[t].z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t].w, bw[t].w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t].w, bw[t].w, acc1, 0, 0, 0);
+        }
+        // C/D map: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            red[wave][0][fq * 4 + rg][fi] = acc0[rg];
+            red[wave][1][fq * 4 + rg][fi] = acc1[rg];
+        }
+        ICK_STAMP(3, 2);
+        __syncthreads();
+        ICK_STAMP(3, 3);
+        // thread (row = tid >> 3, two columns): sum the four K slices in a fixed order, add the bias
+        const int gr = m0 + row;
+        Top2 t2{-INFINITY, -INFINITY, kNone, kNone};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int col = 2 * cp + e, n = n0 + col;
+            float v = ((red[0][row >> 4][row & 15][col] + red[1][row >> 4][row & 15][col]) +
+                       red[2][row >> 4][row & 15][col]) + red[3][row >> 4][row & 15][col];
+            if (n < a.V) {
+                v += bias2[e];
+                if (a.scores != nullptr && gr < a.R) a.scores[(int64_t)gr * a.ld + n] = v;
+                top2_push(t2, v, n);
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            Top2 o;
+            o.v1 = __shfl_xor(t2.v1, off, 64); o.i1 = __shfl_xor(t2.i1, off, 64);
+            o.v2 = __shfl_xor(t2.v2, off, 64); o.i2 = __shfl_xor(t2.i2, off, 64);
+            top2_push(t2, o.v1, o.i1);      // empty slots carry (-inf, kNone): they never displace anything
+            top2_push(t2, o.v2, o.i2);
+        }
+        if (cp == 0 && gr < a.R)
+            a.cand[(int64_t)gr * a.ntiles + blockIdx.x] =
+                make_float4(t2.v1, __int_as_float(t2.i1), t2.v2, __int_as_float(t2.i2));
+        ICK_STAMP(3, 4);
+        if (m0 + 32 < a.R) __syncthreads();       // the exchange buffer is reused by the next block of rows
     }
-    if (cp == 0 && gr < a.R)
-        a.cand[(int64_t)gr * a.ntiles + blockIdx.x] =
-            make_float4(t2.v1, __int_as_float(t2.i1), t2.v2, __int_as_float(t2.i2));
-    ICK_STAMP(3, 4);
 }
 
 struct SelectArgs {
@@ -867,8 +879,7 @@ __device__ __forceinline__ void topk_push(TopK& t, float v, int c) {
 }
 
 struct BeamArgs {
-    const float* scores; int64_t ld;    // (R, ld) vocabulary logits of this step
-    const float* ptr;                   // (R, K + F) pointer scores
+    const float* rec;                   // (R, nchunk, kBeamRec) chunk records of dec_beam_partial_kernel
     float* cum;                         // (R) cumulative log-probability of every hypothesis
     int32_t* fin;                       // (R) hypothesis has produced <end>
     const int64_t* seq_in; int64_t* seq_out;     // (R, max_len) tokens so far
@@ -883,76 +894,163 @@ struct BeamArgs {
     int n_total;
 };
 
+// Block-wide arg-best of (value, code) pairs: larger value wins, ties go to the smaller code.  Result in every thread.
+__device__ __forceinline__ void block_best(float& v, int& c, float* shv, int* shc) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float ov = __shfl_xor(v, off, 64);
+        const int oc = __shfl_xor(c, off, 64);
+        const bool take = ov > v || (ov == v && oc < c);
+        v = take ? ov : v;
+        c = take ? oc : c;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { shv[threadIdx.x >> 6] = v; shc[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    v = shv[0]; c = shc[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        const bool take = shv[w] > v || (shv[w] == v && shc[w] < c);
+        v = take ? shv[w] : v;
+        c = take ? shc[w] : c;
+    }
+}
+
+constexpr int kBeamChunk = 1024;      // scores per stage-1 workgroup
+constexpr int kBeamRec = 2 + 2 * kBeamMax;   // floats per (row, chunk) record: max, sum of exp, kBeamMax x (value, index)
+
+// Stage 1 of the beam selection, one workgroup per (chunk of 1024 scores, row): the chunk's maximum, its sum of
+// exp(score - maximum), and its k best (value, index) pairs -- 5 x 10 k scores per caption are reduced by 50
+// workgroups instead of one.
+struct BeamPartArgs {
+    const float* scores; int64_t ld; const float* ptr;
+    const float* cum; const int32_t* fin;
+    float* rec;                         // (R, nchunk, kBeamRec)
+    int R, k, V, np, nchunk;
+    const int32_t* n_done; int n_total;
+};
+__global__ __launch_bounds__(256) void dec_beam_partial_kernel(BeamPartArgs a) {
+    if (*a.n_done >= a.n_total) return;
+    __shared__ float shv[4];
+    __shared__ int shc[4];
+    __shared__ float red[8];
+    const int tid = threadIdx.x, ch = blockIdx.x;
+    const int64_t r = blockIdx.y;
+    if (a.fin[r] || a.cum[r] == -INFINITY) return;         // ended / unused hypothesis: nothing to expand (uniform)
+    const int Vx = a.V + a.np;
+    const float* row = a.scores + r * a.ld;
+    const float* pr = a.ptr + r * a.np;
+    float x[4];
+    int idx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        idx[q] = ch * kBeamChunk + tid + 256 * q;
+        const int v = min(idx[q], Vx - 1);
+        x[q] = v < a.V ? row[v] : pr[v - a.V];
+        if (idx[q] >= Vx) { x[q] = -INFINITY; idx[q] = kNone; }
+    }
+    float m = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+    m = block_max<4>(m, red);
+    float e = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e += x[q] == -INFINITY ? 0.f : __expf(x[q] - m);
+    e = block_sum<4>(e, red);
+    float* rec = a.rec + (r * a.nchunk + ch) * kBeamRec;
+    if (tid == 0) { rec[0] = m; rec[1] = e; }
+    for (int round = 0; round < a.k; ++round) {
+        float bv = -INFINITY; int bc = kNone;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool take = x[q] > bv || (x[q] == bv && idx[q] < bc);
+            bv = take ? x[q] : bv;
+            bc = take ? idx[q] : bc;
+        }
+        block_best(bv, bc, shv, shc);
+        if (tid == 0) { rec[2 + 2 * round] = bv; rec[3 + 2 * round] = __int_as_float(bc); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (idx[q] == bc) { x[q] = -INFINITY; idx[q] = kNone; }      // the winner leaves the pool
+    }
+}
+
 __global__ __launch_bounds__(256) void dec_select_beam_kernel(BeamArgs a) {
     if (*a.n_done >= a.n_total) return;
-    __shared__ TopK sh[256];
-    __shared__ float red[8];
+    __shared__ float shv[4];
+    __shared__ int shc[4];
     __shared__ float cum_s[kBeamMax], lse_s[kBeamMax];
     __shared__ int fin_s[kBeamMax], parent_s[kBeamMax], tok_s[kBeamMax], nfin_s[kBeamMax];
     const int tid = threadIdx.x, k = a.k;
     const int64_t r0 = (int64_t)blockIdx.x * k;
     const int np = a.K + a.F, Vx = a.V + np;
+    const int nchunk = (Vx + kBeamChunk - 1) / kBeamChunk;
     if (tid < k) { cum_s[tid] = a.cum[r0 + tid]; fin_s[tid] = a.fin[r0 + tid]; }
     __syncthreads();
-    // log-sum-exp of every live row over its V + K + F scores (log-softmax normaliser)
-    for (int j = 0; j < k; ++j) {
-        if (fin_s[j] || cum_s[j] == -INFINITY) continue;       // uniform
-        const float* row = a.scores + (r0 + j) * a.ld;
-        const float* pr = a.ptr + (r0 + j) * np;
+    // log-sum-exp of every live row from its chunk records (wave j handles row j, j + 4)
+    for (int j = tid >> 6; j < k; j += 4) {
+        if (fin_s[j] || cum_s[j] == -INFINITY) continue;
+        const int lane = tid & 63;
         float m = -INFINITY;
-        for (int v = tid; v < Vx; v += 256) m = fmaxf(m, v < a.V ? row[v] : pr[v - a.V]);
-        m = block_max<4>(m, red);
+        for (int c = lane; c < nchunk; c += 64) m = fmaxf(m, a.rec[((r0 + j) * nchunk + c) * kBeamRec]);
+        m = wave_max(m);
         float e = 0.f;
-        for (int v = tid; v < Vx; v += 256) e += __expf((v < a.V ? row[v] : pr[v - a.V]) - m);
-        e = block_sum<4>(e, red);
-        if (tid == 0) lse_s[j] = m + __logf(e);
-        __syncthreads();
-    }
-    TopK t;
-    topk_init(t);
-    for (int j = 0; j < k; ++j) {
-        if (cum_s[j] == -INFINITY) continue;
-        if (fin_s[j]) {                                        // an ended hypothesis competes with its final score
-            if (tid == 0) topk_push(t, cum_s[j], j * Vx);
-            continue;
+        for (int c = lane; c < nchunk; c += 64) {
+            const float* rc = a.rec + ((r0 + j) * nchunk + c) * kBeamRec;
+            e += rc[1] * __expf(rc[0] - m);
         }
-        const float* row = a.scores + (r0 + j) * a.ld;
-        const float* pr = a.ptr + (r0 + j) * np;
-        const float base = cum_s[j] - lse_s[j];
-        for (int v = tid; v < Vx; v += 256) topk_push(t, base + (v < a.V ? row[v] : pr[v - a.V]), j * Vx + v);
+        e = wave_sum(e);
+        if (lane == 0) lse_s[j] = m + __logf(e);
     }
-    sh[tid] = t;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) {
-            TopK x = sh[tid];
-            const TopK y = sh[tid + o];
+    // candidates: k per (live row, chunk), one per ended row; every thread keeps up to NC of them
+    constexpr int NC = 8;
+    float cv[NC]; int cc[NC];
+    const int per_row = nchunk * k, total = k * per_row;
 #pragma unroll
-            for (int i = 0; i < kBeamMax; ++i)
-                if (y.c[i] != kNone) topk_push(x, y.v[i], y.c[i]);
-            sh[tid] = x;
+    for (int q = 0; q < NC; ++q) {
+        cv[q] = -INFINITY; cc[q] = kNone;
+        const int id = tid + 256 * q;
+        if (id < total) {
+            const int j = id / per_row, rem = id - j * per_row, c = rem / k, slot = rem - c * k;
+            if (cum_s[j] != -INFINITY) {
+                if (fin_s[j]) {
+                    if (rem == 0) { cv[q] = cum_s[j]; cc[q] = j * Vx; }        // an ended hypothesis competes as it is
+                } else {
+                    const float* rc = a.rec + ((r0 + j) * nchunk + c) * kBeamRec;
+                    const int idx = __float_as_int(rc[3 + 2 * slot]);
+                    if (idx != kNone) { cv[q] = cum_s[j] - lse_s[j] + rc[2 + 2 * slot]; cc[q] = j * Vx + idx; }
+                }
+            }
         }
-        __syncthreads();
     }
-    if (tid < k) {
-        const TopK best = sh[0];
-        float v = -INFINITY; int c = kNone;
+    for (int round = 0; round < k; ++round) {
+        float bv = -INFINITY; int bc = kNone;
 #pragma unroll
-        for (int i = 0; i < kBeamMax; ++i) if (i == tid) { v = best.v[i]; c = best.c[i]; }
-        int parent = 0, tok = a.pad_token, nf = 1;
-        if (c != kNone) {
-            parent = c / Vx;
-            if (fin_s[parent]) { nf = 1; tok = a.pad_token; }
-            else { tok = c - parent * Vx; nf = tok == a.end_token; }
-        } else {
-            v = -INFINITY;                                      // fewer candidates than beams: a dead slot
+        for (int q = 0; q < NC; ++q) {
+            const bool take = cv[q] > bv || (cv[q] == bv && cc[q] < bc);
+            bv = take ? cv[q] : bv;
+            bc = take ? cc[q] : bc;
         }
-        parent_s[tid] = parent; tok_s[tid] = tok; nfin_s[tid] = nf;
-        a.cum[r0 + tid] = v;
-        a.fin[r0 + tid] = nf;
-        const bool live = c != kNone && !nf;
-        a.next_token[r0 + tid] = live ? tok : 0;
-        a.next_mask[r0 + tid] = !live ? 0 : ((a.has_facts && tok >= a.V + a.K) ? 2 : (tok >= a.V ? 1 : 0));
+        block_best(bv, bc, shv, shc);
+#pragma unroll
+        for (int q = 0; q < NC; ++q)
+            if (cc[q] == bc) { cv[q] = -INFINITY; cc[q] = kNone; }
+        if (tid == 0) {
+            float v = bv; const int c = bc;
+            int parent = 0, tok = a.pad_token, nf = 1;
+            if (c != kNone) {
+                parent = c / Vx;
+                if (fin_s[parent]) { nf = 1; tok = a.pad_token; }
+                else { tok = c - parent * Vx; nf = tok == a.end_token; }
+            } else {
+                v = -INFINITY;                                      // fewer candidates than beams: a dead slot
+            }
+            parent_s[round] = parent; tok_s[round] = tok; nfin_s[round] = nf;
+            a.cum[r0 + round] = v;
+            a.fin[r0 + round] = nf;
+            const bool live = c != kNone && !nf;
+            a.next_token[r0 + round] = live ? tok : 0;
+            a.next_mask[r0 + round] = !live ? 0 : ((a.has_facts && tok >= a.V + a.K) ? 2 : (tok >= a.V ? 1 : 0));
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -1063,7 +1161,7 @@ extern "C" int ick_decode_layers(const ick_decode_ctx* c, int32_t pos, void* str
     va.hv = c->hv; va.wv = c->wv; va.bv = c->bv; va.scores = c->scores; va.ld = c->scores_ld;
     va.cand = reinterpret_cast<float4*>(c->cand); va.R = R; va.d = d; va.V = c->V; va.ntiles = ceil_div(c->V, 16);
     va.n_done = c->n_done; va.n_total = R;
-    hipLaunchKernelGGL(dec_vocab_kernel, dim3(va.ntiles, ceil_div(R, 32)), dim3(256), 0, s, va);
+    hipLaunchKernelGGL(dec_vocab_kernel, dim3(va.ntiles), dim3(256), 0, s, va);
     ICK_LAUNCH_RET();
 }
 
@@ -1090,8 +1188,16 @@ extern "C" int ick_decode_select_beam(const ick_decode_ctx* c, const ick_beam_st
                   c->word_emb && c->pe && c->x0 && c->ee);
     ICK_CHECK_ARG(bs->cum && bs->fin && bs->seq_in && bs->seq_out && bs->anc_in && bs->anc_out);
     ICK_CHECK_ARG((bs->cap_in == nullptr) == (bs->cap_out == nullptr));
+    ICK_CHECK_ARG(bs->rec != nullptr);
+    const int Vx = c->V + c->K + c->F, nchunk = ceil_div(Vx, kBeamChunk);
+    ICK_CHECK_ARG(c->rows_per_sample * nchunk * c->rows_per_sample <= 256 * 8);      // candidates one thread can hold
+    BeamPartArgs pa;
+    pa.scores = c->scores; pa.ld = c->scores_ld; pa.ptr = c->ptr; pa.cum = bs->cum; pa.fin = bs->fin; pa.rec = bs->rec;
+    pa.R = c->R; pa.k = c->rows_per_sample; pa.V = c->V; pa.np = c->K + c->F; pa.nchunk = nchunk;
+    pa.n_done = c->n_done; pa.n_total = c->R;
+    hipLaunchKernelGGL(dec_beam_partial_kernel, dim3(nchunk, c->R), dim3(256), 0, (hipStream_t)stream, pa);
     BeamArgs a;
-    a.scores = c->scores; a.ld = c->scores_ld; a.ptr = c->ptr; a.cum = bs->cum; a.fin = bs->fin;
+    a.rec = bs->rec; a.cum = bs->cum; a.fin = bs->fin;
     a.seq_in = bs->seq_in; a.seq_out = bs->seq_out; a.anc_in = bs->anc_in; a.anc_out = bs->anc_out;
     a.cap_in = bs->cap_in; a.cap_out = bs->cap_out; a.n_done = c->n_done;
     a.next_token = c->next_token; a.next_mask = c->next_mask;

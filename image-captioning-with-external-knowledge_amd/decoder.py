@@ -701,6 +701,9 @@ class DecoderTransformer(nn.Module):
         t["x0"].copy_(x0.view(R, d))
         bs = L.BeamState()
         bs.cum, bs.fin, bs.start_token = cum.data_ptr(), fin.data_ptr(), self.word_map["<start>"]
+        Vx = V + K + (fe.shape[1] if fe is not None else 0)
+        rec = torch.empty(R, (Vx + 1023) // 1024, 18, device=dev, dtype=torch.float32)
+        bs.rec = rec.data_ptr()
         for i in range(max_pred_len):
             cur, nxt = i & 1, (i + 1) & 1
             c.anc = anc[cur].data_ptr()

@@ -83,7 +83,7 @@ class DecodeCtx(C.Structure):
 
 
 class BeamState(C.Structure):
-    _fields_ = [(n, vp) for n in ("cum", "fin", "seq_in", "seq_out", "anc_in", "anc_out", "cap_in", "cap_out")] + \
+    _fields_ = [(n, vp) for n in ("cum", "fin", "seq_in", "seq_out", "anc_in", "anc_out", "cap_in", "cap_out", "rec")] + \
                [("start_token", i32)]
 
 

@@ -263,6 +263,7 @@ typedef struct {
     const int64_t* seq_in; int64_t* seq_out;        /* (R, max_len) */
     const int32_t* anc_in; int32_t* anc_out;        /* (R, max_len) */
     const int64_t* cap_in; int64_t* cap_out;        /* optional (R, max_len) */
+    float* rec;                                     /* workspace (R, ceil((V+K+F)/1024), 18): per-chunk max / sum / best-k records */
     int32_t start_token;
 } ick_beam_state;
 int ick_decode_select_beam(const ick_decode_ctx* ctx, const ick_beam_state* beam, int32_t pos, void* stream);
