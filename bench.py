@@ -31,7 +31,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CONV1_HBM_BYTES = 161.9e6   # measured, see profiles/r01_f_pmc_conv1.txt
+TRAFFIC_TABLE = os.path.join(ROOT, "profiles", "r02_traffic.json")   # PMC bytes per launch, see its "_source"
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_GBS = 8000.0
 
@@ -287,21 +287,25 @@ def main():
                   ("cfg4", "train"): 1.99e6 / 3, ("cfg5", "greedy"): 3.39e6}
         executed_gflop = {("cfg2", "train"): 108.0, ("cfg2", "forward"): 50.85, ("cfg4", "forward"): 101.3}
         roof = {}
+        traffic = {}
+        if os.path.exists(TRAFFIC_TABLE):
+            traffic = json.load(open(TRAFFIC_TABLE))
+        for r in by_kernel:
+            # HBM bytes per launch from the PMC counters (valid for the workload they were collected on: cfg2 / cfg5)
+            if r["name"] in traffic and cfgname in ("cfg2", "cfg5"):
+                r["traffic"] = traffic[r["name"]]
         if by_kernel:
             dom = by_kernel[0]
             roof = {"bound": dom.get("bound", "latency"), "achieved": dom.get("achieved"), "peak": dom.get("peak"),
                     "unit": dom.get("unit"), "frac": dom.get("frac"), "kernel": dom["name"],
                     "kernel_avg_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
                     "share_of_kernel_time": dom["us_per_step"] / max(1e-9, sum(r["us_per_step"] for r in by_kernel)),
-                    "traffic": None,
+                    "traffic": dom.get("traffic"),
                     "sum_kernel_us_per_step": sum(r["us_per_step"] for r in by_kernel),
                     "by_kernel": by_kernel,
                     "how": "HIP events on the launch stream around every C-ABI launch of %d eager single-stream steps "
                            "after the timed region; work = algorithmic FLOP (fp32 MFMA peak %.1f TFLOP/s) or bytes "
                            "(HBM peak %.0f GB/s)" % (args.profile_steps, PEAK_FP32_MFMA_TFLOPS, PEAK_HBM_GBS)}
-            for r in by_kernel:
-                if r["name"].startswith("GEMM %dx300x2048" % (B * 196)) and B == 64:
-                    r["traffic"] = CONV1_HBM_BYTES      # PMC: profiles/r01_f_pmc_conv1.txt (algorithmic 120.3 MB)
         bnd = bounds.get((cfgname, args.mode))
         if bnd is not None:
             roof["pass_bound_steps_per_s"] = bnd * world

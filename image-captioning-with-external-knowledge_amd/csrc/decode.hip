@@ -857,27 +857,6 @@ __global__ __launch_bounds__(256) void dec_select_kernel(SelectArgs a) {
 // beam selection: one workgroup per caption; its k hypotheses are rows b*k .. b*k+k-1
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kBeamMax = 8;
-struct TopK {
-    float v[kBeamMax];
-    int c[kBeamMax];
-};
-__device__ __forceinline__ bool better(float av, int ac, float bv, int bc) { return av > bv || (av == bv && ac < bc); }
-__device__ __forceinline__ void topk_init(TopK& t) {
-#pragma unroll
-    for (int i = 0; i < kBeamMax; ++i) { t.v[i] = -INFINITY; t.c[i] = kNone; }
-}
-__device__ __forceinline__ void topk_push(TopK& t, float v, int c) {
-    if (!better(v, c, t.v[kBeamMax - 1], t.c[kBeamMax - 1])) return;
-    t.v[kBeamMax - 1] = v; t.c[kBeamMax - 1] = c;
-#pragma unroll
-    for (int i = kBeamMax - 1; i > 0; --i) {
-        if (better(t.v[i], t.c[i], t.v[i - 1], t.c[i - 1])) {
-            const float fv = t.v[i]; t.v[i] = t.v[i - 1]; t.v[i - 1] = fv;
-            const int fc = t.c[i]; t.c[i] = t.c[i - 1]; t.c[i - 1] = fc;
-        }
-    }
-}
-
 struct BeamArgs {
     const float* rec;                   // (R, nchunk, kBeamRec) chunk records of dec_beam_partial_kernel
     float* cum;                         // (R) cumulative log-probability of every hypothesis

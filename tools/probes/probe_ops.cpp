@@ -47,6 +47,9 @@ int main(int argc, char** argv) {
         printf("%-28s M=%5d N=%5d K=%4d : %8.2f us  %6.1f TFLOP/s\n", name, M, N, K, us, 2.0 * M * N * K / us * 1e-6);
     };
     gemm("feat_proj (k-major A)", 12544, 300, 2048, true, 0);
+    gemm("feat_proj B=32", 6272, 300, 2048, true, 0);
+    gemm("feat_proj B=16", 3136, 300, 2048, true, 0);
+    gemm("cross KV image rows B=32", 6272, 1800, 300, false, 196);
     gemm("cross KV image rows", 12544, 1800, 300, false, 196);
     gemm("cross KV entity rows", 1280, 1800, 300, false, 20);
     gemm("vocab", 1280, 10000, 300, false, 0);
