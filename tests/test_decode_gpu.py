@@ -142,3 +142,31 @@ def test_beam_one_is_greedy_and_batch_is_independent():
     assert torch.equal(again, full)
     with pytest.raises(ick_amd.lib.IckError):
         dec.predict_beam(enc, max_len, ents, beam_size=9)
+
+
+def test_fused_decode_other_model_sizes():
+    """The decode kernels are not specialised to d = 300 / 10 heads / FF = 512: emb_dim 256, 8 heads (head width 32, no
+    pad columns), decoder_dim 384 (6 chunks), 2 layers -- forward and greedy decode vs the oracle."""
+    variant, B, K, V, max_len, seed = "geo", 3, 7, 120, 9, 11
+    d, H, FF, NL = 256, 8, 384, 2
+    P = synth.make_params(variant, V, seed, d=d, decoder_dim=FF, encoder_dim=320, num_layers=NL)
+    wm = synth.make_word_map(V)
+    m = ick_amd.load_models(variant)
+    dec = m.DecoderTransformer(word_map=wm, emb_dim=d, decoder_dim=FF, encoder_dim=320, num_heads=H, num_layers=NL)
+    missing, unexpected = dec.load_state_dict(P, strict=False)
+    assert missing == ["pos_encoder.pe"] and not unexpected
+    dec = dec.cuda().eval()
+    import ick_amd.ops as ops
+    assert ops.decode_supported(d, H, FF, 196 + K, max_len)
+    cfg = R.config_from_word_map(variant, wm, emb_dim=d, num_heads=H, num_layers=NL)
+    ents = synth.make_entities(variant, B, K, V, seed)
+    enc_out = synth.make_enc_out(B, seed, emb_dim=d)
+    out, scores, t = fused_steps(dec, enc_out.cuda(), ents, None, max_len)
+    for b in range(B):
+        with torch.no_grad():
+            seq, ref = R.predict(cfg, P, enc_out[b:b + 1], max_len, ents[b:b + 1], None, return_scores=True)
+        n = ref.shape[0]
+        assert (scores[b, :n].cpu() - ref).abs().max().item() < 2e-4
+        assert out[b].cpu().tolist() == seq.view(-1).tolist()
+    seqs = dec.predict(enc_out.cuda(), max_len, ents)
+    assert torch.equal(seqs.t().contiguous(), out)
