@@ -197,13 +197,19 @@ def main():
     def make_step(use_graph=True):
         if args.mode == "train":
             from ick_amd.training import TrainStep
-            ts = TrainStep(dec, lr=4e-4, grad_clip=5.0, seed=rank, use_graph=use_graph)   # all-reduces when world > 1
+            # encoder=: the step takes the feature map itself; Encoder.conv1 runs inside the captured step and writes
+            # the image rows straight into the decoder's memory buffer.  All-reduces its bucket when world > 1.
+            ts = TrainStep(dec, lr=4e-4, grad_clip=5.0, seed=rank, use_graph=use_graph, encoder=enc)
+            live = (batch["captions"], feats, batch["caption_masks"], batch["caption_lengths"], batch["entities"], *extra)
+            state = {"args": live}
 
             def step():
-                with torch.no_grad():
-                    e = enc(feats)
-                return ts(batch["captions"], e, batch["caption_masks"], batch["caption_lengths"], batch["entities"],
-                          *extra)
+                out = ts(*state["args"])
+                if state["args"] is live and ts.use_graph:
+                    # from now on the (HBM-resident) batch lives in the step's own input buffers -- where a loader's
+                    # host-to-device copy would put the next batch -- so no per-step device-to-device input copy
+                    state["args"] = ts.input_buffers()
+                return out
         elif args.mode == "forward":
             def step():
                 with torch.no_grad():

@@ -133,6 +133,23 @@ struct RowIn {
     }
 };
 
+// Lane exchanges inside a row of 16 lanes as DPP operands (one VALU instruction each) instead of ds_bpermute round
+// trips through the LDS crossbar (~100 cycles each, four in a row per dot product): quad_perm [1,0,3,2] / [2,3,0,1]
+// pair lanes inside a quad, row_half_mirror / row_mirror then pair quads and halves (every lane of a quad / half
+// already holds the same partial result), row_ror:8 swaps the halves of a row.
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dppi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140, kDppRor8 = 0x128;
+__device__ __forceinline__ float sum8(float v) {      // over aligned groups of 8 lanes, result in every lane
+    v += dppf<kDppXor1>(v); v += dppf<kDppXor2>(v); v += dppf<kDppHalfMirror>(v);
+    return v;
+}
+__device__ __forceinline__ float sum16(float v) { v = sum8(v); v += dppf<kDppMirror>(v); return v; }
+
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
     return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
 }
@@ -167,10 +184,7 @@ struct RowDot {
             float acc = 0.f;
 #pragma unroll
             for (int it = 0; it < 5; ++it) acc += dot4(w[p][it], xr[it]);
-            acc += __shfl_xor(acc, 8, 64);
-            acc += __shfl_xor(acc, 4, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            acc += __shfl_xor(acc, 1, 64);
+            acc = sum16(acc);
             const int r = 16 * p + 4 * wave + sub;
             if (i == 0 && r < nrows) ys[r] = (acc + bv[p]) * scale;
         }
@@ -240,14 +254,11 @@ __device__ __forceinline__ void attend_regs(const float4 (&kreg)[NP], const floa
     float m = -INFINITY;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-        float s = dot4(q4, kreg[q]);
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
+        const float s = sum8(dot4(q4, kreg[q]));
         sc[q] = 32 * q + p8 < S ? s * scale : -INFINITY;
         m = fmaxf(m, sc[q]);
     }
-    m = fmaxf(m, __shfl_xor(m, 8, 64));
+    m = fmaxf(m, dppf<kDppRor8>(m));
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     if ((tid & 63) == 0) red[wave] = m;
@@ -262,8 +273,11 @@ __device__ __forceinline__ void attend_regs(const float4 (&kreg)[NP], const floa
         acc.x = fmaf(e, vreg[q].x, acc.x); acc.y = fmaf(e, vreg[q].y, acc.y);
         acc.z = fmaf(e, vreg[q].z, acc.z); acc.w = fmaf(e, vreg[q].w, acc.w);
     }
+    lsum += dppf<kDppRor8>(lsum);
+    acc.x += dppf<kDppRor8>(acc.x); acc.y += dppf<kDppRor8>(acc.y);
+    acc.z += dppf<kDppRor8>(acc.z); acc.w += dppf<kDppRor8>(acc.w);
 #pragma unroll
-    for (int off = 8; off < 64; off <<= 1) {
+    for (int off = 16; off < 64; off <<= 1) {
         lsum += __shfl_xor(lsum, off, 64);
         acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
         acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
@@ -594,10 +608,7 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
                 acc = fmaf(__fmul_rn(xr[it].z, cv[it].z), wr[it].z, acc);
                 acc = fmaf(__fmul_rn(xr[it].w, cv[it].w), wr[it].w, acc);
             }
-            acc += __shfl_xor(acc, 8, 64);
-            acc += __shfl_xor(acc, 4, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            acc += __shfl_xor(acc, 1, 64);
+            acc = sum16(acc);
             if (i == 0 && k < n) {
                 const float ind = (part == 1 && a.eib) ? a.eib[r * a.F + k] : 1.f;
                 a.ptr[r * (a.K + a.F) + (part == 0 ? 0 : a.K) + k] = acc * ind + bias;
@@ -631,6 +642,14 @@ __device__ __forceinline__ void top2_push(Top2& s, float v, int i) {
     s.i2 = ni2;
 }
 constexpr int kNone = 0x7fffffff;
+template <int CTRL>
+__device__ __forceinline__ Top2 top2_merge_dpp(Top2 t) {
+    const float v1 = dppf<CTRL>(t.v1), v2 = dppf<CTRL>(t.v2);
+    const int i1 = dppi<CTRL>(t.i1), i2 = dppi<CTRL>(t.i2);
+    top2_push(t, v1, i1);
+    top2_push(t, v2, i2);
+    return t;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // vocabulary logits: workgroup = 16 words x 32 rows, the four waves split K; fp32 MFMA 16x16x4
@@ -709,14 +728,9 @@ __global__ __launch_bounds__(256) void dec_vocab_kernel(VocabArgs a) {
                 top2_push(t2, v, n);
             }
         }
-#pragma unroll
-        for (int off = 1; off < 8; off <<= 1) {
-            Top2 o;
-            o.v1 = __shfl_xor(t2.v1, off, 64); o.i1 = __shfl_xor(t2.i1, off, 64);
-            o.v2 = __shfl_xor(t2.v2, off, 64); o.i2 = __shfl_xor(t2.i2, off, 64);
-            top2_push(t2, o.v1, o.i1);      // empty slots carry (-inf, kNone): they never displace anything
-            top2_push(t2, o.v2, o.i2);
-        }
+        t2 = top2_merge_dpp<kDppXor1>(t2);      // empty slots carry (-inf, kNone): they never displace anything
+        t2 = top2_merge_dpp<kDppXor2>(t2);
+        t2 = top2_merge_dpp<kDppHalfMirror>(t2);
         if (cp == 0 && gr < a.R)
             a.cand[(int64_t)gr * a.ntiles + blockIdx.x] =
                 make_float4(t2.v1, __int_as_float(t2.i1), t2.v2, __int_as_float(t2.i2));
@@ -743,8 +757,12 @@ struct SelectArgs {
 };
 
 __device__ __forceinline__ Top2 top2_merge_wave(Top2 t) {
+    t = top2_merge_dpp<kDppXor1>(t);
+    t = top2_merge_dpp<kDppXor2>(t);
+    t = top2_merge_dpp<kDppHalfMirror>(t);
+    t = top2_merge_dpp<kDppMirror>(t);
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
+    for (int off = 16; off < 64; off <<= 1) {
         Top2 o;
         o.v1 = __shfl_xor(t.v1, off, 64); o.i1 = __shfl_xor(t.i1, off, 64);
         o.v2 = __shfl_xor(t.v2, off, 64); o.i2 = __shfl_xor(t.i2, off, 64);

@@ -64,8 +64,13 @@ class _GraphedCall:
 def copy_inputs(static, inputs):
     """Refresh a graph's input buffers: one foreach call instead of a Python-level copy_ per tensor (the host is
     on the critical path here: forward() has just synchronised for the length sort)."""
-    dst = [d for d, s in zip(static, inputs) if d is not None]
-    src = [s for d, s in zip(static, inputs) if d is not None]
+    # an input that IS its static buffer (the caller filled it in place) needs no copy
+    pairs = [(d, s) for d, s in zip(static, inputs) if d is not None and not (
+        s.is_cuda and s.data_ptr() == d.data_ptr() and s.shape == d.shape and s.dtype == d.dtype)]
+    if not pairs:
+        return
+    dst = [d for d, _ in pairs]
+    src = [s for _, s in pairs]
     if all(s.is_cuda and s.shape == d.shape and s.dtype == d.dtype and s.is_contiguous() for d, s in zip(dst, src)):
         ops.copy_batch(dst, src)          # one launch for all of them
     elif all(s.is_cuda and s.shape == d.shape for d, s in zip(dst, src)):

@@ -206,8 +206,15 @@ def project_heads(x, w, bias, nseg, H, S, out=None, s0=0, grp=None, a_gmap=None,
     out (B, nseg, H, S, DHP) at positions s0 .. s0+grp-1 (ick_gemm head-split epilogue)."""
     d = w.shape[0] // nseg
     K = w.shape[1]
-    x2 = x.reshape(-1, K)
-    M = x2.shape[0]
+    strided = x.dim() == 3 and not x.is_contiguous() and x.stride(2) == 1 and a_gmap is None
+    if strided:
+        # rows of a (B, T, K) view with a sample stride (the image rows inside the (B, S, d) memory buffer): no copy,
+        # the GEMM walks the groups itself
+        x2 = x
+        M = x.shape[0] * x.shape[1]
+    else:
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
     grp = grp if grp is not None else (x.shape[1] if x.dim() == 3 else M)
     Bn = M // grp
     if out is None:
@@ -215,7 +222,9 @@ def project_heads(x, w, bias, nseg, H, S, out=None, s0=0, grp=None, a_gmap=None,
     a = L.GemmArgs()
     a.A, a.B, a.C, a.bias = _p(x2), _p(w), _p(out), _p(bias)
     a.M, a.N, a.K = M, w.shape[0], K
-    a.a_rs, a.a_ks = x2.stride(0), 1
+    a.a_rs, a.a_ks = (x.stride(1) if strided else x2.stride(0)), 1
+    if strided:
+        a.a_grp, a.a_gs = x.shape[1], x.stride(0)
     if a_gmap is not None:
         a.a_grp, a.a_gs, a.a_gmap = grp, a_gs, _p(a_gmap)
     a.b_rs, a.b_ks = w.stride(0), 1

@@ -113,21 +113,24 @@ def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds, side=None):
 
 
 def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gmap, seed=0, epoch=None,
-                      fresh_pack=False, overlap=False):
+                      fresh_pack=False, overlap=False, feats=None, conv1=None):
     """Teacher-forced forward on already length-sorted inputs; returns (scores, tape).  Dropout is
     active iff the module is in train() mode (masks derive from `seed` + the device counter `epoch`).
     fresh_pack: rebuild the packed cross-K/V / transposed predicate weights from the live parameters
     (needed when they are updated behind torch's version counters, and inside captured graphs).
     overlap: run the context-encoder chain (small, latency-bound kernels) on a second stream beside the
     image-row K/V projection and the first self-attention block (for captured graphs; eager launches are
-    host-bound and gain nothing)."""
+    host-bound and gain nothing).
+    feats + conv1 = (weight, bias): instead of enc_tok, the (B, 2048, 14, 14) feature map; Encoder.conv1 then runs
+    here and writes the image rows straight into the memory buffer (no (B, 196, d) intermediate, no copy)."""
     tape = Tape()
     m = tape.misc
     ds = DropSites(seed, dec.training, epoch)
     d, V, H = dec.emb_dim, dec.vocab_size, dec.num_heads
     B, L = captions.shape
-    P, K = enc_tok.shape[1], entities.shape[1]
-    dev = enc_tok.device
+    P = feats.shape[2] * feats.shape[3] if feats is not None else enc_tok.shape[1]
+    K = entities.shape[1]
+    dev = captions.device
     ee = ops.entity_encode(dec.variant, entities, _p(dec.entity_encoder.type_embedding.weight), d,
                            facts=facts if dec.has_facts else None,
                            word_emb=_p(dec.word_embedding.weight) if dec.variant == "news" else None)
@@ -164,12 +167,21 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         ops.project_heads(ctx_f, wkv, bkv, nseg, H, S, out=kv, s0=P + K, grp=Fn)
 
     side = ops.SideStream(priority=-1) if overlap else None
-    img = enc_tok.index_select(0, gmap.long()) if gmap is not None else enc_tok
+    if feats is not None:
+        img = mem[:, :P]
+    else:
+        img = enc_tok.index_select(0, gmap.long()) if gmap is not None else enc_tok
     if side is not None:
         side.submit(entity_chain, ee, fe, mem, kv, wkv, bkv, img)
     else:
         entity_chain()
-    mem[:, :P].copy_(img)
+    if feats is not None:
+        cw, cb = conv1
+        Cc = feats.shape[1]
+        ops.gemm_raw(feats, cw.view(d, Cc), mem, B * P, d, Cc, 1, P, Cc, 1, d, bias=cb, a_grp=P, a_gs=Cc * P,
+                     c_grp=P, c_gs=S * d)
+    else:
+        mem[:, :P].copy_(img)
     if side is not None:
         side.flush()     # enqueued after the main stream's next kernel (see SideStream)
     if dec.has_facts:
@@ -517,8 +529,11 @@ class TrainStep:
     replays advance without re-capturing."""
 
     def __init__(self, decoder, lr=4e-4, grad_clip=5.0, betas=(0.9, 0.999), eps=1e-8, process_group=None, seed=0,
-                 use_graph=True):
+                 use_graph=True, encoder=None):
         self.dec = decoder
+        # with an encoder the step also accepts the (B, 2048, 14, 14) feature map: Encoder.conv1 (frozen, as in the
+        # reference's default fine_tune_encoder=False) then runs inside graph A straight into the memory buffer
+        self.enc = encoder
         self.seed = seed  # dropout mask stream; give every rank its own seed
         self.lr, self.clip, self.betas, self.eps = lr, grad_clip, betas, eps
         self.pg = process_group
@@ -564,13 +579,20 @@ class TrainStep:
         self.split = os.environ.get("ICK_SPLIT_ALLREDUCE", "0") != "0"
 
     # ---- device-only halves -------------------------------------------------------------------
-    def _part_a(self, captions, caption_masks, entities, facts, enc_tok, gmap, decode_len):
+    def _enc_kwargs(self, enc_in):
+        if enc_in.dim() == 4:
+            c1 = self.enc.conv1
+            return dict(enc_tok=None, feats=enc_in, conv1=(c1.weight.detach(), c1.bias.detach()))
+        return dict(enc_tok=enc_in)
+
+    def _part_a(self, captions, caption_masks, entities, facts, enc_in, gmap, lengths):
         dec = self.dec
         self.flat_g.zero_()
         ops.stamp("A: start")
-        scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gmap,
+        decode_len = (lengths.reshape(-1) - 1).to(torch.int32)
+        scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, gmap=gmap,
                                          seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
-                                         overlap=self.use_graph)
+                                         overlap=self.use_graph, **self._enc_kwargs(enc_in))
         ops.stamp("fwd: scores done")
         # the two scalars of the loss go straight into the tail of the gradient bucket (it was zeroed above; nothing else
         # touches those two floats)
@@ -583,12 +605,13 @@ class TrainStep:
         return self.flat_g
 
     # ---- the same step in two halves (several ranks: the early half's all-reduce overlaps the late half) ----
-    def _part_a1(self, captions, caption_masks, entities, facts, enc_tok, gmap, decode_len):
+    def _part_a1(self, captions, caption_masks, entities, facts, enc_in, gmap, lengths):
         dec = self.dec
         self.flat_g.zero_()
-        scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gmap,
+        decode_len = (lengths.reshape(-1) - 1).to(torch.int32)
+        scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, gmap=gmap,
                                          seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
-                                         overlap=self.use_graph)
+                                         overlap=self.use_graph, **self._enc_kwargs(enc_in))
         self._loss = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True,
                                    out_sum=self.flat_g[self.n:self.n + 1], out_count=self.flat_g[self.n + 1:])
         self._bp = BackwardPass(dec, tape, self._loss[2], self.grads,
@@ -710,6 +733,17 @@ class TrainStep:
         opt.load_state_dict(self.state_dict())
         return opt
 
+    def input_buffers(self):
+        """The static input tensors of the most recently captured graphs, in __call__'s argument order
+        (captions, encoder_out-or-features, caption_masks, caption_lengths, entities[, facts]).  A loader that writes
+        the next batch straight into them (pinned host-to-device copies) and calls the step with these very tensors
+        skips the per-step device-to-device copy of the inputs."""
+        st = getattr(self, "_last_static", None)
+        if st is None:
+            raise IckError("no captured graph yet: run one step first")
+        captions, masks, entities, facts, enc_in, _, lengths = st
+        return (captions, enc_in, masks, lengths, entities) + ((facts,) if facts is not None else ())
+
     def set_lr(self, lr):
         self.lr = float(lr)
         self._graphs.clear()          # baked into the captured optimizer graph
@@ -734,9 +768,14 @@ class TrainStep:
         # because pack_padded_sequence wants it (geo-aware/models.py:330-336); forward() keeps doing so.
         captions = captions.to(dev, non_blocking=True)
         caption_masks = caption_masks.to(dev, non_blocking=True)
-        enc_tok = dec._token_major(encoder_out)
-        decode_len = (caption_lengths.to(dev, non_blocking=True).reshape(-1) - 1).to(torch.int32)
-        inputs = [captions, caption_masks, entities, facts, enc_tok, None, decode_len]
+        if encoder_out.dim() == 4:
+            if self.enc is None:
+                raise IckError("TrainStep got a (B, C, H, W) feature map but was built without encoder=")
+            enc_in = encoder_out
+        else:
+            enc_in = dec._token_major(encoder_out)
+        lengths = caption_lengths.to(dev, non_blocking=True)
+        inputs = [captions, caption_masks, entities, facts, enc_in, None, lengths]
         key = tuple(None if t is None else tuple(t.shape) for t in inputs)
         if self.use_graph and key not in self._graphs:
             if len(self._graphs) >= 4:
@@ -752,6 +791,7 @@ class TrainStep:
                     ga2 = None
                 gb, _ = self._capture(self._part_b, [])
                 self._graphs[key] = (ga, static, gb, ga2)
+                self._last_static = static
             except RuntimeError as e:   # capture refused (driver / collective library state): run eagerly
                 import warnings
                 warnings.warn("ick_amd TrainStep: hipGraph capture failed (%s); continuing without graphs" % e)

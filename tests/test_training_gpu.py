@@ -422,3 +422,54 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["value"] > 0 and d["scaling"] == "weak"
+
+
+def test_train_step_from_features_and_in_place_input_buffers():
+    """TrainStep(encoder=...) takes the (B, 2048, 14, 14) feature map: Encoder.conv1 runs inside the captured step and
+    writes the image rows into the memory buffer.  Same loss / gradients as encoder(feats) followed by the step; and a
+    batch written in place into the step's own input buffers (no per-step input copy) gives the same result as passing
+    it as arguments."""
+    from ick_amd.training import TrainStep
+    variant, B, L, K, V, seed = "geo", 5, 9, 6, 150, 3
+    P = synth.make_params(variant, V, seed)
+    m = ick_amd.load_models(variant)
+    enc = m.Encoder(emb_dim=300)
+    cw, cb = synth.make_conv1(seed)
+    with torch.no_grad():
+        enc.conv1.weight.copy_(cw)
+        enc.conv1.bias.copy_(cb)
+    enc = enc.cuda().eval()
+
+    def batch_args(s2):
+        b = synth.make_batch(variant, B, L, K, V, 0, s2)
+        return b, synth.make_feats(B, s2).cuda()
+
+    res = {}
+    for mode in ("features", "encoder_out"):
+        dec = zero_dropout(build_decoder(variant, V, P).train())
+        ts = TrainStep(dec, lr=4e-4, encoder=enc if mode == "features" else None)
+        out = []
+        for s2 in (1, 2):
+            b, feats = batch_args(s2)
+            with torch.no_grad():
+                x = feats if mode == "features" else enc(feats)
+            loss = ts(b["captions"].cuda(), x, b["caption_masks"].cuda(), b["caption_lengths"].cuda(), b["entities"])
+            out.append((loss.item(), ts.flat_g[:ts.n].clone()))
+        res[mode] = (out, ts)
+    for (la, ga), (lb, gb) in zip(res["features"][0], res["encoder_out"][0]):
+        assert abs(la - lb) < 1e-5
+        assert (ga - gb).abs().max().item() < 1e-5 * max(1.0, gb.abs().max().item())
+    # in-place refill of the input buffers == passing the batch
+    ts = res["features"][1]
+    bufs = ts.input_buffers()
+    b, feats = batch_args(7)
+    dec2 = zero_dropout(build_decoder(variant, V, P).train())
+    ref_ts = TrainStep(dec2, lr=4e-4, encoder=enc)
+    with torch.no_grad():
+        ts.flat_p.copy_(ref_ts.flat_p); ts.flat_m.zero_(); ts.flat_v.zero_(); ts.counter.zero_()
+    ref_loss = ref_ts(b["captions"].cuda(), feats, b["caption_masks"].cuda(), b["caption_lengths"].cuda(), b["entities"])
+    for dst, src in zip(bufs, (b["captions"], feats, b["caption_masks"], b["caption_lengths"], b["entities"])):
+        dst.copy_(src)
+    loss = ts(*bufs)
+    assert abs(loss.item() - ref_loss.item()) < 1e-5
+    assert (ts.flat_g[:ts.n] - ref_ts.flat_g[:ref_ts.n]).abs().max().item() < 1e-5 * max(1.0, ref_ts.flat_g[:ref_ts.n].abs().max().item())
