@@ -203,7 +203,14 @@ def main():
             live = (batch["captions"], feats, batch["caption_masks"], batch["caption_lengths"], batch["entities"], *extra)
             state = {"args": live}
 
+            legacy = os.environ.get("ICK_BENCH_SEPARATE_ENCODER") == "1"   # A/B: eager Encoder + per-step input copies
+
             def step():
+                if legacy:
+                    with torch.no_grad():
+                        e = enc(feats)
+                    return ts(batch["captions"], e, batch["caption_masks"], batch["caption_lengths"],
+                              batch["entities"], *extra)
                 out = ts(*state["args"])
                 if state["args"] is live and ts.use_graph:
                     # from now on the (HBM-resident) batch lives in the step's own input buffers -- where a loader's
