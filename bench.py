@@ -305,7 +305,7 @@ def main():
             traffic = json.load(open(TRAFFIC_TABLE))
         for r in by_kernel:
             # HBM bytes per launch from the PMC counters (valid for the workload they were collected on: cfg2 / cfg5)
-            if r["name"] in traffic and cfgname in ("cfg2", "cfg5"):
+            if r["name"] in traffic and cfgname in ("cfg2", "cfg5") and args.mode != "beam":
                 r["traffic"] = traffic[r["name"]]
         if by_kernel:
             dom = by_kernel[0]
