@@ -387,14 +387,36 @@ struct Plan {
     int tiles_m, tiles_n, kchunk, split;
 };
 
+// Occupancy cap for the large-tile kernels: a workgroup that declares more LDS than it uses leaves wave slots,
+// registers and LDS of its CU to the latency-bound chain kernels that run beside it on the other stream.
+// ICK_GEMM_LDS_SINGLE / ICK_GEMM_LDS_GROUP: bytes of LDS a 64x64 / 128x64 workgroup declares (<= 65536).
+inline size_t lds_floor(int which) {
+    static long v[2] = {-1, -1};
+    if (v[which] < 0) {
+        const char* e = getenv(which ? "ICK_GEMM_LDS_GROUP" : "ICK_GEMM_LDS_SINGLE");
+        v[which] = e ? std::min(160l * 1024, std::max(0l, atol(e))) : 0;
+    }
+    return (size_t)v[which];
+}
+
 template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC>
 int launch_tile(const Plan& pl, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = WM * WN * 64;
     constexpr int STAGE = Stager<BM, AKM, VEC, 32, NT>::FLOATS + Stager<BN, BKM, VEC, 32, NT>::FLOATS;
     constexpr size_t smem = 2 * STAGE * sizeof(float);
     static_assert(smem <= 64 * 1024, "tile needs the large-LDS attribute");
+    const size_t lds = (TM > 1) ? std::max(smem, lds_floor(0)) : smem;
+    if (lds > 64 * 1024) {
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<WM, WN, TM, TN, AKM, BKM, VEC, 32>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr = true;
+        }
+    }
     hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, AKM, BKM, VEC, 32>), dim3(pl.tiles_m * pl.tiles_n, 1, pl.split),
-                       dim3(NT), smem, s, pl.a, pl.tiles_m, pl.tiles_n, pl.kchunk);
+                       dim3(NT), lds, s, pl.a, pl.tiles_m, pl.tiles_n, pl.kchunk);
     ICK_LAUNCH_RET();
 }
 template <int TM, int TN, bool AKM, bool BKM, bool VEC>
@@ -417,7 +439,8 @@ int launch_group(const Plan* const* pls, int n, hipStream_t s) {
         ga.g[i] = pls[i]->a;
     }
     for (int i = n; i < kGroupMax; ++i) { ga.wg_end[i] = total; ga.tiles_m[i] = ga.tiles_n[i] = 1; ga.kchunk[i] = 32; ga.g[i] = pls[0]->a; }
-    hipLaunchKernelGGL((gemm_group_kernel<2, 2, TM, TN, AKM, BKM, true, 32>), dim3(total), dim3(256), smem, s, ga);
+    const size_t lds = (TM > 1) ? std::max(smem, lds_floor(1)) : smem;
+    hipLaunchKernelGGL((gemm_group_kernel<2, 2, TM, TN, AKM, BKM, true, 32>), dim3(total), dim3(256), lds, s, ga);
     ICK_LAUNCH_RET();
 }
 

@@ -307,7 +307,8 @@ class DecoderTransformer(nn.Module):
         writes the flat bucket directly): drops the packed cross-K/V weights, the transposed predicate
         weights and every captured graph."""
         self.__dict__["_param_epoch"] = self.__dict__.get("_param_epoch", 0) + 1
-        for k in ("_kv_pack", "_pred_wt_cache", "_graphs", "_plist", "_dec_pack"):
+        for k in ("_kv_pack", "_pred_wt_cache", "_graphs", "_plist", "_dec_pack"):   # (_chain_cache keeps its buffer:
+            # captured training graphs write it; its key holds _param_epoch, so the contents are refreshed)
             self.__dict__.pop(k, None)
 
     def _token_major(self, encoder_out):
@@ -333,6 +334,62 @@ class DecoderTransformer(nn.Module):
             self.__dict__["_kv_pack"] = cache
         return cache[1], cache[2]
 
+    def _chain_items(self):
+        """(key, weight view) of every nn.Linear that a row-chain launch (ops.rowchain_fwd) multiplies with: per layer
+        the self-attention out-projection, the cross-attention q-projection and out-projection, linear1, linear2,
+        and -- from the second layer of a stack on -- the self-attention in_proj, which rides on the previous layer's
+        linear2 + norm launch."""
+        d = self.emb_dim
+        items = []
+        for li, layer in enumerate(self.transformer_decoder.layers):
+            items += [(("d", li, "so"), layer.self_attn.out_proj.weight), (("d", li, "cq"), layer.multihead_attn.in_proj_weight[:d]),
+                      (("d", li, "co"), layer.multihead_attn.out_proj.weight), (("d", li, "l1"), layer.linear1.weight),
+                      (("d", li, "l2"), layer.linear2.weight)]
+            if li > 0:
+                items.append((("d", li, "si"), layer.self_attn.in_proj_weight))
+        stacks = [("e", self.transformer_encoder_entities)]
+        if self.has_facts:
+            stacks.append(("f", self.transformer_encoder_facts))
+        for tag, stack in stacks:
+            for li, layer in enumerate(stack.layers):
+                items += [((tag, li, "so"), layer.self_attn.out_proj.weight), ((tag, li, "l1"), layer.linear1.weight),
+                          ((tag, li, "l2"), layer.linear2.weight)]
+                if li > 0:
+                    items.append(((tag, li, "si"), layer.self_attn.in_proj_weight))
+        return items
+
+    def chain_supported(self):
+        """Do the layer widths fit the row-chain kernel (ick_rowchain_supported)?  ICK_NO_ROWCHAIN=1 turns it off."""
+        cached = self.__dict__.get("_chain_ok")
+        if cached is None:
+            d = self.emb_dim
+            ff = max(l.linear1.out_features for st in (self.transformer_decoder, self.transformer_encoder_entities)
+                     for l in st.layers)
+            cached = (not os.environ.get("ICK_NO_ROWCHAIN")) and ops.rowchain_supported(ff, d, max(3 * d, ff))
+            self.__dict__["_chain_ok"] = cached
+        return cached
+
+    def _chain_pack(self, fresh=False):
+        """Packed copies (ops.pack_weights) of the weights the row-chain launches read, as {key: tensor} views of one
+        persistent buffer.  Refreshed when a parameter's version changed, or on every call with fresh=True (inside the
+        captured training step, where the fused Adam updates the weights behind torch's version counters)."""
+        items = self._chain_items()
+        cache = self.__dict__.get("_chain_cache")
+        key = tuple(w._version for _, w in items) + (items[0][1].data_ptr(), self.__dict__.get("_param_epoch", 0))
+        if cache is None or cache["ptr"] != items[0][1].data_ptr() or cache["buf"].device != items[0][1].device:
+            sizes = [ops.packed_weight_floats(w.shape[0], w.shape[1]) for _, w in items]
+            buf = torch.empty(sum(sizes), device=items[0][1].device, dtype=torch.float32)
+            views, off = {}, 0
+            for (k, _), n in zip(items, sizes):
+                views[k] = buf[off:off + n]
+                off += n
+            cache = {"ptr": items[0][1].data_ptr(), "buf": buf, "views": views, "key": None}
+            self.__dict__["_chain_cache"] = cache
+        if fresh or cache["key"] != key:
+            ops.pack_weights([(w.detach(), cache["views"][k]) for k, w in items])
+            cache["key"] = key
+        return cache["views"]
+
     def _pred_wt(self):
         w = self.fc_predicate.weight
         key = (w._version, w.data_ptr())
@@ -342,20 +399,49 @@ class DecoderTransformer(nn.Module):
             self.__dict__["_pred_wt_cache"] = cache
         return cache[1]
 
-    def _context_encoder(self, stack, x):
+    def _context_encoder(self, stack, x, tag="e", out=None):
+        """Post-LN encoder stack on x (B, T, d); `out` (optional (B, T, d) view, e.g. rows of the memory buffer)
+        receives the last layer's output."""
         H = self.num_heads
         d = self.emb_dim
         B, T, _ = x.shape
-        for layer in stack.layers:
-            qkv = ops.project_heads(x, layer.self_attn.in_proj_weight.detach(), layer.self_attn.in_proj_bias.detach(),
-                                    3, H, T)
+        chain = self.chain_supported()
+        pk = self._chain_pack() if chain else None
+        n = len(stack.layers)
+        qkv = None
+        for li, layer in enumerate(stack.layers):
+            if qkv is None:
+                qkv = ops.project_heads(x, layer.self_attn.in_proj_weight.detach(), layer.self_attn.in_proj_bias.detach(),
+                                        3, H, T)
             sa = torch.empty_like(x)
             ops.attention_heads(qkv, qkv, sa, H, d // H, T, T, q_seg=0, k_seg=1, v_seg=2)
+            qkv = None
+            last = li == n - 1
+            if chain:
+                x1 = torch.empty_like(x)
+                f = torch.empty(B, T, layer.linear1.out_features, device=x.device, dtype=torch.float32)
+                ops.rowchain_fwd(sa, pk[(tag, li, "so")], layer.self_attn.out_proj.bias.detach(), x,
+                                 layer.norm1.weight.detach(), layer.norm1.bias.detach(), layer.norm1.eps, x1,
+                                 w2p=pk[(tag, li, "l1")], b2=layer.linear1.bias.detach(), y2=f, relu=True)
+                x2 = out if (last and out is not None) else torch.empty_like(x)
+                nxt = None if last else stack.layers[li + 1]
+                if nxt is not None:
+                    qkv = torch.empty(B, 3, H, T, ops.DHP, device=x.device, dtype=torch.float32)
+                ops.rowchain_fwd(f, pk[(tag, li, "l2")], layer.linear2.bias.detach(), x1, layer.norm2.weight.detach(),
+                                 layer.norm2.bias.detach(), layer.norm2.eps, x2,
+                                 w2p=None if nxt is None else pk[(tag, li + 1, "si")],
+                                 b2=None if nxt is None else nxt.self_attn.in_proj_bias.detach(), y2=qkv,
+                                 heads=None if nxt is None else (3, H, T, 0, T))
+                x = x2
+                continue
             o = ops.linear(sa, layer.self_attn.out_proj.weight.detach(), layer.self_attn.out_proj.bias.detach())
             x = ops.add_layernorm(o, x, layer.norm1.weight.detach(), layer.norm1.bias.detach(), layer.norm1.eps)
             f = ops.linear(x, layer.linear1.weight.detach(), layer.linear1.bias.detach(), relu=True)
             o = ops.linear(f, layer.linear2.weight.detach(), layer.linear2.bias.detach())
             x = ops.add_layernorm(o, x, layer.norm2.weight.detach(), layer.norm2.bias.detach(), layer.norm2.eps)
+            if last and out is not None:
+                out.copy_(x)
+                x = out
         return x
 
     def _encode_context(self, enc_tok, entities, facts, gmap):
@@ -376,6 +462,8 @@ class DecoderTransformer(nn.Module):
             Fn = facts.shape[1]
             fe = ops.fact_encode(facts, ee, self.predicate_embedding.weight.detach())
         wkv, bkv = self._packed_cross_kv()
+        if self.chain_supported():
+            self._chain_pack()      # refreshed (if stale) on the main stream, before the side stream forks
         nseg = wkv.shape[0] // d
         S = P + K + Fn
         kv = torch.empty(B, nseg, H, S, ops.DHP, device=enc_tok.device, dtype=torch.float32)
@@ -390,7 +478,7 @@ class DecoderTransformer(nn.Module):
             ops.project_heads(ctx[0], wkv, bkv, nseg, H, S, out=kv, s0=P, grp=K)
 
         def fact_chain():
-            ctx[1] = self._context_encoder(self.transformer_encoder_facts, fe)
+            ctx[1] = self._context_encoder(self.transformer_encoder_facts, fe, tag="f")
             ops.project_heads(ctx[1], wkv, bkv, nseg, H, S, out=kv, s0=P + K, grp=Fn)
 
         # dependency point now, enqueued after the main stream's next kernel: in a captured graph the main chain
@@ -409,24 +497,54 @@ class DecoderTransformer(nn.Module):
         ctx_e, ctx_f = ctx
         return ee, fe, kv, (ctx_e, ctx_f), side
 
-    def _decoder_layer(self, li, layer, x, kv, S, qkv_buf=None, pos=None, side=None):
+    def _decoder_layer(self, li, layer, x, kv, S, qkv_buf=None, pos=None, side=None, qkv=None, want_next=False):
         """One post-LN decoder layer on x (B, T, d).  With qkv_buf (B, 3, H, max_len, 32) the layer runs
-        one KV-cached decode step: the new q|k|v row is written at position `pos` and attends to [0, pos]."""
+        one KV-cached decode step: the new q|k|v row is written at position `pos` and attends to [0, pos].
+        qkv: this layer's head-major q|k|v when the previous layer's last launch already projected it (row chains);
+        want_next: return (x, next layer's qkv) -- the in_proj of layer li + 1 rides on this layer's linear2 + norm3."""
         H, d = self.num_heads, self.emb_dim
         dh = d // H
         B, T, _ = x.shape
         sa_w, sa_b = layer.self_attn.in_proj_weight.detach(), layer.self_attn.in_proj_bias.detach()
         sa = torch.empty_like(x)
+        chain = qkv_buf is None and self.chain_supported()
         if qkv_buf is None:
-            qkv = ops.project_heads(x, sa_w, sa_b, 3, H, T)
+            if qkv is None:
+                qkv = ops.project_heads(x, sa_w, sa_b, 3, H, T)
             ops.attention_heads(qkv, qkv, sa, H, dh, T, T, q_seg=0, k_seg=1, v_seg=2, causal=True)
         else:
             ML = qkv_buf.shape[3]
             ops.project_heads(x, sa_w, sa_b, 3, H, ML, out=qkv_buf, s0=pos, grp=1)
             ops.attention_heads(qkv_buf, qkv_buf, sa, H, dh, 1, pos + 1, q_seg=0, k_seg=1, v_seg=2, q_t0=pos)
+        ca_w, ca_b = layer.multihead_attn.in_proj_weight.detach(), layer.multihead_attn.in_proj_bias.detach()
+        if chain:
+            pk = self._chain_pack()
+            x1 = torch.empty_like(x)
+            q = torch.empty(B, 1, H, T, ops.DHP, device=x.device, dtype=torch.float32)
+            ops.rowchain_fwd(sa, pk[("d", li, "so")], layer.self_attn.out_proj.bias.detach(), x, layer.norm1.weight.detach(),
+                             layer.norm1.bias.detach(), layer.norm1.eps, x1, w2p=pk[("d", li, "cq")], b2=ca_b[:d], y2=q,
+                             heads=(1, H, T, 0, T))
+            ca = torch.empty_like(x)
+            if side is not None:
+                side.join()    # entity / fact rows of kv come from the side stream
+            ops.attention_heads(q, kv, ca, H, dh, T, S, q_seg=0, k_seg=2 * li, v_seg=2 * li + 1)
+            x2 = torch.empty_like(x)
+            f = torch.empty(B, T, layer.linear1.out_features, device=x.device, dtype=torch.float32)
+            ops.rowchain_fwd(ca, pk[("d", li, "co")], layer.multihead_attn.out_proj.bias.detach(), x1,
+                             layer.norm2.weight.detach(), layer.norm2.bias.detach(), layer.norm2.eps, x2,
+                             w2p=pk[("d", li, "l1")], b2=layer.linear1.bias.detach(), y2=f, relu=True)
+            layers = self.transformer_decoder.layers
+            nxt = layers[li + 1] if (want_next and li + 1 < len(layers)) else None
+            x3 = torch.empty_like(x)
+            qkv_n = None if nxt is None else torch.empty(B, 3, H, T, ops.DHP, device=x.device, dtype=torch.float32)
+            ops.rowchain_fwd(f, pk[("d", li, "l2")], layer.linear2.bias.detach(), x2, layer.norm3.weight.detach(),
+                             layer.norm3.bias.detach(), layer.norm3.eps, x3,
+                             w2p=None if nxt is None else pk[("d", li + 1, "si")],
+                             b2=None if nxt is None else nxt.self_attn.in_proj_bias.detach(), y2=qkv_n,
+                             heads=None if nxt is None else (3, H, T, 0, T))
+            return (x3, qkv_n) if want_next else x3
         o = ops.linear(sa, layer.self_attn.out_proj.weight.detach(), layer.self_attn.out_proj.bias.detach())
         x = ops.add_layernorm(o, x, layer.norm1.weight.detach(), layer.norm1.bias.detach(), layer.norm1.eps)
-        ca_w, ca_b = layer.multihead_attn.in_proj_weight.detach(), layer.multihead_attn.in_proj_bias.detach()
         q = ops.project_heads(x, ca_w[:d], ca_b[:d], 1, H, T)
         ca = torch.empty_like(x)
         if side is not None:
@@ -436,7 +554,8 @@ class DecoderTransformer(nn.Module):
         x = ops.add_layernorm(o, x, layer.norm2.weight.detach(), layer.norm2.bias.detach(), layer.norm2.eps)
         f = ops.linear(x, layer.linear1.weight.detach(), layer.linear1.bias.detach(), relu=True)
         o = ops.linear(f, layer.linear2.weight.detach(), layer.linear2.bias.detach())
-        return ops.add_layernorm(o, x, layer.norm3.weight.detach(), layer.norm3.bias.detach(), layer.norm3.eps)
+        x = ops.add_layernorm(o, x, layer.norm3.weight.detach(), layer.norm3.bias.detach(), layer.norm3.eps)
+        return (x, None) if want_next else x
 
     def _score_head(self, h, ee, fe, eib, gate, out=None):
         """get_scores: vocabulary logits and pointer scores written into one (B, T, V+K[+F]) buffer."""
@@ -475,8 +594,9 @@ class DecoderTransformer(nn.Module):
         x, emb = ops.caption_embed(captions, caption_masks, self.word_embedding.weight.detach(), ee, fe, pe, V,
                                    self.word_map["<pad>"], math.sqrt(d), want_emb=True)
         S = kv.shape[3]
+        qkv = None
         for li, layer in enumerate(self.transformer_decoder.layers):
-            x = self._decoder_layer(li, layer, x, kv, S, side=side if li == 0 else None)
+            x, qkv = self._decoder_layer(li, layer, x, kv, S, side=side if li == 0 else None, qkv=qkv, want_next=True)
         side.join()
         eib = gate = None
         if self.has_facts:

@@ -35,6 +35,27 @@ class GemmArgs(C.Structure):
     ]
 
 
+class RowChainArgs(C.Structure):
+    _fields_ = [
+        ("A", vp), ("a_rs", i64), ("a_grp", i32), ("a_gs", i64),
+        ("M", i32), ("K1", i32), ("d", i32),
+        ("w1p", vp), ("b1", vp), ("res", vp), ("res_rs", i64),
+        ("gamma", vp), ("beta", vp), ("eps", f32),
+        ("drop1_p", f32), ("drop_seed", u32), ("drop1_site", u32), ("drop_epoch", vp),
+        ("o", vp), ("o_rs", i64),
+        ("x", vp), ("x_rs", i64), ("x_grp", i32), ("x_gs", i64),
+        ("mean", vp), ("rstd", vp),
+        ("w2p", vp), ("b2", vp), ("N2", i32), ("flags", i32),
+        ("drop2_p", f32), ("drop2_site", u32),
+        ("y2", vp), ("y2_rs", i64), ("y2_grp", i32), ("y2_gs", i64),
+        ("hs_dh", i32), ("hs_dhp", i32), ("hs_H", i32), ("hs_S", i32), ("hs_s0", i32),
+    ]
+
+
+class PackItem(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("N", i32), ("K", i32), ("src_ld", i64)]
+
+
 class GemmPlanInfo(C.Structure):
     _fields_ = [(n, i32) for n in ("tile_m", "tile_n", "waves", "tiles_m", "tiles_n", "split_k", "a_kmajor", "b_kmajor",
                                    "vec")]
@@ -93,6 +114,10 @@ SIGNATURES = {
     "ick_device_info": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int],
     "ick_gemm": [C.POINTER(GemmArgs), vp],
     "ick_gemm_plan": [C.POINTER(GemmArgs), C.POINTER(GemmPlanInfo)],
+    "ick_rowchain_supported": [i32, i32, i32],
+    "ick_rowchain_fwd": [C.POINTER(RowChainArgs), vp],
+    "ick_pack_weights": [C.POINTER(PackItem), i32, vp],
+    "ick_packed_weight_floats": [i32, i32, C.POINTER(i64)],
     "ick_add_layernorm": [vp, vp, vp, vp, vp, i64, i32, f32, i64, i64, i64, vp, vp, f32, u32, u32, vp, vp],
     "ick_attention": [C.POINTER(AttnArgs), vp],
     "ick_entity_encode": [i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp],

@@ -166,6 +166,90 @@ def add_layernorm(x, res, gamma, beta, eps=1e-5, out=None, save_stats=False, dro
     return (out, mean, rstd) if save_stats else out
 
 
+def rowchain_supported(K1, d, N2=0):
+    """Can ick_rowchain_fwd run a chain with these widths (GEMM 1 input, LayerNorm width, GEMM 2 output)?"""
+    return bool(L.load_raw().ick_rowchain_supported(int(K1), int(d), int(N2)))
+
+
+def packed_weight_floats(N, K):
+    n = L.i64()
+    L.check(L.load_raw().ick_packed_weight_floats(int(N), int(K), C.byref(n)), "ick_packed_weight_floats")
+    return int(n.value)
+
+
+def pack_weights(pairs):
+    """[(w (N, K) with contiguous columns, dst flat float buffer of packed_weight_floats(N, K))]: the packed copies
+    ick_rowchain_fwd reads (include/ick_amd.h), up to 48 matrices per launch."""
+    for i in range(0, len(pairs), 48):
+        chunk = pairs[i:i + 48]
+        items = (L.PackItem * len(chunk))()
+        for it, (src, dst) in zip(items, chunk):
+            assert src.dim() == 2 and src.stride(1) == 1 and dst.is_contiguous()
+            assert dst.numel() == packed_weight_floats(src.shape[0], src.shape[1])
+            it.src, it.dst, it.N, it.K, it.src_ld = _p(src), _p(dst), src.shape[0], src.shape[1], src.stride(0)
+        L.check(L.load().ick_pack_weights(items, len(chunk), _stream()), "ick_pack_weights")
+
+
+def pack_weight(w):
+    """Packed copy of one (N, K) weight (a new tensor)."""
+    dst = torch.empty(packed_weight_floats(w.shape[0], w.shape[1]), device=w.device, dtype=torch.float32)
+    pack_weights([(w, dst)])
+    return dst
+
+
+def rowchain_fwd(a, w1p, b1, res, gamma, beta, eps, x_out, drop1=None, o_out=None, save_stats=False,
+                 w2p=None, b2=None, y2=None, relu=False, drop2=None, heads=None):
+    """One launch for  o = a @ W1.T + b1;  x = LayerNorm(res + dropout1(o)) * gamma + beta;  y2 = act(x @ W2.T + b2)
+    (dropout2 on y2).  a (..., K1) rows with a uniform row stride; w1p / w2p are packed copies (pack_weights) of the
+    (d, K1) and (N2, d) nn.Linear weights; b2 gives N2; x_out (..., d) may be a (B, T, d) view with a sample stride
+    (rows inside the memory buffer); heads = (nseg, H, S, s0, grp): y2 is the head-major buffer (B, nseg, H, S, DHP)
+    of project_heads.  Returns (mean, rstd) when save_stats."""
+    K1, d = a.shape[-1], gamma.shape[0]
+    a2 = a.reshape(-1, K1)
+    if a2.stride(1) != 1:
+        a2 = a2.contiguous()
+    M = a2.shape[0]
+    r2 = res.reshape(-1, d)
+    g = L.RowChainArgs()
+    g.A, g.a_rs, g.a_grp, g.a_gs = _p(a2), a2.stride(0), 0, 0
+    g.M, g.K1, g.d = M, K1, d
+    g.w1p, g.b1 = _p(w1p), _p(b1)
+    g.res, g.res_rs = _p(r2), r2.stride(0)
+    g.gamma, g.beta, g.eps = _p(gamma), _p(beta), eps
+    g.drop1_p, g.drop_seed, g.drop1_site, g.drop_epoch = _dargs(drop1)
+    if o_out is not None:
+        g.o, g.o_rs = _p(o_out), o_out.reshape(-1, d).stride(0)
+    if x_out.dim() == 3 and not x_out.is_contiguous():
+        assert x_out.stride(2) == 1
+        g.x, g.x_rs, g.x_grp, g.x_gs = _p(x_out), x_out.stride(1), x_out.shape[1], x_out.stride(0)
+    else:
+        g.x, g.x_rs, g.x_grp, g.x_gs = _p(x_out), x_out.reshape(-1, d).stride(0), 0, 0
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(M, device=a.device, dtype=torch.float32)
+        rstd = torch.empty(M, device=a.device, dtype=torch.float32)
+        g.mean, g.rstd = _p(mean), _p(rstd)
+    if w2p is not None:
+        N2 = b2.shape[0]
+        g.w2p, g.b2, g.N2, g.flags = _p(w2p), _p(b2), N2, (1 if relu else 0)
+        p2, seed2, site2, ep2 = _dargs(drop2)
+        g.drop2_p, g.drop2_site = p2, site2
+        if p2 > 0.0:
+            if g.drop1_p > 0.0:
+                assert seed2 == g.drop_seed
+            else:
+                g.drop_seed, g.drop_epoch = seed2, ep2
+        g.y2 = _p(y2)
+        if heads is not None:
+            nseg, H, S, s0, grp = heads
+            g.y2_rs, g.y2_grp, g.y2_gs = 0, grp, y2.stride(0)
+            g.hs_dh, g.hs_dhp, g.hs_H, g.hs_S, g.hs_s0 = (N2 // nseg) // H, DHP, H, S, s0
+        else:
+            g.y2_rs, g.y2_grp, g.y2_gs = y2.reshape(-1, N2).stride(0), 0, 0
+    L.check(L.load().ick_rowchain_fwd(C.byref(g), _stream()), "ick_rowchain_fwd")
+    return (mean, rstd) if save_stats else None
+
+
 def attention_raw(Q, K, V, O, B, H, T, S, dh, q_bs, q_hs, q_ts, k_bs, k_hs, k_ss, v_bs, v_hs, v_ss, o_bs, o_ts,
                   causal=False, q_pos0=0, kv_len=None, lse=None, q_off=0, k_off=0, v_off=0, drop=None):
     """Strides in elements: batch / head / row for Q, K, V (see include/ick_amd.h); q_off/k_off/v_off are

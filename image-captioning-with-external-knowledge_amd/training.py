@@ -56,47 +56,110 @@ def _p(x):
 # ----------------------------------------------------------------------------------------------
 # forward with saved activations
 # ----------------------------------------------------------------------------------------------
-def _context_encoder_fwd(dec, stack, x, tape_list, ds):
+def _context_encoder_fwd(dec, stack, x, tape_list, ds, pk=None, tag="e", out=None):
+    """pk: packed weights (dec._chain_pack) -> the row-chain launches (out-projection + norm1 + linear1, linear2 + norm2
+    + the next layer's in_proj) replace the separate GEMM / add & norm kernels; `out`: (B, T, d) view that receives
+    the stack's output (its rows of the memory buffer)."""
     H, d = dec.num_heads, dec.emb_dim
     B, T, _ = x.shape
-    for layer in stack.layers:
+    n = len(stack.layers)
+    qkv = None
+    for li, layer in enumerate(stack.layers):
         p = layer.dropout.p
+        last = li == n - 1
         t = {"x": x, "d_att": ds.site(layer.self_attn.dropout), "d1": ds.site(layer.dropout1.p), "d_ff": ds.site(p),
              "d2": ds.site(layer.dropout2.p)}
-        t["qkv"] = ops.project_heads(x, _p(layer.self_attn.in_proj_weight), _p(layer.self_attn.in_proj_bias), 3, H, T)
+        t["qkv"] = qkv if qkv is not None else ops.project_heads(x, _p(layer.self_attn.in_proj_weight),
+                                                                 _p(layer.self_attn.in_proj_bias), 3, H, T)
+        qkv = None
         t["sa"] = torch.empty_like(x)
         t["lse"] = torch.empty(B * H * T, device=x.device, dtype=torch.float32)
         ops.attention_heads(t["qkv"], t["qkv"], t["sa"], H, d // H, T, T, 0, 1, 2, lse=t["lse"], drop=t["d_att"])
-        t["o1"] = ops.linear(t["sa"], _p(layer.self_attn.out_proj.weight), _p(layer.self_attn.out_proj.bias))
-        t["x1"], t["m1"], t["r1"] = ops.add_layernorm(t["o1"], x, _p(layer.norm1.weight), _p(layer.norm1.bias),
-                                                      layer.norm1.eps, save_stats=True, drop=t["d1"])
-        t["f"] = ops.linear(t["x1"], _p(layer.linear1.weight), _p(layer.linear1.bias), relu=True, drop=t["d_ff"])
-        t["o2"] = ops.linear(t["f"], _p(layer.linear2.weight), _p(layer.linear2.bias))
-        x, t["m2"], t["r2"] = ops.add_layernorm(t["o2"], t["x1"], _p(layer.norm2.weight), _p(layer.norm2.bias),
-                                                layer.norm2.eps, save_stats=True, drop=t["d2"])
+        x2 = out if (last and out is not None) else torch.empty_like(x)
+        if pk is not None:
+            t["o1"], t["x1"], t["o2"] = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+            t["f"] = torch.empty(B, T, layer.linear1.out_features, device=x.device, dtype=torch.float32)
+            t["m1"], t["r1"] = ops.rowchain_fwd(
+                t["sa"], pk[(tag, li, "so")], _p(layer.self_attn.out_proj.bias), x, _p(layer.norm1.weight),
+                _p(layer.norm1.bias), layer.norm1.eps, t["x1"], drop1=t["d1"], o_out=t["o1"], save_stats=True,
+                w2p=pk[(tag, li, "l1")], b2=_p(layer.linear1.bias), y2=t["f"], relu=True, drop2=t["d_ff"])
+            nxt = None if last else stack.layers[li + 1]
+            if nxt is not None:
+                qkv = torch.empty(B, 3, H, T, ops.DHP, device=x.device, dtype=torch.float32)
+            t["m2"], t["r2"] = ops.rowchain_fwd(
+                t["f"], pk[(tag, li, "l2")], _p(layer.linear2.bias), t["x1"], _p(layer.norm2.weight),
+                _p(layer.norm2.bias), layer.norm2.eps, x2, drop1=t["d2"], o_out=t["o2"], save_stats=True,
+                w2p=None if nxt is None else pk[(tag, li + 1, "si")],
+                b2=None if nxt is None else _p(nxt.self_attn.in_proj_bias), y2=qkv,
+                heads=None if nxt is None else (3, H, T, 0, T))
+        else:
+            t["o1"] = ops.linear(t["sa"], _p(layer.self_attn.out_proj.weight), _p(layer.self_attn.out_proj.bias))
+            t["x1"], t["m1"], t["r1"] = ops.add_layernorm(t["o1"], x, _p(layer.norm1.weight), _p(layer.norm1.bias),
+                                                          layer.norm1.eps, save_stats=True, drop=t["d1"])
+            t["f"] = ops.linear(t["x1"], _p(layer.linear1.weight), _p(layer.linear1.bias), relu=True, drop=t["d_ff"])
+            t["o2"] = ops.linear(t["f"], _p(layer.linear2.weight), _p(layer.linear2.bias))
+            y, t["m2"], t["r2"] = ops.add_layernorm(t["o2"], t["x1"], _p(layer.norm2.weight), _p(layer.norm2.bias),
+                                                    layer.norm2.eps, save_stats=True, drop=t["d2"])
+            if last and out is not None:
+                out.copy_(y)
+            else:
+                x2 = y
+        x = x2
         tape_list.append(t)
     return x
 
 
-def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds, side=None):
+def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds, side=None, pk=None, qkv=None):
+    """Returns (x, qkv of the next layer or None).  pk: packed weights -> row-chain launches (see above); then the
+    in_proj of layer li + 1 rides on this layer's linear2 + norm3 launch."""
     H, d = dec.num_heads, dec.emb_dim
     dh = d // H
     B, T, _ = x.shape
     t = {"x": x, "d_sa": ds.site(layer.self_attn.dropout), "d1": ds.site(layer.dropout1.p),
          "d_ca": ds.site(layer.multihead_attn.dropout), "d2": ds.site(layer.dropout2.p),
          "d_ff": ds.site(layer.dropout.p), "d3": ds.site(layer.dropout3.p)}
-    t["qkv"] = ops.project_heads(x, _p(layer.self_attn.in_proj_weight), _p(layer.self_attn.in_proj_bias), 3, H, T)
+    t["qkv"] = qkv if qkv is not None else ops.project_heads(x, _p(layer.self_attn.in_proj_weight),
+                                                             _p(layer.self_attn.in_proj_bias), 3, H, T)
     t["sa"] = torch.empty_like(x)
     t["lse_s"] = torch.empty(B * H * T, device=x.device, dtype=torch.float32)
     ops.attention_heads(t["qkv"], t["qkv"], t["sa"], H, dh, T, T, 0, 1, 2, causal=True, lse=t["lse_s"],
                         drop=t["d_sa"])
+    ca_w, ca_b = _p(layer.multihead_attn.in_proj_weight), _p(layer.multihead_attn.in_proj_bias)
+    t["ca"] = torch.empty_like(x)
+    t["lse_c"] = torch.empty(B * H * T, device=x.device, dtype=torch.float32)
+    if pk is not None:
+        for k in ("o1", "x1", "o2", "x2", "o3"):
+            t[k] = torch.empty_like(x)
+        t["qc"] = torch.empty(B, 1, H, T, ops.DHP, device=x.device, dtype=torch.float32)
+        t["m1"], t["r1"] = ops.rowchain_fwd(
+            t["sa"], pk[("d", li, "so")], _p(layer.self_attn.out_proj.bias), x, _p(layer.norm1.weight),
+            _p(layer.norm1.bias), layer.norm1.eps, t["x1"], drop1=t["d1"], o_out=t["o1"], save_stats=True,
+            w2p=pk[("d", li, "cq")], b2=ca_b[:d], y2=t["qc"], heads=(1, H, T, 0, T))
+        ops.stamp("fwd: layer %d reaches cross-attention" % li)
+        if side is not None:
+            side.join()    # the context rows of kv (and of the saved memory) come from the side stream
+        ops.attention_heads(t["qc"], kv, t["ca"], H, dh, T, S, 0, 2 * li, 2 * li + 1, lse=t["lse_c"], drop=t["d_ca"])
+        t["f"] = torch.empty(B, T, layer.linear1.out_features, device=x.device, dtype=torch.float32)
+        t["m2"], t["r2"] = ops.rowchain_fwd(
+            t["ca"], pk[("d", li, "co")], _p(layer.multihead_attn.out_proj.bias), t["x1"], _p(layer.norm2.weight),
+            _p(layer.norm2.bias), layer.norm2.eps, t["x2"], drop1=t["d2"], o_out=t["o2"], save_stats=True,
+            w2p=pk[("d", li, "l1")], b2=_p(layer.linear1.bias), y2=t["f"], relu=True, drop2=t["d_ff"])
+        layers = dec.transformer_decoder.layers
+        nxt = layers[li + 1] if li + 1 < len(layers) else None
+        x3 = torch.empty_like(x)
+        qkv_n = None if nxt is None else torch.empty(B, 3, H, T, ops.DHP, device=x.device, dtype=torch.float32)
+        t["m3"], t["r3"] = ops.rowchain_fwd(
+            t["f"], pk[("d", li, "l2")], _p(layer.linear2.bias), t["x2"], _p(layer.norm3.weight), _p(layer.norm3.bias),
+            layer.norm3.eps, x3, drop1=t["d3"], o_out=t["o3"], save_stats=True,
+            w2p=None if nxt is None else pk[("d", li + 1, "si")],
+            b2=None if nxt is None else _p(nxt.self_attn.in_proj_bias), y2=qkv_n,
+            heads=None if nxt is None else (3, H, T, 0, T))
+        tape_list.append(t)
+        return x3, qkv_n
     t["o1"] = ops.linear(t["sa"], _p(layer.self_attn.out_proj.weight), _p(layer.self_attn.out_proj.bias))
     t["x1"], t["m1"], t["r1"] = ops.add_layernorm(t["o1"], x, _p(layer.norm1.weight), _p(layer.norm1.bias),
                                                   layer.norm1.eps, save_stats=True, drop=t["d1"])
-    ca_w, ca_b = _p(layer.multihead_attn.in_proj_weight), _p(layer.multihead_attn.in_proj_bias)
     t["qc"] = ops.project_heads(t["x1"], ca_w[:d], ca_b[:d], 1, H, T)
-    t["ca"] = torch.empty_like(x)
-    t["lse_c"] = torch.empty(B * H * T, device=x.device, dtype=torch.float32)
     ops.stamp("fwd: layer %d reaches cross-attention" % li)
     if side is not None:
         side.join()    # the context rows of kv (and of the saved memory) come from the side stream
@@ -109,7 +172,7 @@ def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds, side=None):
     x, t["m3"], t["r3"] = ops.add_layernorm(t["o3"], t["x2"], _p(layer.norm3.weight), _p(layer.norm3.bias),
                                             layer.norm3.eps, save_stats=True, drop=t["d3"])
     tape_list.append(t)
-    return x
+    return x, None
 
 
 def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gmap, seed=0, epoch=None,
@@ -154,16 +217,20 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     if dec.has_facts:
         tape.enc_layers["facts"] = []
 
+    # packed weight copies of the row-chain launches: refreshed here, on the main stream, before the side stream forks
+    pk = dec._chain_pack(fresh=fresh_pack) if dec.chain_supported() else None
+
     def entity_chain():
         ops.stamp("side: context chain starts")
-        ctx_e = _context_encoder_fwd(dec, dec.transformer_encoder_entities, ee, tape.enc_layers["entities"], ds)
-        mem[:, P:P + K].copy_(ctx_e)
+        # the stack's last add & norm writes the entity rows of the memory buffer directly
+        ctx_e = _context_encoder_fwd(dec, dec.transformer_encoder_entities, ee, tape.enc_layers["entities"], ds, pk=pk,
+                                     tag="e", out=mem[:, P:P + K])
         ops.project_heads(ctx_e, wkv, bkv, nseg, H, S, out=kv, s0=P, grp=K)
         ops.stamp("side: context chain done")
 
     def fact_chain():
-        ctx_f = _context_encoder_fwd(dec, dec.transformer_encoder_facts, fe, tape.enc_layers["facts"], ds)
-        mem[:, P + K:].copy_(ctx_f)
+        ctx_f = _context_encoder_fwd(dec, dec.transformer_encoder_facts, fe, tape.enc_layers["facts"], ds, pk=pk,
+                                     tag="f", out=mem[:, P + K:])
         ops.project_heads(ctx_f, wkv, bkv, nseg, H, S, out=kv, s0=P + K, grp=Fn)
 
     side = ops.SideStream(priority=-1) if overlap else None
@@ -197,8 +264,10 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     m["d_pos"] = ds.site(dec.pos_encoder.dropout.p)
     x = ops.caption_embed(captions, caption_masks, _p(dec.word_embedding.weight), ee, fe, pe, V,
                           dec.word_map["<pad>"], math.sqrt(d), drop=m["d_pos"])
+    qkv = None
     for li, layer in enumerate(dec.transformer_decoder.layers):
-        x = _decoder_layer_fwd(dec, li, layer, x, kv, S, tape.dec_layers, ds, side=side if li == 0 else None)
+        x, qkv = _decoder_layer_fwd(dec, li, layer, x, kv, S, tape.dec_layers, ds, side=side if li == 0 else None,
+                                    pk=pk, qkv=qkv)
     if side is not None:
         side.join()
     ops.stamp("fwd: decoder layers done")
@@ -592,7 +661,7 @@ class TrainStep:
         decode_len = (lengths.reshape(-1) - 1).to(torch.int32)
         scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, gmap=gmap,
                                          seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
-                                         overlap=self.use_graph, **self._enc_kwargs(enc_in))
+                                         overlap=self.use_graph and not os.environ.get("ICK_NO_FWD_OVERLAP"), **self._enc_kwargs(enc_in))
         ops.stamp("fwd: scores done")
         # the two scalars of the loss go straight into the tail of the gradient bucket (it was zeroed above; nothing else
         # touches those two floats)
@@ -611,7 +680,7 @@ class TrainStep:
         decode_len = (lengths.reshape(-1) - 1).to(torch.int32)
         scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, gmap=gmap,
                                          seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
-                                         overlap=self.use_graph, **self._enc_kwargs(enc_in))
+                                         overlap=self.use_graph and not os.environ.get("ICK_NO_FWD_OVERLAP"), **self._enc_kwargs(enc_in))
         self._loss = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True,
                                    out_sum=self.flat_g[self.n:self.n + 1], out_count=self.flat_g[self.n + 1:])
         self._bp = BackwardPass(dec, tape, self._loss[2], self.grads,

@@ -105,6 +105,49 @@ int ick_add_layernorm(const float* x, const float* res, const float* gamma, cons
                       float drop_p, uint32_t drop_seed, uint32_t drop_site, /* dropout applied to x (dropout1/2/3) */
                       const uint32_t* drop_epoch, void* stream);
 
+/* Row-resident chain of a post-LN Transformer block, one launch instead of three (GEMM, add & norm, GEMM):
+ *     o  = A W1^T + b1                                        (M x d;   A is M x K1)
+ *     x  = LayerNorm(res + dropout1(o)) * gamma + beta         (M x d)
+ *     y2 = act(x W2^T + b2), dropout2                          (M x N2;  optional: w2p == NULL stops after x)
+ * i.e. what torch's TransformerDecoderLayer / TransformerEncoderLayer forward (post-LN) does between two attention
+ * cores for the layers built at geo-aware/models.py:241-244, knowledge-aware/models.py:319-330:
+ *   self_attn.out_proj -> dropout1 -> norm1 -> multihead_attn q-projection        (K1 = d,   N2 = d, head-split)
+ *   multihead_attn.out_proj -> dropout2 -> norm2 -> linear1 + ReLU + dropout      (K1 = d,   N2 = FF)
+ *   linear2 -> dropout3 -> norm3 -> the next layer's self_attn in_proj            (K1 = FF,  N2 = 3 d, head-split)
+ * Weights are passed as PACKED copies of the nn.Linear weights (w1p of the (d, K1) weight, w2p of the (N2, d) one),
+ * laid out for the kernel's operand loads and refreshed by ick_pack_weights after every optimizer step.
+ * Row r of A at A + (r / a_grp) * a_gs + (r % a_grp) * a_rs (a_grp <= 0: r * a_rs); x and y2 likewise; with
+ * hs_dh > 0 y2 is scattered head-major exactly like ick_gemm's head-split epilogue (y2_grp / y2_gs = c_grp / c_gs).
+ * o, mean, rstd are optional outputs for the backward pass.  Dropout masks are those of ick_add_layernorm (drop1,
+ * element index r * d + c) and of ick_gemm (drop2, r * N2 + c).  Limits: K1 <= 512, d <= 320, N2 <= 1024. */
+typedef struct {
+    const float* A; int64_t a_rs; int32_t a_grp; int64_t a_gs;
+    int32_t M, K1, d;
+    const float* w1p; const float* b1;
+    const float* res; int64_t res_rs;
+    const float* gamma; const float* beta; float eps;
+    float drop1_p; uint32_t drop_seed, drop1_site; const uint32_t* drop_epoch;
+    float* o; int64_t o_rs;
+    float* x; int64_t x_rs; int32_t x_grp; int64_t x_gs;
+    float* mean; float* rstd;
+    const float* w2p; const float* b2; int32_t N2; int32_t flags;   /* flags: ICK_GEMM_RELU */
+    float drop2_p; uint32_t drop2_site;
+    float* y2; int64_t y2_rs; int32_t y2_grp; int64_t y2_gs;
+    int32_t hs_dh, hs_dhp, hs_H, hs_S, hs_s0;
+} ick_rowchain_args;
+int ick_rowchain_supported(int32_t K1, int32_t d, int32_t N2);
+int ick_rowchain_fwd(const ick_rowchain_args* args, void* stream);
+
+/* Packed copy of a row-major (N, K) weight with row stride src_ld:
+ *   dst[((slab * (K16 / 4) + k4) * 64 + l) * 4 + kk] = W[64 * slab + l][4 * k4 + kk]   (0 for rows >= N, k >= K),
+ * K16 = K rounded up to 16, slabs = ceil(N / 64); dst holds *floats of ick_packed_weight_floats(N, K, &floats), 16-byte aligned.
+ * count <= 48 matrices per launch. */
+typedef struct {
+    const float* src; float* dst; int32_t N, K; int64_t src_ld;
+} ick_pack_item;
+int ick_packed_weight_floats(int32_t N, int32_t K, int64_t* floats);
+int ick_pack_weights(const ick_pack_item* items, int32_t count, void* stream);
+
 /* Multi-head attention core: O = softmax(Q K^T * scale [+ causal mask]) V per (batch, head).
  * Q element (b,t,h,j) at Q[b*q_bs + h*q_hs + t*q_ts + j]; K/V element (b,s,h,j) at
  * K[b*k_bs + h*k_hs + s*k_ss + j]; O element at O[b*o_bs + t*o_ts + h*dh + j] (row-major rows for the

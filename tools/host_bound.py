@@ -24,10 +24,13 @@ import os  # noqa: E402
 from ick_amd import ops  # noqa: E402
 if os.environ.get("ICK_TIMESTAMPS"):
     ops.stamps_enable()
-ts = TrainStep(dec, lr=4e-4, grad_clip=5.0, seed=0)
+IN_GRAPH = os.environ.get("ICK_SEPARATE_ENCODER") is None     # conv1 inside the captured step (bench.py's path)
+ts = TrainStep(dec, lr=4e-4, grad_clip=5.0, seed=0, encoder=enc if IN_GRAPH else None)
 
 
 def step():
+    if IN_GRAPH:
+        return ts(batch["captions"], feats, batch["caption_masks"], batch["caption_lengths"], batch["entities"])
     with torch.no_grad():
         e = enc(feats)
     return ts(batch["captions"], e, batch["caption_masks"], batch["caption_lengths"], batch["entities"])
