@@ -25,124 +25,27 @@
 //     and 16 k, so the kernel needs no edge handling).
 #include <cstdlib>
 
-#include "common.h"
+#include "rowchain.h"
+
+// Diagnostic build (-DICK_CHAIN_STAMPS, tools/debug/chain_stamps.py): thread 0 of workgroup 0 records the shader clock
+// at the phase boundaries of the kernel.  Compiled out of the product library.
+#ifdef ICK_CHAIN_STAMPS
+__device__ unsigned long long ick_chain_stamps[16];
+#define ICK_CSTAMP(i)                                                                                     \
+    do {                                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.x == 0) ick_chain_stamps[i] = __builtin_amdgcn_s_memtime();      \
+    } while (0)
+extern "C" int ick_debug_read_chain_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ick_chain_stamps), sizeof(ick_chain_stamps));
+}
+#else
+#define ICK_CSTAMP(i)
+#endif
 
 namespace ick {
 namespace {
 
-constexpr int kRows = 8;          // rows per workgroup
-constexpr int kWaves = 16;
-constexpr int kThreads = kWaves * 64;
-constexpr int kMaxK = 512;        // widest GEMM input (linear2: dim_feedforward)
-constexpr int kLdx = kMaxK + 16 + 4;
-constexpr int kMaxD = 320;        // LayerNorm width (5 columns per lane)
-constexpr int kMaxN2 = 1024;      // widest second GEMM (in_proj: 3 d)
-constexpr int kPartFloats = kRows * 64 * kWaves;   // every (slab, K split) pair is one wave: 8 rows x 64 columns each
-
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-
-struct GemmPlan {   // how the 16 waves cover N columns x K
-    int nslab, splits, kper;
-};
-__host__ __device__ inline GemmPlan plan_for(int N, int K) {
-    GemmPlan g;
-    g.nslab = (N + 63) / 64;
-    g.splits = kWaves / g.nslab;
-    if (g.splits < 1) g.splits = 1;
-    const int maxs = (K + 15) / 16;
-    if (g.splits > maxs) g.splits = maxs;
-    if (g.splits > 4) g.splits = 4;
-    g.kper = (((K + g.splits - 1) / g.splits) + 15) / 16 * 16;
-    return g;
-}
-
-#define ICK_MF(U)                                                                            \
-    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b[(U) >> 2][(U) & 3], acc0, 4, U, 0);        \
-    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b[(U) >> 2][(U) & 3], acc1, 4, U, 0);
-
-// acc[row] (lane = column of the wave's slab) = Xs[row][k range of the wave's split] . W[col][k] from the packed copy
-// Wp; Xs is zero beyond K.  Returns false for a wave without work (more waves than slabs x splits).
-struct Slab { int slab, h; };
-__device__ __forceinline__ Slab slab_of(const GemmPlan& g) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: K offsets stay in SGPRs
-    return Slab{wave % g.nslab, wave / g.nslab};
-}
-template <int DBG>
-__device__ __forceinline__ void row_gemm(const float* Xs, int K, const float* __restrict__ Wp, const GemmPlan g,
-                                         const Slab w, f32x4& acc0, f32x4& acc1) {
-    const int lane = threadIdx.x & 63;
-    acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int kb = w.h * g.kper;
-    const int ke = min(K, kb + g.kper);
-    if (w.h >= g.splits || kb >= ke) return;
-    const int K16 = (K + 15) & ~15;
-    const int slab_bytes = K16 * 64 * 4;                 // one slab of the packed copy
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(Wp) + (size_t)w.slab * K16 * 64, (short)0, slab_bytes, 0x00020000);
-    const int voff = lane * 16;
-    const int nchunk = (ke - kb + 15) >> 4;
-    const float* xa = Xs + (lane & 3) * kLdx + (lane >> 2);
-    f32x4 bq[3][4];
-    // Software pipeline, two chunks ahead, without branches around the loads (the compiler's s_waitcnt counting
-    // only stays exact in straight-line code): a chunk beyond this wave's K range is fetched from beyond the
-    // descriptor's extent (no memory access, zeros).
-    auto load = [&](f32x4 (&b)[4], int c) {
-        const int base = c < nchunk ? (kb + 16 * c) * 256 : slab_bytes;      // scalar; 16 k = 4 KiB
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (DBG == 1 || DBG == 3) b[j] = f32x4{(float)base, 1.f, 2.f, (float)j};
-            else b[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, base + j * 1024, 0));
-        }
-    };
-    auto mfma = [&](const f32x4 (&b)[4], int c) {
-        const int k0 = kb + 16 * c;
-        const float a0 = xa[k0], a1 = xa[4 * kLdx + k0];
-        if (DBG == 2 || DBG == 3) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { acc0 += b[j] * a0; acc1 += b[j] * a1; }
-            return;
-        }
-        ICK_MF(0) ICK_MF(1) ICK_MF(2) ICK_MF(3) ICK_MF(4) ICK_MF(5) ICK_MF(6) ICK_MF(7)
-        ICK_MF(8) ICK_MF(9) ICK_MF(10) ICK_MF(11) ICK_MF(12) ICK_MF(13) ICK_MF(14) ICK_MF(15)
-    };
-    // sched_barrier: the machine scheduler otherwise sinks the prefetches down to their uses (vmcnt(0) per chunk)
-#define ICK_STEP(LD, LC, MF, MC)              \
-    load(bq[LD], LC);                        \
-    __builtin_amdgcn_sched_barrier(0);       \
-    mfma(bq[MF], MC);                        \
-    __builtin_amdgcn_sched_barrier(0);
-    load(bq[0], 0);
-    load(bq[1], 1);
-    __builtin_amdgcn_sched_barrier(0);
-    int c = 0;
-    for (; c + 3 <= nchunk; c += 3) {
-        ICK_STEP(2, c + 2, 0, c)
-        ICK_STEP(0, c + 3, 1, c + 1)
-        ICK_STEP(1, c + 4, 2, c + 2)
-    }
-    if (c < nchunk) {          // one or two chunks left, already in flight
-        mfma(bq[0], c);
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < nchunk) mfma(bq[1], c + 1);
-    }
-#undef ICK_STEP
-}
-
-// Row offsets of the 8 rows of a workgroup under the (grp, gs, rs) addressing, without a division per row.
-struct RowOff {
-    int g, i, grp;
-    int64_t gs, rs;
-    __device__ __forceinline__ RowOff(int row0, int grp_, int64_t gs_, int64_t rs_) : grp(grp_), gs(gs_), rs(rs_) {
-        if (grp > 0) { g = row0 / grp; i = row0 - g * grp; } else { g = 0; i = row0; }
-    }
-    __device__ __forceinline__ int64_t next() {    // offset of the current row; advances to the following one
-        const int64_t o = (int64_t)g * gs + (int64_t)i * rs;
-        ++i;
-        if (grp > 0 && i >= grp) { i = 0; ++g; }
-        return o;
-    }
-};
+using namespace rowchain;
 
 template <int DBG>
 __global__ __launch_bounds__(kThreads) void rowchain_fwd_kernel(ick_rowchain_args p) {
@@ -155,6 +58,8 @@ __global__ __launch_bounds__(kThreads) void rowchain_fwd_kernel(ick_rowchain_arg
     // Thread mappings are chosen so that nothing below divides per element: at 16 waves a VALU instruction of
     // every thread costs 16 cycles of the CU, a 32-bit division ~40 of them.
 
+    ICK_CSTAMP(0);
+    const uint32_t seed = p.drop_epoch ? p.drop_seed + *p.drop_epoch : p.drop_seed;
     // ---- the residual row, gamma / beta / bias of the LayerNorm wave: issued first, consumed after GEMM 1
     const bool ln_wave = wave < kRows;
     const int lrow = row0 + wave;
@@ -169,22 +74,43 @@ __global__ __launch_bounds__(kThreads) void rowchain_fwd_kernel(ick_rowchain_arg
         rb[j] = ok ? p.beta[c] : 0.f;
         rbias[j] = ok && p.b1 ? p.b1[c] : 0.f;
     }
+    // ---- everything the second GEMM's epilogue needs besides the accumulators (bias, column offset): also up front
+    const int N2 = p.N2;
+    const GemmPlan g2 = plan_for(max(N2, 1), d);
+    const Slab w2 = slab_of(g2);
+    const int col2 = w2.slab * 64 + lane;
+    const bool hs = p.hs_dh > 0;
+    float bias2 = 0.f;
+    int64_t coff2 = col2;
+    if (p.w2p != nullptr && col2 < N2) {
+        if (p.b2) bias2 = p.b2[col2];
+        if (hs) {
+            const int hd = p.hs_H * p.hs_dh;
+            const int seg = small_div(col2, hd), rr = col2 - seg * hd;
+            const int hh = small_div(rr, p.hs_dh), jj = rr - hh * p.hs_dh;
+            coff2 = (int64_t)p.hs_s0 * p.hs_dhp + ((int64_t)seg * p.hs_H + hh) * ((int64_t)p.hs_S * p.hs_dhp) + jj;
+        }
+    }
+    ICK_CSTAMP(1);
     // ---- A rows -> LDS (zero beyond K1 up to the next multiple of 16, zero rows beyond M): wave = (row, half)
     const int K1 = p.K1, K1p = (K1 + 15) & ~15;
     {
         const int r = wave & (kRows - 1), half = wave >> 3;
         const int gr = row0 + r;
         int64_t off = (int64_t)gr * p.a_rs;
-        if (p.a_grp > 0) { const int g = gr / p.a_grp; off = (int64_t)g * p.a_gs + (int64_t)(gr - g * p.a_grp) * p.a_rs; }
+        if (p.a_grp > 0) { const int g = small_div(gr, p.a_grp); off = (int64_t)g * p.a_gs + (int64_t)(gr - g * p.a_grp) * p.a_rs; }
         const float* arow = p.A + off;
         for (int k = lane + 64 * half; k < K1p; k += 128) Xs[r * kLdx + k] = (gr < M && k < K1) ? arow[k] : 0.f;
     }
+    ICK_CSTAMP(2);
     __syncthreads();
+    ICK_CSTAMP(3);
     const GemmPlan g1 = plan_for(d, K1);
     {
         const Slab w = slab_of(g1);
         f32x4 acc0, acc1;
-        row_gemm<DBG>(Xs, K1, p.w1p, g1, w, acc0, acc1);
+        row_gemm<DBG>(Xs, kLdx, K1, p.w1p, g1, w, acc0, acc1);
+        ICK_CSTAMP(4);
         if (w.h < g1.splits) {
             float* q = Ps + (size_t)w.h * kRows * (g1.nslab * 64) + w.slab * 64 + lane;
 #pragma unroll
@@ -195,10 +121,11 @@ __global__ __launch_bounds__(kThreads) void rowchain_fwd_kernel(ick_rowchain_arg
         }
     }
     __syncthreads();
+    ICK_CSTAMP(5);
     // ---- o = sum of the K splits + bias; x = LayerNorm(res + dropout(o)); one wave per row
     const int dp = (d + 15) & ~15;
     if (ln_wave) {
-        const Dropout drop = make_dropout(p.drop1_p, p.drop_epoch ? p.drop_seed + *p.drop_epoch : p.drop_seed, p.drop1_site);
+        const Dropout drop = make_dropout(p.drop1_p, seed, p.drop1_site);
         const int npad = g1.nslab * 64;
         float v[5];
         float sum = 0.f;
@@ -230,7 +157,7 @@ __global__ __launch_bounds__(kThreads) void rowchain_fwd_kernel(ick_rowchain_arg
         float* xr = nullptr;
         if (lrow_ok) {
             int64_t off = (int64_t)lrow * p.x_rs;
-            if (p.x_grp > 0) { const int g = lrow / p.x_grp; off = (int64_t)g * p.x_gs + (int64_t)(lrow - g * p.x_grp) * p.x_rs; }
+            if (p.x_grp > 0) { const int g = small_div(lrow, p.x_grp); off = (int64_t)g * p.x_gs + (int64_t)(lrow - g * p.x_grp) * p.x_rs; }
             xr = p.x + off;
         }
 #pragma unroll
@@ -247,15 +174,16 @@ __global__ __launch_bounds__(kThreads) void rowchain_fwd_kernel(ick_rowchain_arg
             p.rstd[lrow] = rstd;
         }
     }
+    ICK_CSTAMP(6);
     if (p.w2p == nullptr) return;     // uniform
     __syncthreads();
+    ICK_CSTAMP(7);
     // ---- y2 = act(x W2^T + b2), dropout: the K split 0 wave of a slab adds the other splits' partials (LDS) to its
     // accumulators and stores its 64 columns of the 8 rows -- plain rows or the head-split scatter of ick_gemm
-    const int N2 = p.N2;
-    const GemmPlan g2 = plan_for(N2, d);
-    const Slab w = slab_of(g2);
+    const Slab w = w2;
     f32x4 acc0, acc1;
-    row_gemm<DBG>(Xs, d, p.w2p, g2, w, acc0, acc1);
+    row_gemm<DBG>(Xs, kLdx, d, p.w2p, g2, w, acc0, acc1);
+    ICK_CSTAMP(8);
     const int npad = g2.nslab * 64;
     if (g2.splits > 1) {
         if (w.h > 0 && w.h < g2.splits) {
@@ -268,39 +196,30 @@ __global__ __launch_bounds__(kThreads) void rowchain_fwd_kernel(ick_rowchain_arg
         }
         __syncthreads();
     }
-    if (w.h != 0) return;
-    const int col = w.slab * 64 + lane;
-    if (col >= N2) return;
+    ICK_CSTAMP(9);
+    if (w.h != 0 || col2 >= N2) return;
     float y[kRows];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { y[i] = acc0[i]; y[4 + i] = acc1[i]; }
     for (int h = 1; h < g2.splits; ++h) {
-        const float* q = Ps + (size_t)(h - 1) * kRows * npad + col;
+        const float* q = Ps + (size_t)(h - 1) * kRows * npad + col2;
 #pragma unroll
         for (int i = 0; i < kRows; ++i) y[i] += q[i * npad];
     }
-    const float bias = p.b2 ? p.b2[col] : 0.f;
-    const Dropout drop = make_dropout(p.drop2_p, p.drop_epoch ? p.drop_seed + *p.drop_epoch : p.drop_seed, p.drop2_site);
+    const Dropout drop = make_dropout(p.drop2_p, seed, p.drop2_site);
     const bool relu = p.flags & ICK_GEMM_RELU;
-    const bool hs = p.hs_dh > 0;
-    int64_t coff = col;
-    if (hs) {
-        const int hd = p.hs_H * p.hs_dh;
-        const int seg = col / hd, rr = col - seg * hd;
-        const int hh = rr / p.hs_dh, jj = rr - hh * p.hs_dh;
-        coff = (int64_t)p.hs_s0 * p.hs_dhp + ((int64_t)seg * p.hs_H + hh) * ((int64_t)p.hs_S * p.hs_dhp) + jj;
-    }
     RowOff ro(row0, p.y2_grp, p.y2_gs, hs ? (int64_t)p.hs_dhp : p.y2_rs);
 #pragma unroll
     for (int i = 0; i < kRows; ++i) {
         const int gr = row0 + i;
         const int64_t roff = ro.next();
         if (gr >= M) break;
-        float t = y[i] + bias;
+        float t = y[i] + bias2;
         if (relu) t = fmaxf(t, 0.f);
-        if (drop.on()) t *= drop.mask((uint32_t)gr * (uint32_t)N2 + (uint32_t)col);
-        p.y2[roff + coff] = t;
+        if (drop.on()) t *= drop.mask((uint32_t)gr * (uint32_t)N2 + (uint32_t)col2);
+        p.y2[roff + coff2] = t;
     }
+    ICK_CSTAMP(10);
 }
 
 // Packed weight copies: dst[slab][k4][l][kk] = W[64 slab + l][4 k4 + kk] (zero for rows >= N, k >= K), k4 < K16 / 4.
@@ -320,13 +239,21 @@ __global__ __launch_bounds__(512) void pack_weights_kernel(PackBatch pb) {
     const int K16 = (m.K + 15) & ~15;
     const int ktiles = (K16 + 31) / 32;
     const int slab = local / ktiles, kt = local - slab * ktiles;
-    {   // in: thread (row r = tid / 8, 8 threads x float4 along k)
+    if (m.src_cs == 1) {   // in: thread (row r = tid / 8, 8 threads x 4 floats along the contiguous k)
         const int r = threadIdx.x >> 3, q = threadIdx.x & 7;
         const int n = slab * 64 + r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k = kt * 32 + 4 * q + e;
-            tile[r][4 * q + e] = (n < m.N && k < m.K) ? m.src[(int64_t)n * m.src_ld + k] : 0.f;
+            tile[r][4 * q + e] = (n < m.N && k < m.K) ? m.src[(int64_t)n * m.src_rs + k] : 0.f;
+        }
+    } else {               // transposed source (rows contiguous): thread (row r = tid % 64, 8 groups x 4 k)
+        const int r = threadIdx.x & 63, q = threadIdx.x >> 6;
+        const int n = slab * 64 + r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = kt * 32 + 4 * q + e;
+            tile[r][4 * q + e] = (n < m.N && k < m.K) ? m.src[(int64_t)n * m.src_rs + (int64_t)k * m.src_cs] : 0.f;
         }
     }
     __syncthreads();
@@ -356,7 +283,7 @@ extern "C" int ick_pack_weights(const ick_pack_item* items, int32_t count, void*
     int total = 0;
     for (int i = 0; i < count; ++i) {
         const ick_pack_item& m = items[i];
-        if (!m.src || !m.dst || m.N <= 0 || m.K <= 0 || m.src_ld < m.K) return ICK_EINVAL;
+        if (!m.src || !m.dst || m.N <= 0 || m.K <= 0 || m.src_rs <= 0 || m.src_cs <= 0) return ICK_EINVAL;
         if (reinterpret_cast<uintptr_t>(m.dst) & 15) return ICK_EALIGN;
         pb.it[i] = m;
         total += ((m.N + 63) / 64) * ((((m.K + 15) & ~15) + 31) / 32);

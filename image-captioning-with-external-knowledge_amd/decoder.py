@@ -369,12 +369,22 @@ class DecoderTransformer(nn.Module):
             self.__dict__["_chain_ok"] = cached
         return cached
 
-    def _chain_pack(self, fresh=False):
+    def _chain_items_bwd(self):
+        """(key, transposed weight view) for the backward chains (ops.rowchain_bwd): the data gradient of a Linear
+        multiplies with W, i.e. the row-chain GEMM reads a packed copy of W.T."""
+        items = []
+        for key, w in self._chain_items():
+            items.append(((key[0], key[1], key[2] + "T"), w.t()))
+        return items
+
+    def _chain_pack(self, fresh=False, bwd=False):
         """Packed copies (ops.pack_weights) of the weights the row-chain launches read, as {key: tensor} views of one
-        persistent buffer.  Refreshed when a parameter's version changed, or on every call with fresh=True (inside the
-        captured training step, where the fused Adam updates the weights behind torch's version counters)."""
-        items = self._chain_items()
-        cache = self.__dict__.get("_chain_cache")
+        persistent buffer (bwd: of the transposed weights, for the data-gradient chains).  Refreshed when a parameter's
+        version changed, or on every call with fresh=True (inside the captured training step, where the fused Adam
+        updates the weights behind torch's version counters)."""
+        items = self._chain_items_bwd() if bwd else self._chain_items()
+        name = "_chain_cache_bwd" if bwd else "_chain_cache"
+        cache = self.__dict__.get(name)
         key = tuple(w._version for _, w in items) + (items[0][1].data_ptr(), self.__dict__.get("_param_epoch", 0))
         if cache is None or cache["ptr"] != items[0][1].data_ptr() or cache["buf"].device != items[0][1].device:
             sizes = [ops.packed_weight_floats(w.shape[0], w.shape[1]) for _, w in items]
@@ -384,11 +394,22 @@ class DecoderTransformer(nn.Module):
                 views[k] = buf[off:off + n]
                 off += n
             cache = {"ptr": items[0][1].data_ptr(), "buf": buf, "views": views, "key": None}
-            self.__dict__["_chain_cache"] = cache
+            self.__dict__[name] = cache
         if fresh or cache["key"] != key:
             ops.pack_weights([(w.detach(), cache["views"][k]) for k, w in items])
             cache["key"] = key
         return cache["views"]
+
+    def chain_bwd_supported(self):
+        cached = self.__dict__.get("_chain_bwd_ok")
+        if cached is None:
+            d = self.emb_dim
+            ff = max(l.linear1.out_features for st in (self.transformer_decoder, self.transformer_encoder_entities)
+                     for l in st.layers)
+            cached = self.chain_supported() and not os.environ.get("ICK_NO_ROWCHAIN_BWD") and \
+                ops.rowchain_bwd_supported(3 * d, d, ff)
+            self.__dict__["_chain_bwd_ok"] = cached
+        return cached
 
     def _pred_wt(self):
         w = self.fc_predicate.weight

@@ -52,8 +52,25 @@ class RowChainArgs(C.Structure):
     ]
 
 
+class RowChainBwdArgs(C.Structure):
+    _fields_ = [
+        ("M", i32), ("d", i32), ("drop_seed", u32), ("drop_epoch", vp),
+        ("g0", vp), ("g0_rs", i64), ("K0", i32), ("w0p", vp),
+        ("dzin", vp), ("dzin_rs", i64),
+        ("o1", vp), ("res1", vp), ("mean1", vp), ("rstd1", vp), ("gamma1", vp),
+        ("drop1_p", f32), ("drop1_site", u32),
+        ("do1", vp), ("part1", vp),
+        ("w1p", vp), ("N1", i32), ("act", vp), ("gate_scale", f32), ("t_out", vp),
+        ("w2p", vp),
+        ("o2", vp), ("res2", vp), ("mean2", vp), ("rstd2", vp), ("gamma2", vp),
+        ("drop2_p", f32), ("drop2_site", u32),
+        ("do2", vp), ("part2", vp),
+        ("w3p", vp), ("out3", vp), ("dz_out", vp),
+    ]
+
+
 class PackItem(C.Structure):
-    _fields_ = [("src", vp), ("dst", vp), ("N", i32), ("K", i32), ("src_ld", i64)]
+    _fields_ = [("src", vp), ("dst", vp), ("N", i32), ("K", i32), ("src_rs", i64), ("src_cs", i64)]
 
 
 class GemmPlanInfo(C.Structure):
@@ -116,6 +133,8 @@ SIGNATURES = {
     "ick_gemm_plan": [C.POINTER(GemmArgs), C.POINTER(GemmPlanInfo)],
     "ick_rowchain_supported": [i32, i32, i32],
     "ick_rowchain_fwd": [C.POINTER(RowChainArgs), vp],
+    "ick_rowchain_bwd_supported": [i32, i32, i32],
+    "ick_rowchain_bwd": [C.POINTER(RowChainBwdArgs), vp],
     "ick_pack_weights": [C.POINTER(PackItem), i32, vp],
     "ick_packed_weight_floats": [i32, i32, C.POINTER(i64)],
     "ick_add_layernorm": [vp, vp, vp, vp, vp, i64, i32, f32, i64, i64, i64, vp, vp, f32, u32, u32, vp, vp],

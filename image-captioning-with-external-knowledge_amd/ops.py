@@ -178,15 +178,17 @@ def packed_weight_floats(N, K):
 
 
 def pack_weights(pairs):
-    """[(w (N, K) with contiguous columns, dst flat float buffer of packed_weight_floats(N, K))]: the packed copies
-    ick_rowchain_fwd reads (include/ick_amd.h), up to 48 matrices per launch."""
+    """[(m (N, K) 2-D view with positive strides, dst flat float buffer of packed_weight_floats(N, K))]: the packed
+    copies the row-chain kernels read (include/ick_amd.h), up to 48 matrices per launch.  A transposed view (w.t())
+    gives the operand of the data-gradient chains."""
     for i in range(0, len(pairs), 48):
         chunk = pairs[i:i + 48]
         items = (L.PackItem * len(chunk))()
         for it, (src, dst) in zip(items, chunk):
-            assert src.dim() == 2 and src.stride(1) == 1 and dst.is_contiguous()
+            assert src.dim() == 2 and dst.is_contiguous()
             assert dst.numel() == packed_weight_floats(src.shape[0], src.shape[1])
-            it.src, it.dst, it.N, it.K, it.src_ld = _p(src), _p(dst), src.shape[0], src.shape[1], src.stride(0)
+            it.src, it.dst, it.N, it.K = _p(src), _p(dst), src.shape[0], src.shape[1]
+            it.src_rs, it.src_cs = src.stride(0), src.stride(1)
         L.check(L.load().ick_pack_weights(items, len(chunk), _stream()), "ick_pack_weights")
 
 
@@ -248,6 +250,55 @@ def rowchain_fwd(a, w1p, b1, res, gamma, beta, eps, x_out, drop1=None, o_out=Non
             g.y2_rs, g.y2_grp, g.y2_gs = y2.reshape(-1, N2).stride(0), 0, 0
     L.check(L.load().ick_rowchain_fwd(C.byref(g), _stream()), "ick_rowchain_fwd")
     return (mean, rstd) if save_stats else None
+
+
+def rowchain_bwd_supported(K0, d, N1=0):
+    return bool(L.load_raw().ick_rowchain_bwd_supported(int(K0), int(d), int(N1)))
+
+
+def ln_partials(rows, d, device):
+    """Buffer for the per-workgroup gamma / beta partial sums of a LayerNorm backward (8 rows per workgroup)."""
+    rpb = L.load_raw().ick_layernorm_bwd_rows_per_block()
+    return torch.empty((rows + rpb - 1) // rpb, 2 * d, device=device, dtype=torch.float32)
+
+
+def rowchain_bwd(M, d, norm1, w3p, out3, dz_out, g0=None, w0p=None, dzin=None, ffn=None, norm2=None):
+    """One launch for the data-gradient path between two attention-backward kernels (include/ick_amd.h,
+    ick_rowchain_bwd).  norm1 / norm2 = dict(o, res, mean, rstd, gamma, drop, do, part): saved forward tensors of an
+    add & norm, its dropout triple, and the outputs do (M, d) / part (ln_partials).  ffn = dict(w1p, w2p, act,
+    gate_scale, t_out) with packed linear2.weight.T / linear1.weight.T.  g0 (M, K0) @ W0 (packed W0.T = w0p) and dzin
+    (M, d) are the two addends of the incoming gradient."""
+    a = L.RowChainBwdArgs()
+    a.M, a.d = M, d
+    seeds = []
+
+    def norm(prefix, n):
+        setattr(a, "o" + prefix, _p(n["o"])); setattr(a, "res" + prefix, _p(n["res"]))
+        setattr(a, "mean" + prefix, _p(n["mean"])); setattr(a, "rstd" + prefix, _p(n["rstd"]))
+        setattr(a, "gamma" + prefix, _p(n["gamma"]))
+        pp, seed, site, ep = _dargs(n.get("drop"))
+        setattr(a, "drop%s_p" % prefix, pp); setattr(a, "drop%s_site" % prefix, site)
+        if pp > 0.0:
+            seeds.append((seed, ep))
+        setattr(a, "do" + prefix, _p(n["do"])); setattr(a, "part" + prefix, _p(n["part"]))
+
+    norm("1", norm1)
+    if g0 is not None:
+        g2 = g0.reshape(M, -1)
+        assert g2.stride(1) == 1
+        a.g0, a.g0_rs, a.K0, a.w0p = _p(g2), g2.stride(0), g2.shape[1], _p(w0p)
+    if dzin is not None:
+        z2 = dzin.reshape(M, d)
+        a.dzin, a.dzin_rs = _p(z2), z2.stride(0)
+    if ffn is not None:
+        a.w1p, a.N1, a.act, a.gate_scale = _p(ffn["w1p"]), ffn["act"].shape[-1], _p(ffn["act"]), float(ffn["gate_scale"])
+        a.t_out, a.w2p = _p(ffn["t_out"]), _p(ffn["w2p"])
+        norm("2", norm2)
+    if seeds:
+        assert all(s == seeds[0] for s in seeds)
+        a.drop_seed, a.drop_epoch = seeds[0]
+    a.w3p, a.out3, a.dz_out = _p(w3p), _p(out3), _p(dz_out)
+    L.check(L.load().ick_rowchain_bwd(C.byref(a), _stream()), "ick_rowchain_bwd")
 
 
 def attention_raw(Q, K, V, O, B, H, T, S, dh, q_bs, q_hs, q_ts, k_bs, k_hs, k_ss, v_bs, v_hs, v_ss, o_bs, o_ts,
@@ -508,24 +559,28 @@ def layernorm_bwd(dy, x, res, gamma, mean, rstd, dgamma, dbeta, drop=None):
     L.check(L.load().ick_layernorm_bwd(_p(dy), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), _p(dz), None, None,
                                        rows, d, _p(dxd), *_dargs(drop), _p(part), _stream()), "ick_layernorm_bwd")
 
-    def reduce_partials():
-        if dbeta.data_ptr() == dgamma.data_ptr() + 4 * d:     # adjacent in a flat gradient bucket: one launch
-            colsum(part, dgamma, n_out=2 * d)
-        else:
-            colsum(part[:, :d], dgamma)
-            colsum(part[:, d:], dbeta)
-
     if SIDE is not None:
         SIDE.flush()     # side work marked earlier goes out now that the main chain has its next kernel
-        # the partial sums are reduced inside the layer's grouped weight-gradient launch (no kernel of their own)
-        if dbeta.data_ptr() == dgamma.data_ptr() + 4 * d:
+    ln_partials_reduce(part, dgamma, dbeta)
+    return dz, dxd
+
+
+def ln_partials_reduce(part, dgamma, dbeta):
+    """dgamma / dbeta += column sums of the per-workgroup partials (rows x 2d) of a LayerNorm backward: inside the layer's
+    grouped weight-gradient launch when a SideStream is installed (no kernel of their own), else two column sums."""
+    d = part.shape[1] // 2
+    adjacent = dbeta.data_ptr() == dgamma.data_ptr() + 4 * d      # adjacent in a flat gradient bucket: one problem
+    if SIDE is not None:
+        if adjacent:
             SIDE.add_problem(colsum_problem(part, dgamma), part)
         else:
             SIDE.add_problem(colsum_problem(part[:, :d], dgamma), part)
             SIDE.add_problem(colsum_problem(part[:, d:], dbeta), part)
+    elif adjacent:
+        colsum(part, dgamma, n_out=2 * d)
     else:
-        reduce_partials()
-    return dz, dxd
+        colsum(part[:, :d], dgamma)
+        colsum(part[:, d:], dbeta)
 
 
 def relu_bwd(dy, act, out=None, scale=1.0):

@@ -251,6 +251,10 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         mem[:, :P].copy_(img)
     if side is not None:
         side.flush()     # enqueued after the main stream's next kernel (see SideStream)
+    if pk is not None and dec.chain_bwd_supported():
+        # packed transposed weights of the backward chains: needed a millisecond from now, refreshed here where the
+        # main stream has slack (it waits for the context chain before the first cross-attention)
+        m["pkb"] = dec._chain_pack(fresh=fresh_pack, bwd=True)
     if dec.has_facts:
         # on the main stream, beside the entity chain on the side stream: two chains of small kernels overlap well
         # (a chain beside the large projection below does not)
@@ -316,9 +320,57 @@ def _lin_bwd(grads, dy2, x2, lin_w, lin_b, w_rows=None, need_dx=True, dx=None, a
                           gate=gate, gate_scale=gate_scale)
 
 
-def _context_encoder_bwd(dec, stack, tapes, dx, grads):
+def _norm_args(t, i, res, layer_norm, grads, M, d, dev):
+    """The saved forward tensors of add & norm number i of a layer + fresh outputs, as ops.rowchain_bwd wants them."""
+    return dict(o=t["o%d" % i], res=res, mean=t["m%d" % i], rstd=t["r%d" % i], gamma=_p(layer_norm.weight),
+                drop=t["d%d" % i], do=torch.empty(M, d, device=dev, dtype=torch.float32),
+                part=ops.ln_partials(M, d, dev))
+
+
+def _context_encoder_bwd(dec, stack, tapes, dx, grads, pkb=None, tag="e"):
+    """pkb: packed transposed weights (dec._chain_pack(bwd=True)) -> one ops.rowchain_bwd launch per layer for
+    [in_proj data gradient of the layer above] + norm2' + linear2' + ReLU' + linear1' + norm1' + out_proj' instead
+    of six kernels."""
     H, d = dec.num_heads, dec.emb_dim
-    for layer, t in zip(reversed(list(stack.layers)), reversed(tapes)):
+    layers = list(stack.layers)
+    if pkb is not None:
+        dev = dx.device
+        dz, g0, w0p = dx, None, None
+        for li in reversed(range(len(layers))):
+            layer, t = layers[li], tapes[li]
+            B, T, _ = t["x"].shape
+            M = B * T
+            n2 = _norm_args(t, 2, t["x1"], layer.norm2, grads, M, d, dev)
+            n1 = _norm_args(t, 1, t["x"], layer.norm1, grads, M, d, dev)
+            dpre = torch.empty(M, layer.linear1.out_features, device=dev, dtype=torch.float32)
+            dsa = torch.empty(M, d, device=dev, dtype=torch.float32)
+            dz_out = torch.empty(M, d, device=dev, dtype=torch.float32)
+            ops.rowchain_bwd(M, d, n2, pkb[(tag, li, "soT")], dsa, dz_out, g0=g0, w0p=w0p, dzin=dz,
+                             ffn=dict(w1p=pkb[(tag, li, "l2T")], w2p=pkb[(tag, li, "l1T")], act=t["f"],
+                                      gate_scale=_keep_scale(t["d_ff"]), t_out=dpre), norm2=n1)
+            if ops.SIDE is not None:
+                ops.SIDE.flush()
+            ops.ln_partials_reduce(n2["part"], _g(grads, layer.norm2.weight), _g(grads, layer.norm2.bias))
+            ops.ln_partials_reduce(n1["part"], _g(grads, layer.norm1.weight), _g(grads, layer.norm1.bias))
+            _lin_bwd(grads, n2["do"], t["f"].view(M, -1), layer.linear2.weight, layer.linear2.bias, need_dx=False)
+            _lin_bwd(grads, dpre, t["x1"].view(M, d), layer.linear1.weight, layer.linear1.bias, need_dx=False)
+            _lin_bwd(grads, n1["do"], t["sa"].view(M, d), layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias,
+                     need_dx=False)
+            dqkv = ops.attention_bwd_buffer((B, T, 3 * d), T, T, d // H, dev)
+            ops.attention_heads_bwd(t["qkv"], t["qkv"], t["sa"], dsa.view(B, T, d), t["lse"], dqkv[:, :, :d],
+                                    dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:], H, d // H, T, T, 0, 1, 2, drop=t["d_att"])
+            if li > 0:
+                # the in_proj data gradient rides on the next launch (the layer below); only its weight gradient here
+                _lin_bwd(grads, dqkv.view(M, 3 * d), t["x"].view(M, d), layer.self_attn.in_proj_weight,
+                         layer.self_attn.in_proj_bias, need_dx=False)
+                dz, g0, w0p = dz_out, dqkv.view(M, 3 * d), pkb[(tag, li, "siT")]
+            else:
+                dx = _lin_bwd(grads, dqkv.view(M, 3 * d), t["x"].view(M, d), layer.self_attn.in_proj_weight,
+                              layer.self_attn.in_proj_bias, dx=dz_out, acc=True).view(B, T, d)
+            if ops.SIDE is not None:
+                ops.SIDE.flush_group()      # this layer's weight gradients: one grouped launch
+        return dx
+    for layer, t in zip(reversed(layers), reversed(tapes)):
         B, T, _ = t["x"].shape
         M = B * T
         dz, do2 = ops.layernorm_bwd(dx, t["o2"], t["x1"], _p(layer.norm2.weight), t["m2"], t["r2"],
@@ -339,6 +391,67 @@ def _context_encoder_bwd(dec, stack, tapes, dx, grads):
         if ops.SIDE is not None:
             ops.SIDE.flush_group()      # this layer's weight gradients: one grouped launch
     return dx
+
+
+def _decoder_layer_bwd_chain(dec, li, layer, t, state, dkv_rows, kv, S, grads, pkb, mem2=None):
+    """Backward of decoder layer li as two ops.rowchain_bwd launches around the cross-attention backward + the
+    self-attention backward.  state = (dz, g0, w0p): the residual-path gradient of this layer's output, and -- from the
+    layer above -- the in_proj gradient whose data gradient rides on this layer's first launch.  Returns the state
+    for the layer below."""
+    H, d = dec.num_heads, dec.emb_dim
+    dh = d // H
+    B, T, _ = t["x"].shape
+    M = B * T
+    dev = t["x"].device
+    dz, g0, w0p = state
+    n3 = _norm_args(t, 3, t["x2"], layer.norm3, grads, M, d, dev)
+    n2 = _norm_args(t, 2, t["x1"], layer.norm2, grads, M, d, dev)
+    dpre = torch.empty(M, layer.linear1.out_features, device=dev, dtype=torch.float32)
+    dca = torch.empty(M, d, device=dev, dtype=torch.float32)
+    dz_a = torch.empty(M, d, device=dev, dtype=torch.float32)
+    ops.rowchain_bwd(M, d, n3, pkb[("d", li, "coT")], dca, dz_a, g0=g0, w0p=w0p, dzin=dz,
+                     ffn=dict(w1p=pkb[("d", li, "l2T")], w2p=pkb[("d", li, "l1T")], act=t["f"],
+                              gate_scale=_keep_scale(t["d_ff"]), t_out=dpre), norm2=n2)
+    if ops.SIDE is not None:
+        ops.SIDE.flush()
+    ops.ln_partials_reduce(n3["part"], _g(grads, layer.norm3.weight), _g(grads, layer.norm3.bias))
+    ops.ln_partials_reduce(n2["part"], _g(grads, layer.norm2.weight), _g(grads, layer.norm2.bias))
+    _lin_bwd(grads, n3["do"], t["f"].view(M, -1), layer.linear2.weight, layer.linear2.bias, need_dx=False)
+    _lin_bwd(grads, dpre, t["x2"].view(M, d), layer.linear1.weight, layer.linear1.bias, need_dx=False)
+    _lin_bwd(grads, n2["do"], t["ca"].view(M, d), layer.multihead_attn.out_proj.weight,
+             layer.multihead_attn.out_proj.bias, need_dx=False)
+    dq = torch.empty(B, T, d, device=dev, dtype=torch.float32)
+    c0 = 2 * li * d
+    ops.attention_heads_bwd(t["qc"], kv, t["ca"], dca.view(B, T, d), t["lse_c"], dq, dkv_rows[:, :, c0:c0 + d],
+                            dkv_rows[:, :, c0 + d:c0 + 2 * d], H, dh, T, S, 0, 2 * li, 2 * li + 1, drop=t["d_ca"])
+    if mem2 is not None:
+        _kv_proj_param_grads(layer, li, dkv_rows, mem2, grads, d)
+    n1 = _norm_args(t, 1, t["x"], layer.norm1, grads, M, d, dev)
+    dsa = torch.empty(M, d, device=dev, dtype=torch.float32)
+    dz_b = torch.empty(M, d, device=dev, dtype=torch.float32)
+    ops.rowchain_bwd(M, d, n1, pkb[("d", li, "soT")], dsa, dz_b, g0=dq.view(M, d), w0p=pkb[("d", li, "cqT")], dzin=dz_a)
+    if ops.SIDE is not None:
+        ops.SIDE.flush()
+    ops.ln_partials_reduce(n1["part"], _g(grads, layer.norm1.weight), _g(grads, layer.norm1.bias))
+    _lin_bwd(grads, dq.view(M, d), t["x1"].view(M, d), layer.multihead_attn.in_proj_weight,
+             layer.multihead_attn.in_proj_bias, w_rows=slice(0, d), need_dx=False)
+    _lin_bwd(grads, n1["do"], t["sa"].view(M, d), layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias,
+             need_dx=False)
+    dqkv = ops.attention_bwd_buffer((B, T, 3 * d), T, T, dh, dev)
+    ops.attention_heads_bwd(t["qkv"], t["qkv"], t["sa"], dsa.view(B, T, d), t["lse_s"], dqkv[:, :, :d],
+                            dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:], H, dh, T, T, 0, 1, 2, causal=True,
+                            drop=t["d_sa"])
+    if li > 0:
+        _lin_bwd(grads, dqkv.view(M, 3 * d), t["x"].view(M, d), layer.self_attn.in_proj_weight,
+                 layer.self_attn.in_proj_bias, need_dx=False)
+        out = (dz_b, dqkv.view(M, 3 * d), pkb[("d", li, "siT")])
+    else:
+        dx0 = _lin_bwd(grads, dqkv.view(M, 3 * d), t["x"].view(M, d), layer.self_attn.in_proj_weight,
+                       layer.self_attn.in_proj_bias, dx=dz_b, acc=True).view(B, T, d)
+        out = (dx0, None, None)
+    if ops.SIDE is not None:
+        ops.SIDE.flush_group()          # this layer's weight gradients: one grouped launch
+    return out
 
 
 def _decoder_layer_bwd(dec, li, layer, t, dx, dkv_rows, kv, S, grads, mem2=None):
@@ -504,10 +617,19 @@ def _backward_phases(dec, tape, dscores, grads, want_image_grad=False):
     dkv_rows = ops.attention_bwd_buffer((B, S, nseg * d), L, S, d // H, dev)
     dx = dh
     ops.stamp("bwd: head done")
-    for li in reversed(range(len(layers))):
-        dx = _decoder_layer_bwd(dec, li, layers[li], tape.dec_layers[li], dx, dkv_rows, m["kv"], S, grads,
-                                mem2=m["mem"].view(B * S, d))
-        ops.stamp("bwd: decoder layer %d done" % li)
+    pkb = m.get("pkb")
+    if pkb is not None:
+        state = (dh.view(M, d), None, None)
+        for li in reversed(range(len(layers))):
+            state = _decoder_layer_bwd_chain(dec, li, layers[li], tape.dec_layers[li], state, dkv_rows, m["kv"], S,
+                                             grads, pkb, mem2=m["mem"].view(B * S, d))
+            ops.stamp("bwd: decoder layer %d done" % li)
+        dx = state[0]
+    else:
+        for li in reversed(range(len(layers))):
+            dx = _decoder_layer_bwd(dec, li, layers[li], tape.dec_layers[li], dx, dkv_rows, m["kv"], S, grads,
+                                    mem2=m["mem"].view(B * S, d))
+            ops.stamp("bwd: decoder layer %d done" % li)
     yield    # ---- end of the early phase: every gradient of early_parameters() has been enqueued
     # ---- cross K/V projection: the weight gradients went out with the decoder layers; data gradient for the
     # context rows only (the image rows' gradient would be Encoder.conv1's, which the reference never uses)
@@ -525,12 +647,12 @@ def _backward_phases(dec, tape, dscores, grads, want_image_grad=False):
     # ---- context encoders
     ops.stamp("bwd: context gradient ready")
     dee_enc = _context_encoder_bwd(dec, dec.transformer_encoder_entities, tape.enc_layers["entities"],
-                                   dctx[:, :K].contiguous(), grads)
+                                   dctx[:, :K].contiguous(), grads, pkb=pkb, tag="e")
     ops.stamp("bwd: entity context encoder done")
     dee += dee_enc
     if dec.has_facts:
         dfe_enc = _context_encoder_bwd(dec, dec.transformer_encoder_facts, tape.enc_layers["facts"],
-                                       dctx[:, K:].contiguous(), grads)
+                                       dctx[:, K:].contiguous(), grads, pkb=pkb, tag="f")
         dfe += dfe_enc
     # ---- caption embedding, fact encoder, entity encoder
     gword = _g(grads, dec.word_embedding.weight)

@@ -25,10 +25,20 @@ def save_checkpoint(data_name, epoch, epochs_since_improvement, encoder, decoder
         # device-side caches and pinned staging buffers are not part of a checkpoint
         for k in ("_graphs", "_kv_pack", "_pred_wt_cache", "_len_pin", "_idx_pin", "_plist", "_pin_ev", "_dec_pack"):
             decoder.__dict__.pop(k, None)
+    # the packed weight copies of the row-chain kernels stay alive (captured training graphs write into them by
+    # address) but are not pickled either
+    stash = {}
+    if hasattr(decoder, "__dict__"):
+        stash = {k: decoder.__dict__.pop(k) for k in ("_chain_cache", "_chain_cache_bwd", "_chain_ok", "_chain_bwd_ok")
+                 if k in decoder.__dict__}
     name = checkpoint_name(data_name, epoch)
-    torch.save(state, os.path.join(out_dir, name))
-    if is_best:
-        torch.save(state, os.path.join(out_dir, "BEST_" + name))
+    try:
+        torch.save(state, os.path.join(out_dir, name))
+        if is_best:
+            torch.save(state, os.path.join(out_dir, "BEST_" + name))
+    finally:
+        if stash:
+            decoder.__dict__.update(stash)
     return os.path.join(out_dir, name)
 
 

@@ -138,12 +138,49 @@ typedef struct {
 int ick_rowchain_supported(int32_t K1, int32_t d, int32_t N2);
 int ick_rowchain_fwd(const ick_rowchain_args* args, void* stream);
 
-/* Packed copy of a row-major (N, K) weight with row stride src_ld:
- *   dst[((slab * (K16 / 4) + k4) * 64 + l) * 4 + kk] = W[64 * slab + l][4 * k4 + kk]   (0 for rows >= N, k >= K),
- * K16 = K rounded up to 16, slabs = ceil(N / 64); dst holds *floats of ick_packed_weight_floats(N, K, &floats), 16-byte aligned.
- * count <= 48 matrices per launch. */
+/* Backward of the row-resident chains, one launch for the data-gradient path between two attention-backward
+ * kernels (what `loss.backward()`, geo-aware/train.py:284, runs for a post-LN Transformer block):
+ *     dx        = dzin + g0 W0                  (g0: M x K0 gradient of the Linear that consumed the block's output,
+ *                                                W0 its (K0, d) weight; either addend may be absent)
+ *     dz1, do1  = LayerNorm'(dx)                 (ick_layernorm_bwd semantics: dz1 = gradient of the normalised sum and of
+ *                                                the residual operand, do1 = dz1 * dropout mask = gradient of o1)
+ *     t         = do1 W2, zeroed / scaled by the ReLU + dropout gate (ick_gemm's gate)     } FFN blocks only
+ *     dx2       = dz1 + t W1                                                                } (w1p != NULL):
+ *     dz2, do2  = LayerNorm'(dx2)                                                           } linear2, linear1, norm
+ *     out3      = do W3                          (do = do2 for FFN blocks, do1 otherwise; W3 = the out-projection)
+ *     dz_out    = dz2 (FFN blocks) or dz1
+ * Weights are packed copies (ick_pack_weights) of the TRANSPOSED nn.Linear weights: w0p of W0^T (d x K0), w1p of
+ * linear2.weight^T (N1 x d), w2p of linear1.weight^T (d x N1), w3p of out_proj.weight^T (d x d).
+ * o / res / mean / rstd / gamma are the saved forward tensors of the norms (as for ick_layernorm_bwd); part1 / part2
+ * receive the per-workgroup gamma / beta partial sums, ceil(M / 8) x 2d floats each (ick_layernorm_bwd's layout, 8 rows
+ * per workgroup).  All row-major with dense rows (d, N1) except g0 / dzin (g0_rs, dzin_rs).
+ * Limits: K0 <= 960, d <= 320, N1 <= 512. */
 typedef struct {
-    const float* src; float* dst; int32_t N, K; int64_t src_ld;
+    int32_t M, d;
+    uint32_t drop_seed; const uint32_t* drop_epoch;
+    const float* g0; int64_t g0_rs; int32_t K0; const float* w0p;
+    const float* dzin; int64_t dzin_rs;
+    const float* o1; const float* res1; const float* mean1; const float* rstd1; const float* gamma1;
+    float drop1_p; uint32_t drop1_site;
+    float* do1; float* part1;
+    const float* w1p; int32_t N1; const float* act; float gate_scale; float* t_out;
+    const float* w2p;
+    const float* o2; const float* res2; const float* mean2; const float* rstd2; const float* gamma2;
+    float drop2_p; uint32_t drop2_site;
+    float* do2; float* part2;
+    const float* w3p; float* out3;
+    float* dz_out;
+} ick_rowchain_bwd_args;
+int ick_rowchain_bwd_supported(int32_t K0, int32_t d, int32_t N1);
+int ick_rowchain_bwd(const ick_rowchain_bwd_args* args, void* stream);
+
+/* Packed copy of an (N, K) matrix whose element (n, k) is src[n * src_rs + k * src_cs] (a weight: src_cs = 1; its
+ * transpose, for the data-gradient chains: src_rs = 1, src_cs = the weight's row stride):
+ *   dst[((slab * (K16 / 4) + k4) * 64 + l) * 4 + kk] = M[64 * slab + l][4 * k4 + kk]   (0 for rows >= N, k >= K),
+ * K16 = K rounded up to 16, slabs = ceil(N / 64); dst holds *floats of ick_packed_weight_floats(N, K, &floats)
+ * floats, 16-byte aligned.  count <= 48 matrices per launch. */
+typedef struct {
+    const float* src; float* dst; int32_t N, K; int64_t src_rs, src_cs;
 } ick_pack_item;
 int ick_packed_weight_floats(int32_t N, int32_t K, int64_t* floats);
 int ick_pack_weights(const ick_pack_item* items, int32_t count, void* stream);

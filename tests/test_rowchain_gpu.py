@@ -102,3 +102,64 @@ def test_chain_dropout_masks_and_head_split_equal_the_unfused_kernels():
     f_u = ops.linear(x_u, t["w2"], t["b2"], relu=True, drop=d2)
     assert ((f == 0) == (f_u == 0)).all()
     assert (f - f_u).abs().max() < 5e-5
+
+
+def _ln_bwd_ref(dx, o, res, gamma, mask):
+    """float64 reference of the add & norm backward: returns dz (gradient of the normalised sum) and do = dz * mask."""
+    z = (o.double() * mask.double() + res.double()).requires_grad_(True)
+    y = torch.nn.functional.layer_norm(z, (z.shape[1],), gamma.double(), torch.zeros_like(gamma).double(), 1e-5)
+    y.backward(dx.double())
+    zh = ((z - z.mean(1, keepdim=True)) * (z.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()).detach()
+    return z.grad, z.grad * mask.double(), (dx.double() * zh).sum(0), dx.double().sum(0)
+
+
+@pytest.mark.parametrize("M,ffn,pre,p", [(1280, True, True, 0.0), (1280, False, True, 0.0), (37, True, False, 0.0),
+                                          (160, True, True, 0.3), (160, False, True, 0.2)])
+def test_backward_chain_matches_reference(M, ffn, pre, p):
+    from ick_amd import ops
+    d, FF, K0 = 300, 512, 900 if ffn else 300
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g).cuda()
+    seed, ep = 77, None
+    mk = lambda site: ops.dropout_mask(M, d, p, seed, site) if p > 0 else torch.ones(M, d, device="cuda")
+    dr = lambda site: (p, seed, site) if p > 0 else None
+
+    def norm_inputs(site):
+        o, res, gamma = r(M, d), r(M, d), 1 + 0.1 * r(d)
+        z = o * mk(site) + res
+        return dict(o=o, res=res, gamma=gamma, mean=z.mean(1), rstd=(z.var(1, unbiased=False) + 1e-5).rsqrt(),
+                    drop=dr(site), do=torch.empty(M, d, device="cuda"), part=ops.ln_partials(M, d, "cuda"))
+
+    n1 = norm_inputs(3)
+    w3 = r(d, d) / d ** 0.5
+    g0 = r(M, K0) if pre else None
+    w0 = r(K0, d) / K0 ** 0.5 if pre else None
+    dzin = r(M, d)
+    out3, dz_out = torch.empty(M, d, device="cuda"), torch.empty(M, d, device="cuda")
+    kw = {}
+    if ffn:
+        n2 = norm_inputs(4)
+        w2l, w1l = r(d, FF) / FF ** 0.5, r(FF, d) / d ** 0.5        # linear2.weight (d, FF), linear1.weight (FF, d)
+        act = (r(M, FF).relu() * (torch.rand(M, FF, generator=g).cuda() > 0.3)).contiguous()
+        t_out = torch.empty(M, FF, device="cuda")
+        kw = dict(ffn=dict(w1p=ops.pack_weight(w2l.t()), w2p=ops.pack_weight(w1l.t()), act=act, gate_scale=1.25,
+                           t_out=t_out), norm2=n2)
+    ops.rowchain_bwd(M, d, n1, ops.pack_weight(w3.t()), out3, dz_out, g0=g0, w0p=ops.pack_weight(w0.t()) if pre else None,
+                     dzin=dzin, **kw)
+    # reference
+    dx = dzin.double() + (g0.double() @ w0.double() if pre else 0)
+    dz1, do1, dg1, db1 = _ln_bwd_ref(dx, n1["o"], n1["res"], n1["gamma"], mk(3))
+    tol = 3e-5
+    assert (n1["do"].double() - do1).abs().max() < tol
+    assert (n1["part"].double().sum(0)[:d] - dg1).abs().max() < 1e-3 and (n1["part"].double().sum(0)[d:] - db1).abs().max() < 1e-3
+    last_do, last_dz = do1, dz1
+    if ffn:
+        t = (do1 @ w2l.double()) * (act.double() > 0) * 1.25
+        assert (t_out.double() - t).abs().max() < tol
+        dx2 = dz1 + t @ w1l.double()
+        dz2, do2, dg2, db2 = _ln_bwd_ref(dx2, n2["o"], n2["res"], n2["gamma"], mk(4))
+        assert (n2["do"].double() - do2).abs().max() < 2 * tol
+        assert (n2["part"].double().sum(0)[:d] - dg2).abs().max() < 1e-3
+        last_do, last_dz = do2, dz2
+    assert (dz_out.double() - last_dz).abs().max() < 2 * tol
+    assert (out3.double() - last_do @ w3.double()).abs().max() < 2 * tol
