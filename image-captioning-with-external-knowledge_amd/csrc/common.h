@@ -26,23 +26,23 @@ inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Reductions over the 64 lanes of a wave, result in every lane.  The four steps inside a row of 16 lanes are DPP
 // operands of the add / max itself (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: one VALU instruction
-// each); only the two steps across rows go through ds_bpermute (~100 cycles each).
+// each); the four row results are then read into scalar registers (v_readlane) and combined as (r0 + r1) + (r2 + r3)
+// -- the value the xor-16 / xor-32 butterfly gives, without its two ds_bpermute round trips (~100 cycles each).
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
+__device__ __forceinline__ float lane_f32(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_f32<0xB1>(v); v += dpp_f32<0x4E>(v); v += dpp_f32<0x141>(v); v += dpp_f32<0x140>(v);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    return (lane_f32(v, 0) + lane_f32(v, 16)) + (lane_f32(v, 32) + lane_f32(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_f32<0xB1>(v)); v = fmaxf(v, dpp_f32<0x4E>(v));
     v = fmaxf(v, dpp_f32<0x141>(v)); v = fmaxf(v, dpp_f32<0x140>(v));
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    v = fmaxf(v, __shfl_xor(v, 32, 64));
-    return v;
+    return fmaxf(fmaxf(lane_f32(v, 0), lane_f32(v, 16)), fmaxf(lane_f32(v, 32), lane_f32(v, 48)));
 }
 
 // Block-wide reductions for blocks of NW waves; scratch must hold NW floats.

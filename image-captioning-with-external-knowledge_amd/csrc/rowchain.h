@@ -43,35 +43,43 @@ __device__ __forceinline__ Slab slab_of(const GemmPlan& g) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: K offsets stay in SGPRs
     return Slab{wave % g.nslab, wave / g.nslab};
 }
+// begin(): descriptor + the loads of the first two K chunks (they depend on nothing but the weights, so a kernel issues
+// them before it waits for the rows the GEMM multiplies: the first weight round trip hides behind that wait);
+// run(): the pipelined K loop.
 template <int DBG = 0>
-__device__ __forceinline__ void row_gemm(const float* Xs, int ldx, int K, const float* __restrict__ Wp, const GemmPlan g,
-                                         const Slab w, f32x4& acc0, f32x4& acc1) {
-    const int lane = threadIdx.x & 63;
-    acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int kb = w.h * g.kper;
-    const int ke = min(K, kb + g.kper);
-    if (w.h >= g.splits || kb >= ke) return;
-    const int K16 = (K + 15) & ~15;
-    const int slab_bytes = K16 * 64 * 4;                 // one slab of the packed copy
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(Wp) + (size_t)w.slab * K16 * 64, (short)0, slab_bytes, 0x00020000);
-    const int voff = lane * 16;
-    const int nchunk = (ke - kb + 15) >> 4;
-    const float* xa = Xs + (lane & 3) * ldx + (lane >> 2);
+struct RowGemm {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff, nchunk, kb, slab_bytes;
     f32x4 bq[3][4];
+
     // Software pipeline, two chunks ahead, without branches around the loads (the compiler's s_waitcnt counting
     // only stays exact in straight-line code): a chunk beyond this wave's K range is fetched from beyond the
     // descriptor's extent (no memory access, zeros).
-    auto load = [&](f32x4 (&b)[4], int c) {
+    __device__ __forceinline__ void load(f32x4 (&b)[4], int c) {
         const int base = c < nchunk ? (kb + 16 * c) * 256 : slab_bytes;      // scalar; 16 k = 4 KiB
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (DBG == 1 || DBG == 3) b[j] = f32x4{(float)base, 1.f, 2.f, (float)j};
             else b[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, base + j * 1024, 0));
         }
-    };
-    auto mfma = [&](const f32x4 (&b)[4], int c) {
+    }
+
+    __device__ __forceinline__ void begin(int K, const float* __restrict__ Wp, const GemmPlan g, const Slab w) {
+        kb = w.h * g.kper;
+        const int ke = min(K, kb + g.kper);
+        nchunk = (w.h < g.splits && kb < ke) ? (ke - kb + 15) >> 4 : 0;     // 0: a wave without work
+        const int K16 = (K + 15) & ~15;
+        slab_bytes = K16 * 64 * 4;                 // one slab of the packed copy
+        const int slab = w.h < g.splits ? w.slab : 0;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wp) + (size_t)slab * K16 * 64, (short)0, slab_bytes,
+                                                 0x00020000);
+        voff = (threadIdx.x & 63) * 16;
+        load(bq[0], 0);
+        load(bq[1], 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    __device__ __forceinline__ void mfma(const f32x4 (&b)[4], const float* xa, int ldx, int c, f32x4& acc0, f32x4& acc1) {
         const int k0 = kb + 16 * c;
         const float a0 = xa[k0], a1 = xa[4 * ldx + k0];
         if (DBG == 2 || DBG == 3) {
@@ -81,29 +89,33 @@ __device__ __forceinline__ void row_gemm(const float* Xs, int ldx, int K, const 
         }
         ICK_MF(0) ICK_MF(1) ICK_MF(2) ICK_MF(3) ICK_MF(4) ICK_MF(5) ICK_MF(6) ICK_MF(7)
         ICK_MF(8) ICK_MF(9) ICK_MF(10) ICK_MF(11) ICK_MF(12) ICK_MF(13) ICK_MF(14) ICK_MF(15)
-    };
-    // sched_barrier: the machine scheduler otherwise sinks the prefetches down to their uses (vmcnt(0) per chunk)
+    }
+
+    __device__ __forceinline__ void run(const float* Xs, int ldx, f32x4& acc0, f32x4& acc1) {
+        const int lane = threadIdx.x & 63;
+        acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* xa = Xs + (lane & 3) * ldx + (lane >> 2);
+        // sched_barrier: the machine scheduler otherwise sinks the prefetches down to their uses (vmcnt(0) per chunk)
 #define ICK_STEP(LD, LC, MF, MC)              \
     load(bq[LD], LC);                        \
     __builtin_amdgcn_sched_barrier(0);       \
-    mfma(bq[MF], MC);                        \
+    mfma(bq[MF], xa, ldx, MC, acc0, acc1);   \
     __builtin_amdgcn_sched_barrier(0);
-    load(bq[0], 0);
-    load(bq[1], 1);
-    __builtin_amdgcn_sched_barrier(0);
-    int c = 0;
-    for (; c + 3 <= nchunk; c += 3) {
-        ICK_STEP(2, c + 2, 0, c)
-        ICK_STEP(0, c + 3, 1, c + 1)
-        ICK_STEP(1, c + 4, 2, c + 2)
-    }
-    if (c < nchunk) {          // one or two chunks left, already in flight
-        mfma(bq[0], c);
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < nchunk) mfma(bq[1], c + 1);
-    }
+        int c = 0;
+        for (; c + 3 <= nchunk; c += 3) {
+            ICK_STEP(2, c + 2, 0, c)
+            ICK_STEP(0, c + 3, 1, c + 1)
+            ICK_STEP(1, c + 4, 2, c + 2)
+        }
+        if (c < nchunk) {          // one or two chunks left, already in flight
+            mfma(bq[0], xa, ldx, c, acc0, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < nchunk) mfma(bq[1], xa, ldx, c + 1, acc0, acc1);
+        }
 #undef ICK_STEP
-}
+    }
+};
 
 // a / b for 0 <= a < 2^22, 0 < b < 2^22 without the ~40-instruction integer division sequence (every VALU instruction of
 // a 16-wave workgroup costs 16 cycles of its CU): float quotient, then one correction step

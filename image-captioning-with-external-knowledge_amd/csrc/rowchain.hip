@@ -92,6 +92,10 @@ __global__ __launch_bounds__(kThreads) void rowchain_fwd_kernel(ick_rowchain_arg
         }
     }
     ICK_CSTAMP(1);
+    const GemmPlan g1 = plan_for(d, p.K1);
+    const Slab w1 = slab_of(g1);
+    RowGemm<DBG> mm1, mm2;
+    mm1.begin(p.K1, p.w1p, g1, w1);       // weights of GEMM 1 start streaming before the rows arrive
     // ---- A rows -> LDS (zero beyond K1 up to the next multiple of 16, zero rows beyond M): wave = (row, half)
     const int K1 = p.K1, K1p = (K1 + 15) & ~15;
     {
@@ -105,11 +109,10 @@ __global__ __launch_bounds__(kThreads) void rowchain_fwd_kernel(ick_rowchain_arg
     ICK_CSTAMP(2);
     __syncthreads();
     ICK_CSTAMP(3);
-    const GemmPlan g1 = plan_for(d, K1);
     {
-        const Slab w = slab_of(g1);
+        const Slab w = w1;
         f32x4 acc0, acc1;
-        row_gemm<DBG>(Xs, kLdx, K1, p.w1p, g1, w, acc0, acc1);
+        mm1.run(Xs, kLdx, acc0, acc1);
         ICK_CSTAMP(4);
         if (w.h < g1.splits) {
             float* q = Ps + (size_t)w.h * kRows * (g1.nslab * 64) + w.slab * 64 + lane;
@@ -122,6 +125,7 @@ __global__ __launch_bounds__(kThreads) void rowchain_fwd_kernel(ick_rowchain_arg
     }
     __syncthreads();
     ICK_CSTAMP(5);
+    if (p.w2p != nullptr) mm2.begin(d, p.w2p, g2, w2);    // ... and those of GEMM 2 behind the LayerNorm
     // ---- o = sum of the K splits + bias; x = LayerNorm(res + dropout(o)); one wave per row
     const int dp = (d + 15) & ~15;
     if (ln_wave) {
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(kThreads) void rowchain_fwd_kernel(ick_rowchain_arg
     // accumulators and stores its 64 columns of the 8 rows -- plain rows or the head-split scatter of ick_gemm
     const Slab w = w2;
     f32x4 acc0, acc1;
-    row_gemm<DBG>(Xs, kLdx, d, p.w2p, g2, w, acc0, acc1);
+    mm2.run(Xs, kLdx, acc0, acc1);
     ICK_CSTAMP(8);
     const int npad = g2.nslab * 64;
     if (g2.splits > 1) {

@@ -113,7 +113,12 @@ __global__ __launch_bounds__(kThreads) void rowchain_bwd_kernel(ick_rowchain_bwd
     // ---- dx = dzin + g0 W0
     const bool pre = p.g0 != nullptr;          // uniform
     const GemmPlan g0p = plan_for(d, pre ? p.K0 : 16);
+    const GemmPlan gF2 = plan_for(d, ffn ? N1 : 16);
+    const GemmPlan g3 = plan_for(d, d);
+    RowGemm<> mm;                              // one at a time: the next GEMM's first loads go out before the stage
+                                               // that produces its rows (norm / epilogue) runs
     if (pre) {
+        mm.begin(p.K0, p.w0p, g0p, slab_of(g0p));
         const int K0 = p.K0, K0p = (K0 + 15) & ~15;
         const int r = wave & (kRows - 1), half = wave >> 3;
         const int gr = row0 + r;
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(kThreads) void rowchain_bwd_kernel(ick_rowchain_bwd
         __syncthreads();
         const Slab w = slab_of(g0p);
         f32x4 acc0, acc1;
-        row_gemm(XA, kLdA, K0, p.w0p, g0p, w, acc0, acc1);
+        mm.run(XA, kLdA, acc0, acc1);
         if (w.h < g0p.splits) {
             float* q = Ps + (size_t)w.h * kRows * (g0p.nslab * 64) + w.slab * 64 + lane;
 #pragma unroll
@@ -134,6 +139,8 @@ __global__ __launch_bounds__(kThreads) void rowchain_bwd_kernel(ick_rowchain_bwd
         __syncthreads();
     }
     // ---- norm stage 1 (one wave per row)
+    if (ffn) mm.begin(d, p.w1p, gF1, wF1);
+    else mm.begin(d, p.w3p, g3, slab_of(g3));
     if (ln_wave) {
         float dx[5], dz[5], dod[5], dgam[5], dbet[5];
         const int npad = g0p.nslab * 64;
@@ -180,7 +187,8 @@ __global__ __launch_bounds__(kThreads) void rowchain_bwd_kernel(ick_rowchain_bwd
         // ---- t = gate(do1 W2): the K split 0 wave of a slab owns the result
         {
             f32x4 acc0, acc1;
-            row_gemm(XB, kLdB, d, p.w1p, gF1, wF1, acc0, acc1);
+            mm.run(XB, kLdB, acc0, acc1);
+            mm.begin(N1, p.w2p, gF2, slab_of(gF2));
             const int npad = gF1.nslab * 64;
             if (gF1.splits > 1) {
                 if (wF1.h > 0 && wF1.h < gF1.splits) {
@@ -212,11 +220,11 @@ __global__ __launch_bounds__(kThreads) void rowchain_bwd_kernel(ick_rowchain_bwd
             __syncthreads();
         }
         // ---- dx2 = dz1 + t W1
-        const GemmPlan gF2 = plan_for(d, N1);
         {
             const Slab w = slab_of(gF2);
             f32x4 acc0, acc1;
-            row_gemm(XA, kLdA, N1, p.w2p, gF2, w, acc0, acc1);
+            mm.run(XA, kLdA, acc0, acc1);
+            mm.begin(d, p.w3p, g3, slab_of(g3));
             if (w.h < gF2.splits) {
                 float* q = Ps + (size_t)w.h * kRows * (gF2.nslab * 64) + w.slab * 64 + lane;
 #pragma unroll
@@ -271,10 +279,9 @@ __global__ __launch_bounds__(kThreads) void rowchain_bwd_kernel(ick_rowchain_bwd
         }
     }
     // ---- out = do W3 (data gradient of the out-projection): K split 0 waves store
-    const GemmPlan g3 = plan_for(d, d);
     const Slab w3 = slab_of(g3);
     f32x4 acc0, acc1;
-    row_gemm(XB, kLdB, d, p.w3p, g3, w3, acc0, acc1);
+    mm.run(XB, kLdB, acc0, acc1);
     const int npad = g3.nslab * 64;
     const int col = w3.slab * 64 + lane;
     if (g3.splits > 1) {

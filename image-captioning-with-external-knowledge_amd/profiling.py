@@ -47,6 +47,17 @@ def classify(name, args):
     if name == "ick_attention_bwd":
         a = _struct(args[0])
         return "attention backward", 10.0 * a.B * a.H * a.T * a.S * a.dh, "flop"
+    if name == "ick_rowchain_fwd":
+        a = _struct(args[0])
+        fl = 2.0 * a.M * (a.K1 * a.d + (a.d * a.N2 if a.w2p else 0))
+        return "row chain forward (out-projection + add & norm + next Linear)", fl, "flop"
+    if name == "ick_rowchain_bwd":
+        a = _struct(args[0])
+        fl = 2.0 * a.M * ((a.K0 * a.d if a.g0 else 0) + (2 * a.d * a.N1 if a.w1p else 0) + a.d * a.d)
+        return "row chain backward (Linear' + norm' [+ FFN' + norm'] + out-projection')", fl, "flop"
+    if name == "ick_pack_weights":
+        arr, n = args[0], args[1]
+        return "packed weight copies", 8.0 * sum(arr[i].N * arr[i].K for i in range(n)), "byte"
     if name == "ick_add_layernorm":
         rows, d = args[5], args[6]
         return "residual + LayerNorm", 4.0 * rows * d * 3, "byte"
