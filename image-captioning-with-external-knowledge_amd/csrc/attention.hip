@@ -26,6 +26,7 @@ namespace {
 // (dh..DHP) may hold anything and are masked to zero in registers.
 template <int DHP, bool VEC>
 __global__ __launch_bounds__(256) void attn_kernel(ick_attn_args p, int TQ, int SLD) {
+    chain_priority();
     constexpr int VLD = DHP + 4;  // float4 rows; 8 lanes x 16 B cover the 32 banks once
     constexpr int G = DHP / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -201,6 +202,7 @@ int launch_attn(const ick_attn_args& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 template <int DHP>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(ick_attn_bwd_args p, int TQ, int SLD) {
+    chain_priority();
     constexpr int VLD = DHP + 4;
     constexpr int G = DHP / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];

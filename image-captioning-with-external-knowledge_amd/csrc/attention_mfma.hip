@@ -75,6 +75,7 @@ __device__ __forceinline__ void stage_transposed(const float* __restrict__ src, 
 // ---------------------------------------------------------------------------------------------
 template <int NQT, int MAXT>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ick_attn_args p, int SP) {
+    chain_priority();
     constexpr int NQ = NQT * 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Vt = smem;                    // max(DHP * SP, 4 waves * NQT * 2 tiles * 256)   V^T: [col][key]
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ick_attn_args p, int
 // ---------------------------------------------------------------------------------------------
 template <int NQT, int MAXT>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p, int SP, bool st2) {
+    chain_priority();
     constexpr int NQ = NQT * 16;
     constexpr int TLD = NQ + 4;          // row stride of the transposed Q / dO tiles ([col][query])
     extern __shared__ __attribute__((aligned(16))) float smem[];

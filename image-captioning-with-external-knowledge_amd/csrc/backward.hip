@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             int64_t rows, int d, int rows_per_block,
                                                             float* __restrict__ dx_drop, DropArg darg,
                                                             float* __restrict__ partials) {
+    chain_priority();
     extern __shared__ float sm[];  // 2 * d partial sums
     const Dropout drop = darg.get();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(256) void caption_embed_bwd_kernel(const float* __r
                                                                 float* __restrict__ dfe, int B, int L, int K, int F,
                                                                 int V, int d, int pad_token, float scale,
                                                                 DropArg darg) {
+    chain_priority();
     const Dropout drop = darg.get();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -194,6 +196,7 @@ __global__ __launch_bounds__(256) void pointer_bwd_dh_kernel(const float* __rest
                                                              const float* __restrict__ ctx, const float* __restrict__ w,
                                                              const float* __restrict__ ind, float* __restrict__ dh,
                                                              int T, int Kc, int d) {
+    chain_priority();
     const int b = blockIdx.y, t = blockIdx.x;
     const float* dsr = ds + ((int64_t)b * T + t) * ds_ld + col0;
     for (int c = threadIdx.x; c < d; c += 256) {
@@ -228,6 +231,7 @@ __global__ __launch_bounds__(256) void pointer_bwd_dctx_kernel(const float* __re
                                                                const float* __restrict__ w, const float* __restrict__ ind,
                                                                float* __restrict__ dctx, float* __restrict__ dw,
                                                                float* __restrict__ dbias, int T, int Kc, int d) {
+    chain_priority();
     extern __shared__ float gs[];   // T * Kc gradients (indicator applied), 4 floats of scratch, 4 x 64 partial d w
     float* red = gs + T * Kc;
     float* dwp = red + 4;
@@ -269,6 +273,7 @@ __global__ __launch_bounds__(256) void entity_encode_bwd_kernel(int variant, con
                                                                 const float* __restrict__ word_emb, int vocab,
                                                                 float* __restrict__ dtype_emb, int ntypes,
                                                                 float* __restrict__ dword, int B, int K, int d) {
+    chain_priority();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B * K) return;
@@ -311,6 +316,7 @@ __global__ __launch_bounds__(256) void fact_encode_bwd_kernel(const float* __res
                                                               const int64_t* __restrict__ facts, float* __restrict__ dee,
                                                               float* __restrict__ dpred, int num_pred, int B, int K,
                                                               int F, int d) {
+    chain_priority();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B * F) return;

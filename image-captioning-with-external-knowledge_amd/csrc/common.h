@@ -45,6 +45,17 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(fmaxf(lane_f32(v, 0), lane_f32(v, 16)), fmaxf(lane_f32(v, 32), lane_f32(v, 48)));
 }
 
+// Wave priority for the instruction arbiter (s_setprio, 0..3).  The latency-bound chain kernels (a few hundred
+// workgroups, one dependent launch after another) raise it: beside a bulk GEMM on the other stream their waves
+// otherwise get a round-robin share of the matrix pipe (measured: the 14 us in_proj GEMM of the context encoder
+// takes 111 us beside Encoder.conv1), while the bulk kernel hardly notices the few cycles they take.
+// ICK_NO_SETPRIO (compile time) turns it off.
+__device__ __forceinline__ void chain_priority() {
+#ifndef ICK_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+}
+
 // Block-wide reductions for blocks of NW waves; scratch must hold NW floats.
 template <int NW>
 __device__ __forceinline__ float block_sum(float v, float* scratch) {

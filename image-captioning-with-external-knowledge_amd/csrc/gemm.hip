@@ -354,6 +354,7 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
 template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(ick_gemm_args p, int tiles_m, int tiles_n, int kchunk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if constexpr (TM == 1) chain_priority();     // 32 x 32 tiles: the chain GEMMs (single launches, not the grouped weight gradients)
     gemm_tile<WM, WN, TM, TN, AKM, BKM, VEC, BKT>(p, tiles_m, tiles_n, kchunk, blockIdx.x, blockIdx.z, smem);
 }
 

@@ -17,6 +17,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
                                                             int64_t rows, int d, float eps, int64_t x_ld,
                                                             int64_t res_ld, int64_t y_ld, float* save_mean,
                                                             float* save_rstd, DropArg darg) {
+    chain_priority();
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;

@@ -17,6 +17,7 @@ __global__ __launch_bounds__(256) void entity_encode_kernel(int variant, const f
                                                             const float* __restrict__ type_emb, int ntypes,
                                                             const float* __restrict__ word_emb, int vocab,
                                                             float* __restrict__ out, int B, int K, int F, int d) {
+    chain_priority();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B * K) return;
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(256) void fact_encode_kernel(const int64_t* __restr
                                                           const float* __restrict__ ee,
                                                           const float* __restrict__ pred_emb, int num_pred,
                                                           float* __restrict__ out, int B, int K, int F, int d) {
+    chain_priority();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B * F) return;
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(256) void caption_embed_kernel(const int64_t* __res
                                                             float* __restrict__ out, float* __restrict__ emb_out, int B,
                                                             int L, int K, int F, int V, int d, int pad_token,
                                                             float scale, int pos0, DropArg darg) {
+    chain_priority();
     const Dropout drop = darg.get();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -49,6 +49,7 @@ using namespace rowchain;
 
 template <int DBG>
 __global__ __launch_bounds__(kThreads) void rowchain_fwd_kernel(ick_rowchain_args p) {
+    chain_priority();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                       // [8][kLdx]   GEMM input rows (A, then the normalised rows)
     float* Ps = smem + kRows * kLdx;        // K-split partials

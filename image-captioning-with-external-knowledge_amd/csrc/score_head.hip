@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void pointer_scores_kernel(const float* __rest
                                                              const float* __restrict__ ind, float* __restrict__ out,
                                                              int T, int Kc, int d, int64_t out_ld, int col0,
                                                              const int32_t* __restrict__ out_gmap) {
+    chain_priority();
     constexpr int KB = 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y, t = blockIdx.x;
