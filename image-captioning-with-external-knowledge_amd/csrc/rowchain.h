@@ -39,14 +39,16 @@ __host__ __device__ __forceinline__ GemmPlan plan_for(int N, int K) {
 // acc[row] (lane = column of the wave's slab) = Xs[row][k range of the wave's split] . W[col][k] from the packed copy
 // Wp; Xs is zero beyond K.  Returns false for a wave without work (more waves than slabs x splits).
 struct Slab { int slab, h; };
+__device__ __forceinline__ Slab unit_of(const GemmPlan& g, int unit) {      // unit = slab + nslab * K split (scalar)
+    return Slab{unit % g.nslab, unit / g.nslab};
+}
 __device__ __forceinline__ Slab slab_of(const GemmPlan& g) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: K offsets stay in SGPRs
-    return Slab{wave % g.nslab, wave / g.nslab};
+    return unit_of(g, wave);
 }
 // begin(): descriptor + the loads of the first two K chunks (they depend on nothing but the weights, so a kernel issues
 // them before it waits for the rows the GEMM multiplies: the first weight round trip hides behind that wait);
 // run(): the pipelined K loop.
-template <int DBG = 0>
 struct RowGemm {
     __amdgpu_buffer_rsrc_t rsrc;
     int voff, nchunk, kb, slab_bytes;
@@ -59,8 +61,7 @@ struct RowGemm {
         const int base = c < nchunk ? (kb + 16 * c) * 256 : slab_bytes;      // scalar; 16 k = 4 KiB
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (DBG == 1 || DBG == 3) b[j] = f32x4{(float)base, 1.f, 2.f, (float)j};
-            else b[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, base + j * 1024, 0));
+            b[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, base + j * 1024, 0));
         }
     }
 
@@ -82,11 +83,6 @@ struct RowGemm {
     __device__ __forceinline__ void mfma(const f32x4 (&b)[4], const float* xa, int ldx, int c, f32x4& acc0, f32x4& acc1) {
         const int k0 = kb + 16 * c;
         const float a0 = xa[k0], a1 = xa[4 * ldx + k0];
-        if (DBG == 2 || DBG == 3) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { acc0 += b[j] * a0; acc1 += b[j] * a1; }
-            return;
-        }
         ICK_MF(0) ICK_MF(1) ICK_MF(2) ICK_MF(3) ICK_MF(4) ICK_MF(5) ICK_MF(6) ICK_MF(7)
         ICK_MF(8) ICK_MF(9) ICK_MF(10) ICK_MF(11) ICK_MF(12) ICK_MF(13) ICK_MF(14) ICK_MF(15)
     }

@@ -47,8 +47,13 @@ namespace {
 
 using namespace rowchain;
 
-template <int DBG>
-__global__ __launch_bounds__(kThreads) void rowchain_fwd_kernel(ick_rowchain_args p) {
+// NW = waves per workgroup.  The 16 (slab, K split) units of a GEMM stage are dealt to the waves round robin: one per
+// wave at NW = 16, two at NW = 8.  The 8-wave form does the same matrix work per SIMD, but half the wave slots and
+// registers: it still finds room on a CU that already hosts two 8-wave GEMM workgroups (Encoder.conv1) or after a
+// single 4-wave one retires, where the 16-wave form waits for the bulk kernel to drain (measured: 137 us for a 25 us
+// launch beside the image K/V projection) -- callers pass ICK_CHAIN_SLIM for chains that run beside bulk GEMMs.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void rowchain_fwd_kernel(ick_rowchain_args p) {
     chain_priority();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                       // [8][kLdx]   GEMM input rows (A, then the normalised rows)
@@ -58,7 +63,6 @@ __global__ __launch_bounds__(kThreads) void rowchain_fwd_kernel(ick_rowchain_arg
     const int d = p.d, M = p.M;
     // Thread mappings are chosen so that nothing below divides per element: at 16 waves a VALU instruction of
     // every thread costs 16 cycles of the CU, a 32-bit division ~40 of them.
-
     ICK_CSTAMP(0);
     const uint32_t seed = p.drop_epoch ? p.drop_seed + *p.drop_epoch : p.drop_seed;
     // ---- the residual row, gamma / beta / bias of the LayerNorm wave: issued first, consumed after GEMM 1
@@ -75,58 +79,43 @@ __global__ __launch_bounds__(kThreads) void rowchain_fwd_kernel(ick_rowchain_arg
         rb[j] = ok ? p.beta[c] : 0.f;
         rbias[j] = ok && p.b1 ? p.b1[c] : 0.f;
     }
-    // ---- everything the second GEMM's epilogue needs besides the accumulators (bias, column offset): also up front
-    const int N2 = p.N2;
-    const GemmPlan g2 = plan_for(max(N2, 1), d);
-    const Slab w2 = slab_of(g2);
-    const int col2 = w2.slab * 64 + lane;
-    const bool hs = p.hs_dh > 0;
-    float bias2 = 0.f;
-    int64_t coff2 = col2;
-    if (p.w2p != nullptr && col2 < N2) {
-        if (p.b2) bias2 = p.b2[col2];
-        if (hs) {
-            const int hd = p.hs_H * p.hs_dh;
-            const int seg = small_div(col2, hd), rr = col2 - seg * hd;
-            const int hh = small_div(rr, p.hs_dh), jj = rr - hh * p.hs_dh;
-            coff2 = (int64_t)p.hs_s0 * p.hs_dhp + ((int64_t)seg * p.hs_H + hh) * ((int64_t)p.hs_S * p.hs_dhp) + jj;
-        }
-    }
     ICK_CSTAMP(1);
-    const GemmPlan g1 = plan_for(d, p.K1);
-    const Slab w1 = slab_of(g1);
-    RowGemm<DBG> mm1, mm2;
-    mm1.begin(p.K1, p.w1p, g1, w1);       // weights of GEMM 1 start streaming before the rows arrive
-    // ---- A rows -> LDS (zero beyond K1 up to the next multiple of 16, zero rows beyond M): wave = (row, half)
     const int K1 = p.K1, K1p = (K1 + 15) & ~15;
+    const GemmPlan g1 = plan_for(d, K1);
+    const int units1 = g1.nslab * g1.splits;
+    RowGemm mm;
+    mm.begin(K1, p.w1p, g1, unit_of(g1, wave));       // weights of GEMM 1 start streaming before the rows arrive
+    // ---- A rows -> LDS (zero beyond K1 up to the next multiple of 16, zero rows beyond M): wave = (row, part)
     {
-        const int r = wave & (kRows - 1), half = wave >> 3;
+        const int r = wave & (kRows - 1), part = wave >> 3;
         const int gr = row0 + r;
         int64_t off = (int64_t)gr * p.a_rs;
         if (p.a_grp > 0) { const int g = small_div(gr, p.a_grp); off = (int64_t)g * p.a_gs + (int64_t)(gr - g * p.a_grp) * p.a_rs; }
         const float* arow = p.A + off;
-        for (int k = lane + 64 * half; k < K1p; k += 128) Xs[r * kLdx + k] = (gr < M && k < K1) ? arow[k] : 0.f;
+        for (int k = lane + 64 * part; k < K1p; k += 8 * NW) Xs[r * kLdx + k] = (gr < M && k < K1) ? arow[k] : 0.f;
     }
     ICK_CSTAMP(2);
     __syncthreads();
     ICK_CSTAMP(3);
-    {
-        const Slab w = w1;
+    for (int u = wave; u < units1; u += NW) {
+        const Slab w = unit_of(g1, u);
+        if (u != wave) mm.begin(K1, p.w1p, g1, w);
         f32x4 acc0, acc1;
-        mm1.run(Xs, kLdx, acc0, acc1);
-        ICK_CSTAMP(4);
-        if (w.h < g1.splits) {
-            float* q = Ps + (size_t)w.h * kRows * (g1.nslab * 64) + w.slab * 64 + lane;
+        mm.run(Xs, kLdx, acc0, acc1);
+        float* q = Ps + (size_t)w.h * kRows * (g1.nslab * 64) + w.slab * 64 + lane;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                q[i * g1.nslab * 64] = acc0[i];
-                q[(4 + i) * g1.nslab * 64] = acc1[i];
-            }
+        for (int i = 0; i < 4; ++i) {
+            q[i * g1.nslab * 64] = acc0[i];
+            q[(4 + i) * g1.nslab * 64] = acc1[i];
         }
     }
+    ICK_CSTAMP(4);
     __syncthreads();
     ICK_CSTAMP(5);
-    if (p.w2p != nullptr) mm2.begin(d, p.w2p, g2, w2);    // ... and those of GEMM 2 behind the LayerNorm
+    const int N2 = p.N2;
+    const GemmPlan g2 = plan_for(max(N2, 1), d);
+    const int units2 = p.w2p != nullptr ? g2.nslab * g2.splits : 0;
+    if (wave < units2) mm.begin(d, p.w2p, g2, unit_of(g2, wave));    // ... and those of GEMM 2 behind the LayerNorm
     // ---- o = sum of the K splits + bias; x = LayerNorm(res + dropout(o)); one wave per row
     const int dp = (d + 15) & ~15;
     if (ln_wave) {
@@ -183,46 +172,66 @@ __global__ __launch_bounds__(kThreads) void rowchain_fwd_kernel(ick_rowchain_arg
     if (p.w2p == nullptr) return;     // uniform
     __syncthreads();
     ICK_CSTAMP(7);
-    // ---- y2 = act(x W2^T + b2), dropout: the K split 0 wave of a slab adds the other splits' partials (LDS) to its
-    // accumulators and stores its 64 columns of the 8 rows -- plain rows or the head-split scatter of ick_gemm
-    const Slab w = w2;
-    f32x4 acc0, acc1;
-    mm2.run(Xs, kLdx, acc0, acc1);
-    ICK_CSTAMP(8);
+    // ---- y2 = act(x W2^T + b2), dropout.  A wave whose only unit is a K split 0 keeps the result in its accumulators
+    // and adds the other splits' partials (LDS); otherwise every unit goes through LDS and its split 0 owner reads it back
     const int npad = g2.nslab * 64;
-    if (g2.splits > 1) {
-        if (w.h > 0 && w.h < g2.splits) {
-            float* q = Ps + (size_t)(w.h - 1) * kRows * npad + w.slab * 64 + lane;
+    const bool direct = NW >= 16;     // one unit per wave
+    f32x4 acc0, acc1;
+    for (int u = wave; u < units2; u += NW) {
+        const Slab w = unit_of(g2, u);
+        if (u != wave) mm.begin(d, p.w2p, g2, w);
+        mm.run(Xs, kLdx, acc0, acc1);
+        if (!(direct && w.h == 0)) {
+            float* q = Ps + (size_t)w.h * kRows * npad + w.slab * 64 + lane;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 q[i * npad] = acc0[i];
                 q[(4 + i) * npad] = acc1[i];
             }
         }
-        __syncthreads();
     }
+    ICK_CSTAMP(8);
+    if (g2.splits > 1 || !direct) __syncthreads();
     ICK_CSTAMP(9);
-    if (w.h != 0 || col2 >= N2) return;
-    float y[kRows];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { y[i] = acc0[i]; y[4 + i] = acc1[i]; }
-    for (int h = 1; h < g2.splits; ++h) {
-        const float* q = Ps + (size_t)(h - 1) * kRows * npad + col2;
-#pragma unroll
-        for (int i = 0; i < kRows; ++i) y[i] += q[i * npad];
-    }
     const Dropout drop = make_dropout(p.drop2_p, seed, p.drop2_site);
     const bool relu = p.flags & ICK_GEMM_RELU;
-    RowOff ro(row0, p.y2_grp, p.y2_gs, hs ? (int64_t)p.hs_dhp : p.y2_rs);
+    const bool hs = p.hs_dh > 0;
+    for (int u = wave; u < units2; u += NW) {
+        const Slab w = unit_of(g2, u);
+        const int col2 = w.slab * 64 + lane;
+        if (w.h != 0 || col2 >= N2) continue;
+        float y[kRows];
+        if (direct) {
 #pragma unroll
-    for (int i = 0; i < kRows; ++i) {
-        const int gr = row0 + i;
-        const int64_t roff = ro.next();
-        if (gr >= M) break;
-        float t = y[i] + bias2;
-        if (relu) t = fmaxf(t, 0.f);
-        if (drop.on()) t *= drop.mask((uint32_t)gr * (uint32_t)N2 + (uint32_t)col2);
-        p.y2[roff + coff2] = t;
+            for (int i = 0; i < 4; ++i) { y[i] = acc0[i]; y[4 + i] = acc1[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kRows; ++i) y[i] = Ps[i * npad + col2];
+        }
+        for (int h = 1; h < g2.splits; ++h) {
+            const float* q = Ps + (size_t)h * kRows * npad + col2;
+#pragma unroll
+            for (int i = 0; i < kRows; ++i) y[i] += q[i * npad];
+        }
+        const float bias2 = p.b2 ? p.b2[col2] : 0.f;
+        int64_t coff2 = col2;
+        if (hs) {
+            const int hd = p.hs_H * p.hs_dh;
+            const int seg = small_div(col2, hd), rr = col2 - seg * hd;
+            const int hh = small_div(rr, p.hs_dh), jj = rr - hh * p.hs_dh;
+            coff2 = (int64_t)p.hs_s0 * p.hs_dhp + ((int64_t)seg * p.hs_H + hh) * ((int64_t)p.hs_S * p.hs_dhp) + jj;
+        }
+        RowOff ro(row0, p.y2_grp, p.y2_gs, hs ? (int64_t)p.hs_dhp : p.y2_rs);
+#pragma unroll
+        for (int i = 0; i < kRows; ++i) {
+            const int gr = row0 + i;
+            const int64_t roff = ro.next();
+            if (gr >= M) break;
+            float t = y[i] + bias2;
+            if (relu) t = fmaxf(t, 0.f);
+            if (drop.on()) t *= drop.mask((uint32_t)gr * (uint32_t)N2 + (uint32_t)col2);
+            p.y2[roff + coff2] = t;
+        }
     }
     ICK_CSTAMP(10);
 }
@@ -322,11 +331,10 @@ extern "C" int ick_rowchain_fwd(const ick_rowchain_args* in, void* stream) {
     }
     constexpr size_t smem = (size_t)(kRows * kLdx + kPartFloats) * sizeof(float);
     static_assert(smem <= 64 * 1024, "needs the large-LDS attribute");
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("ICK_RC_DBG"); dbg = e ? atoi(e) : 0; }
-    if (dbg == 1) hipLaunchKernelGGL(rowchain_fwd_kernel<1>, dim3(ceil_div(a.M, kRows)), dim3(kThreads), smem, (hipStream_t)stream, a);
-    else if (dbg == 3) hipLaunchKernelGGL(rowchain_fwd_kernel<3>, dim3(ceil_div(a.M, kRows)), dim3(kThreads), smem, (hipStream_t)stream, a);
-    else if (dbg == 2) hipLaunchKernelGGL(rowchain_fwd_kernel<2>, dim3(ceil_div(a.M, kRows)), dim3(kThreads), smem, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(rowchain_fwd_kernel<0>, dim3(ceil_div(a.M, kRows)), dim3(kThreads), smem, (hipStream_t)stream, a);
+    const dim3 grid(ceil_div(a.M, kRows));
+    if (a.flags & ICK_CHAIN_SLIM)
+        hipLaunchKernelGGL(rowchain_fwd_kernel<8>, grid, dim3(8 * 64), smem, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(rowchain_fwd_kernel<16>, grid, dim3(16 * 64), smem, (hipStream_t)stream, a);
     ICK_LAUNCH_RET();
 }

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kThreads) void rowchain_bwd_kernel(ick_rowchain_bwd
     const GemmPlan g0p = plan_for(d, pre ? p.K0 : 16);
     const GemmPlan gF2 = plan_for(d, ffn ? N1 : 16);
     const GemmPlan g3 = plan_for(d, d);
-    RowGemm<> mm;                              // one at a time: the next GEMM's first loads go out before the stage
+    RowGemm mm;                              // one at a time: the next GEMM's first loads go out before the stage
                                                // that produces its rows (norm / epilogue) runs
     if (pre) {
         mm.begin(p.K0, p.w0p, g0p, slab_of(g0p));

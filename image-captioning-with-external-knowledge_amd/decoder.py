@@ -377,11 +377,12 @@ class DecoderTransformer(nn.Module):
             items.append(((key[0], key[1], key[2] + "T"), w.t()))
         return items
 
-    def _chain_pack(self, fresh=False, bwd=False):
+    def _chain_pack(self, fresh=False, bwd=False, subset=None):
         """Packed copies (ops.pack_weights) of the weights the row-chain launches read, as {key: tensor} views of one
         persistent buffer (bwd: of the transposed weights, for the data-gradient chains).  Refreshed when a parameter's
         version changed, or on every call with fresh=True (inside the captured training step, where the fused Adam
-        updates the weights behind torch's version counters)."""
+        updates the weights behind torch's version counters); then `subset` (a predicate on the item key) limits the
+        launch to the copies the caller needs first -- the rest follows in a later call."""
         items = self._chain_items_bwd() if bwd else self._chain_items()
         name = "_chain_cache_bwd" if bwd else "_chain_cache"
         cache = self.__dict__.get(name)
@@ -395,7 +396,9 @@ class DecoderTransformer(nn.Module):
                 off += n
             cache = {"ptr": items[0][1].data_ptr(), "buf": buf, "views": views, "key": None}
             self.__dict__[name] = cache
-        if fresh or cache["key"] != key:
+        if fresh and subset is not None:
+            ops.pack_weights([(w.detach(), cache["views"][k]) for k, w in items if subset(k)])
+        elif fresh or cache["key"] != key:
             ops.pack_weights([(w.detach(), cache["views"][k]) for k, w in items])
             cache["key"] = key
         return cache["views"]

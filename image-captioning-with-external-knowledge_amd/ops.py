@@ -200,12 +200,13 @@ def pack_weight(w):
 
 
 def rowchain_fwd(a, w1p, b1, res, gamma, beta, eps, x_out, drop1=None, o_out=None, save_stats=False,
-                 w2p=None, b2=None, y2=None, relu=False, drop2=None, heads=None):
+                 w2p=None, b2=None, y2=None, relu=False, drop2=None, heads=None, slim=False):
     """One launch for  o = a @ W1.T + b1;  x = LayerNorm(res + dropout1(o)) * gamma + beta;  y2 = act(x @ W2.T + b2)
     (dropout2 on y2).  a (..., K1) rows with a uniform row stride; w1p / w2p are packed copies (pack_weights) of the
     (d, K1) and (N2, d) nn.Linear weights; b2 gives N2; x_out (..., d) may be a (B, T, d) view with a sample stride
     (rows inside the memory buffer); heads = (nseg, H, S, s0, grp): y2 is the head-major buffer (B, nseg, H, S, DHP)
-    of project_heads.  Returns (mean, rstd) when save_stats."""
+    of project_heads.  slim: 8-wave workgroups (ICK_CHAIN_SLIM), for chains that run beside bulk GEMMs on another
+    stream.  Returns (mean, rstd) when save_stats."""
     K1, d = a.shape[-1], gamma.shape[0]
     a2 = a.reshape(-1, K1)
     if a2.stride(1) != 1:
@@ -248,6 +249,8 @@ def rowchain_fwd(a, w1p, b1, res, gamma, beta, eps, x_out, drop1=None, o_out=Non
             g.hs_dh, g.hs_dhp, g.hs_H, g.hs_S, g.hs_s0 = (N2 // nseg) // H, DHP, H, S, s0
         else:
             g.y2_rs, g.y2_grp, g.y2_gs = y2.reshape(-1, N2).stride(0), 0, 0
+    if slim:
+        g.flags |= 256
     L.check(L.load().ick_rowchain_fwd(C.byref(g), _stream()), "ick_rowchain_fwd")
     return (mean, rstd) if save_stats else None
 

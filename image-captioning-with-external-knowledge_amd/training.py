@@ -56,7 +56,7 @@ def _p(x):
 # ----------------------------------------------------------------------------------------------
 # forward with saved activations
 # ----------------------------------------------------------------------------------------------
-def _context_encoder_fwd(dec, stack, x, tape_list, ds, pk=None, tag="e", out=None):
+def _context_encoder_fwd(dec, stack, x, tape_list, ds, pk=None, tag="e", out=None, slim=False):
     """pk: packed weights (dec._chain_pack) -> the row-chain launches (out-projection + norm1 + linear1, linear2 + norm2
     + the next layer's in_proj) replace the separate GEMM / add & norm kernels; `out`: (B, T, d) view that receives
     the stack's output (its rows of the memory buffer)."""
@@ -82,7 +82,7 @@ def _context_encoder_fwd(dec, stack, x, tape_list, ds, pk=None, tag="e", out=Non
             t["m1"], t["r1"] = ops.rowchain_fwd(
                 t["sa"], pk[(tag, li, "so")], _p(layer.self_attn.out_proj.bias), x, _p(layer.norm1.weight),
                 _p(layer.norm1.bias), layer.norm1.eps, t["x1"], drop1=t["d1"], o_out=t["o1"], save_stats=True,
-                w2p=pk[(tag, li, "l1")], b2=_p(layer.linear1.bias), y2=t["f"], relu=True, drop2=t["d_ff"])
+                w2p=pk[(tag, li, "l1")], b2=_p(layer.linear1.bias), y2=t["f"], relu=True, drop2=t["d_ff"], slim=slim)
             nxt = None if last else stack.layers[li + 1]
             if nxt is not None:
                 qkv = torch.empty(B, 3, H, T, ops.DHP, device=x.device, dtype=torch.float32)
@@ -91,7 +91,7 @@ def _context_encoder_fwd(dec, stack, x, tape_list, ds, pk=None, tag="e", out=Non
                 _p(layer.norm2.bias), layer.norm2.eps, x2, drop1=t["d2"], o_out=t["o2"], save_stats=True,
                 w2p=None if nxt is None else pk[(tag, li + 1, "si")],
                 b2=None if nxt is None else _p(nxt.self_attn.in_proj_bias), y2=qkv,
-                heads=None if nxt is None else (3, H, T, 0, T))
+                heads=None if nxt is None else (3, H, T, 0, T), slim=slim)
         else:
             t["o1"] = ops.linear(t["sa"], _p(layer.self_attn.out_proj.weight), _p(layer.self_attn.out_proj.bias))
             t["x1"], t["m1"], t["r1"] = ops.add_layernorm(t["o1"], x, _p(layer.norm1.weight), _p(layer.norm1.bias),
@@ -217,20 +217,29 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     if dec.has_facts:
         tape.enc_layers["facts"] = []
 
-    # packed weight copies of the row-chain launches: refreshed here, on the main stream, before the side stream forks
-    pk = dec._chain_pack(fresh=fresh_pack) if dec.chain_supported() else None
+    # packed weight copies of the row-chain launches.  Inside the captured step they are refreshed in three launches
+    # placed where they cost nothing: the context encoders' copies now (the side chain needs them first), the decoder
+    # layers' after Encoder.conv1 has been enqueued, the transposed copies of the backward chains on the side stream
+    # once the context chain is done (it idles until the backward pass).
+    chain = dec.chain_supported()
+    staged = chain and fresh_pack and overlap
+    pk = dec._chain_pack(fresh=fresh_pack, subset=(lambda k: k[0] != "d") if staged else None) if chain else None
+    # the context chains run beside Encoder.conv1 and the image K/V projection: 8-wave workgroups find room there
+    slim_ctx = overlap and not os.environ.get("ICK_NO_SLIM")
 
     def entity_chain():
         ops.stamp("side: context chain starts")
         # the stack's last add & norm writes the entity rows of the memory buffer directly
         ctx_e = _context_encoder_fwd(dec, dec.transformer_encoder_entities, ee, tape.enc_layers["entities"], ds, pk=pk,
-                                     tag="e", out=mem[:, P:P + K])
+                                     tag="e", out=mem[:, P:P + K], slim=slim_ctx)
         ops.project_heads(ctx_e, wkv, bkv, nseg, H, S, out=kv, s0=P, grp=K)
         ops.stamp("side: context chain done")
+        if staged and dec.chain_bwd_supported():
+            m["pkb"] = dec._chain_pack(fresh=True, bwd=True)
 
     def fact_chain():
         ctx_f = _context_encoder_fwd(dec, dec.transformer_encoder_facts, fe, tape.enc_layers["facts"], ds, pk=pk,
-                                     tag="f", out=mem[:, P + K:])
+                                     tag="f", out=mem[:, P + K:], slim=slim_ctx)
         ops.project_heads(ctx_f, wkv, bkv, nseg, H, S, out=kv, s0=P + K, grp=Fn)
 
     side = ops.SideStream(priority=-1) if overlap else None
@@ -251,9 +260,9 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         mem[:, :P].copy_(img)
     if side is not None:
         side.flush()     # enqueued after the main stream's next kernel (see SideStream)
-    if pk is not None and dec.chain_bwd_supported():
-        # packed transposed weights of the backward chains: needed a millisecond from now, refreshed here where the
-        # main stream has slack (it waits for the context chain before the first cross-attention)
+    if staged:
+        dec._chain_pack(fresh=True, subset=lambda k: k[0] == "d")
+    elif pk is not None and dec.chain_bwd_supported():
         m["pkb"] = dec._chain_pack(fresh=fresh_pack, bwd=True)
     if dec.has_facts:
         # on the main stream, beside the entity chain on the side stream: two chains of small kernels overlap well

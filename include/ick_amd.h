@@ -130,11 +130,13 @@ typedef struct {
     float* o; int64_t o_rs;
     float* x; int64_t x_rs; int32_t x_grp; int64_t x_gs;
     float* mean; float* rstd;
-    const float* w2p; const float* b2; int32_t N2; int32_t flags;   /* flags: ICK_GEMM_RELU */
+    const float* w2p; const float* b2; int32_t N2; int32_t flags;   /* flags: ICK_GEMM_RELU, ICK_CHAIN_SLIM */
     float drop2_p; uint32_t drop2_site;
     float* y2; int64_t y2_rs; int32_t y2_grp; int64_t y2_gs;
     int32_t hs_dh, hs_dhp, hs_H, hs_S, hs_s0;
 } ick_rowchain_args;
+#define ICK_CHAIN_SLIM 256   /* 8-wave workgroups: for chains that run beside bulk GEMMs on another stream (they find
+                                room on a busy CU where the 16-wave form waits for the bulk kernel to drain) */
 int ick_rowchain_supported(int32_t K1, int32_t d, int32_t N2);
 int ick_rowchain_fwd(const ick_rowchain_args* args, void* stream);
 

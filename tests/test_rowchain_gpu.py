@@ -31,7 +31,8 @@ def _torch_ref(t, relu):
                                              (1280, 512, 300, 900, False), (1280, 512, 300, 0, False),
                                              (37, 300, 300, 512, True), (5, 384, 256, 768, False),
                                              (64, 64, 64, 64, False), (100, 300, 300, 1024, False)])
-def test_chain_matches_torch_and_unfused(M, K1, d, N2, relu):
+@pytest.mark.parametrize("slim", [False, True])
+def test_chain_matches_torch_and_unfused(M, K1, d, N2, relu, slim):
     from ick_amd import ops
     assert ops.rowchain_supported(K1, d, N2)
     t = _mk(M, K1, d, N2, 7)
@@ -41,7 +42,7 @@ def test_chain_matches_torch_and_unfused(M, K1, d, N2, relu):
     w1p = ops.pack_weight(t["w1"])
     w2p = ops.pack_weight(t["w2"]) if N2 else None
     mean, rstd = ops.rowchain_fwd(t["a"], w1p, t["b1"], t["res"], t["gamma"], t["beta"], 1e-5, x, o_out=o,
-                                  save_stats=True, w2p=w2p, b2=t["b2"], y2=y2, relu=relu)
+                                  save_stats=True, w2p=w2p, b2=t["b2"], y2=y2, relu=relu, slim=slim)
     ro, rx, ry = _torch_ref(t, relu)
     assert (o.double() - ro).abs().max() < 2e-5
     assert (x.double() - rx).abs().max() < 2e-5

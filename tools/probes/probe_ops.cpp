@@ -120,7 +120,7 @@ int main(int argc, char** argv) {
     float us = timeit([&] { ick_add_layernorm(A, B, bias, bias, C, 1280, 300, 1e-5f, 300, 300, 300, nullptr, nullptr, 0.f, 0, 0, nullptr, st); }, iters);
     printf("%-28s rows=1280               : %8.2f us\n", "add_layernorm", us);
     // row-resident chains (rowchain.hip): GEMM + add & norm (+ GEMM) in one launch
-    auto chain = [&](const char* name, int M, int K1, int N2, int hs) {
+    auto chain = [&](const char* name, int M, int K1, int N2, int hs, int slim = 0) {
         ick_rowchain_args a; memset(&a, 0, sizeof(a));
         a.A = A; a.a_rs = K1; a.M = M; a.K1 = K1; a.d = 300; a.w1p = B; a.b1 = bias; a.res = A + 4000000; a.res_rs = 300;
         a.gamma = bias; a.beta = bias; a.eps = 1e-5f; a.o = C; a.o_rs = 300; a.x = C + 1000000; a.x_rs = 300;
@@ -129,6 +129,7 @@ int main(int argc, char** argv) {
             a.w2p = B + 1000000; a.b2 = bias; a.N2 = N2; a.y2 = C + 2000000; a.y2_rs = N2;
             if (hs) { a.hs_dh = 30; a.hs_dhp = 32; a.hs_H = 10; a.hs_S = hs; a.y2_grp = hs; a.y2_gs = (int64_t)(N2 / 300) * 10 * hs * 32; }
         }
+        if (slim) a.flags |= ICK_CHAIN_SLIM;
         int rc = ick_rowchain_fwd(&a, st);
         if (rc) { printf("%s rc=%d\n", name, rc); return; }
         float t = timeit([&] { ick_rowchain_fwd(&a, st); }, iters);
@@ -140,6 +141,9 @@ int main(int argc, char** argv) {
     chain("chain out+LN+ffn1", 1280, 300, 512, 0);
     chain("chain ffn2+LN+in_proj", 1280, 512, 900, 20);
     chain("chain out+LN+q B=16", 320, 300, 300, 20);
+    chain("chain out+LN+ffn1 slim", 1280, 300, 512, 0, 1);
+    chain("chain ffn2+LN+in_proj slim", 1280, 512, 900, 20, 1);
+    chain("chain ffn2+LN slim", 1280, 512, 0, 0, 1);
     // backward probes
     float *mean = bias + 4096, *rstd = bias + 8192;
     us = timeit([&] { ick_layernorm_bwd(A, B, C, bias, mean, rstd, C + 4000000, bias + 1024, bias + 2048, 1280, 300, nullptr, 0.f, 0, 0, nullptr, nullptr, st); }, iters);
