@@ -260,6 +260,8 @@ def main():
     by_kernel = []
     if not args.no_profile:
         dec.use_hip_graphs = False
+        os.environ["ICK_GROUP_SAME_STREAM"] = "1"     # the captured step's launches (grouped weight gradients, staged
+                                                       # packs, 8-wave context chains), one stream
         pstep = make_step(use_graph=False)
         pstep()
         fence()
@@ -270,6 +272,7 @@ def main():
         if rank == 0:
             by_kernel = prof.summarise(prof.stop(), args.profile_steps)
         fence()
+        os.environ.pop("ICK_GROUP_SAME_STREAM", None)
         dec.use_hip_graphs = True
 
     if rank == 0:

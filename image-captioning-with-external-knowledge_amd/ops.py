@@ -2,6 +2,7 @@
 device memory + stream plumbing; all arithmetic happens in libick_amd.so."""
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -661,7 +662,10 @@ class SideStream:
     def __init__(self, priority=0):
         # priority -1: the chain of small kernels on the side stream competes with a large GEMM on the main stream
         # for workgroup slots; a high-priority queue gets its workgroups dispatched first
-        self.stream = torch.cuda.Stream(priority=priority)
+        # ICK_GROUP_SAME_STREAM=1 (bench.py's per-kernel pass): same grouping and launch order as the captured step, but
+        # everything on the caller's stream, so that HIP events around a launch time that launch alone
+        self.stream = torch.cuda.current_stream() if os.environ.get("ICK_GROUP_SAME_STREAM") else \
+            torch.cuda.Stream(priority=priority)
         self.pending = False
         self.keep = []   # tensors the side stream reads stay referenced until the pass ends, so the caching
                          # allocator cannot hand their memory to the main stream meanwhile (also under capture)

@@ -792,7 +792,7 @@ class TrainStep:
         decode_len = (lengths.reshape(-1) - 1).to(torch.int32)
         scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, gmap=gmap,
                                          seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
-                                         overlap=self.use_graph and not os.environ.get("ICK_NO_FWD_OVERLAP"), **self._enc_kwargs(enc_in))
+                                         overlap=(self.use_graph or bool(os.environ.get("ICK_GROUP_SAME_STREAM"))) and not os.environ.get("ICK_NO_FWD_OVERLAP"), **self._enc_kwargs(enc_in))
         ops.stamp("fwd: scores done")
         # the two scalars of the loss go straight into the tail of the gradient bucket (it was zeroed above; nothing else
         # touches those two floats)
@@ -800,7 +800,7 @@ class TrainStep:
                                       out_sum=self.flat_g[self.n:self.n + 1], out_count=self.flat_g[self.n + 1:])
         ops.stamp("CE done")
         backward_from_tape(dec, tape, dscores, self.grads,
-                           overlap=self.use_graph and not os.environ.get("ICK_NO_BWD_OVERLAP"))
+                           overlap=(self.use_graph or bool(os.environ.get("ICK_GROUP_SAME_STREAM"))) and not os.environ.get("ICK_NO_BWD_OVERLAP"))
         ops.stamp("A: end (after join)")
         return self.flat_g
 
@@ -811,11 +811,11 @@ class TrainStep:
         decode_len = (lengths.reshape(-1) - 1).to(torch.int32)
         scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, gmap=gmap,
                                          seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
-                                         overlap=self.use_graph and not os.environ.get("ICK_NO_FWD_OVERLAP"), **self._enc_kwargs(enc_in))
+                                         overlap=(self.use_graph or bool(os.environ.get("ICK_GROUP_SAME_STREAM"))) and not os.environ.get("ICK_NO_FWD_OVERLAP"), **self._enc_kwargs(enc_in))
         self._loss = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True,
                                    out_sum=self.flat_g[self.n:self.n + 1], out_count=self.flat_g[self.n + 1:])
         self._bp = BackwardPass(dec, tape, self._loss[2], self.grads,
-                                overlap=self.use_graph and not os.environ.get("ICK_NO_BWD_OVERLAP"))
+                                overlap=(self.use_graph or bool(os.environ.get("ICK_GROUP_SAME_STREAM"))) and not os.environ.get("ICK_NO_BWD_OVERLAP"))
         self._bp.early(join=True)
         return self.flat_g
 
