@@ -194,10 +194,25 @@ __device__ __forceinline__ void read_frag(const float* lds, int row0, int t, int
     }
 }
 
+// Split-K problems whose K split count is a multiple of 8 (the weight gradients: small outputs, long reductions):
+// workgroups are dispatched round robin over the 8 XCDs in linear order, so XCD x is given the whole tile grid of the K
+// splits x, x + 8, ...: every XCD then streams only its own K range of both operands and the re-reads by the other
+// tiles of the grid hit its L2 (PMC, tools/pmc_traffic.sh: the cross-K/V weight gradient moved 215-300 MB per launch
+// for ~60 MB of operands with the tile-major order).  Returns false (nothing changed) for other split counts.
+__device__ __forceinline__ bool split_major(int& bid, int& zid, int nt, int nsplit) {
+    if (nsplit < 8 || (nsplit & 7) != 0) return false;
+    const int lin = bid + nt * zid;
+    const int x = lin & 7, j = lin >> 3;
+    const int r = j / nt;
+    zid = x + 8 * r;
+    bid = j - r * nt;
+    return true;
+}
+
 // One output tile: workgroup `bid` of the tiles_m x tiles_n grid of problem p, K slice `zid`.
 template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT>
 __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, int tiles_n, int kchunk, int bid,
-                                          int zid, float* smem) {
+                                          int zid, float* smem, bool xcd_remap = true) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     constexpr int BK = BKT;
     using SA = Stager<BM, AKM, VEC, BKT, WM * WN * 64>;
@@ -206,7 +221,7 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
 
     // XCD-aware tile order (blocks b, b+8, ... share an XCD).
     const int nwg = tiles_m * tiles_n;
-    {
+    if (xcd_remap) {
         const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
         bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
     }
@@ -355,7 +370,9 @@ template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(ick_gemm_args p, int tiles_m, int tiles_n, int kchunk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if constexpr (TM == 1) chain_priority();     // 32 x 32 tiles: the chain GEMMs (single launches, not the grouped weight gradients)
-    gemm_tile<WM, WN, TM, TN, AKM, BKM, VEC, BKT>(p, tiles_m, tiles_n, kchunk, blockIdx.x, blockIdx.z, smem);
+    int bid = blockIdx.x, zid = blockIdx.z;
+    const bool by_split = split_major(bid, zid, gridDim.x, gridDim.z);
+    gemm_tile<WM, WN, TM, TN, AKM, BKM, VEC, BKT>(p, tiles_m, tiles_n, kchunk, bid, zid, smem, !by_split);
 }
 
 // Several independent problems of the same kernel configuration in one launch (the weight-gradient GEMMs of a
@@ -363,8 +380,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(ick_gemm_args p, int
 constexpr int kGroupMax = 8;
 struct GroupArgs {
     int count;
-    int wg_end[kGroupMax];      // exclusive prefix sums of workgroups (tiles * K splits)
-    int tiles_m[kGroupMax], tiles_n[kGroupMax], kchunk[kGroupMax];
+    int wg_end[kGroupMax];      // exclusive prefix sums of workgroups (tiles * K splits, each rounded up to 8 so that a
+                                // problem's first workgroup lands on XCD 0: the XCD-aware orders assume that)
+    int tiles_m[kGroupMax], tiles_n[kGroupMax], kchunk[kGroupMax], split[kGroupMax];
     ick_gemm_args g[kGroupMax];
 };
 
@@ -375,8 +393,11 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GroupArgs ga) {
     while (gi + 1 < ga.count && (int)blockIdx.x >= ga.wg_end[gi]) ++gi;
     const int local = blockIdx.x - (gi > 0 ? ga.wg_end[gi - 1] : 0);
     const int nt = ga.tiles_m[gi] * ga.tiles_n[gi];
-    gemm_tile<WM, WN, TM, TN, AKM, BKM, VEC, BKT>(ga.g[gi], ga.tiles_m[gi], ga.tiles_n[gi], ga.kchunk[gi], local % nt,
-                                                  local / nt, smem);
+    if (local >= nt * ga.split[gi]) return;      // padding
+    int zid = local / nt, bid = local - zid * nt;
+    const bool by_split = split_major(bid, zid, nt, ga.split[gi]);
+    gemm_tile<WM, WN, TM, TN, AKM, BKM, VEC, BKT>(ga.g[gi], ga.tiles_m[gi], ga.tiles_n[gi], ga.kchunk[gi], bid, zid, smem,
+                                                  !by_split);
 }
 
 // Host-side plan of one problem: validated arguments + kernel configuration.
@@ -434,12 +455,15 @@ int launch_group(const Plan* const* pls, int n, hipStream_t s) {
     ga.count = n;
     int total = 0;
     for (int i = 0; i < n; ++i) {
-        total += pls[i]->tiles_m * pls[i]->tiles_n * pls[i]->split;
+        total += (pls[i]->tiles_m * pls[i]->tiles_n * pls[i]->split + 7) & ~7;
         ga.wg_end[i] = total;
         ga.tiles_m[i] = pls[i]->tiles_m; ga.tiles_n[i] = pls[i]->tiles_n; ga.kchunk[i] = pls[i]->kchunk;
+        ga.split[i] = pls[i]->split;
         ga.g[i] = pls[i]->a;
     }
-    for (int i = n; i < kGroupMax; ++i) { ga.wg_end[i] = total; ga.tiles_m[i] = ga.tiles_n[i] = 1; ga.kchunk[i] = 32; ga.g[i] = pls[0]->a; }
+    for (int i = n; i < kGroupMax; ++i) {
+        ga.wg_end[i] = total; ga.tiles_m[i] = ga.tiles_n[i] = 1; ga.kchunk[i] = 32; ga.split[i] = 0; ga.g[i] = pls[0]->a;
+    }
     const size_t lds = (TM > 1) ? std::max(smem, lds_floor(1)) : smem;
     hipLaunchKernelGGL((gemm_group_kernel<2, 2, TM, TN, AKM, BKM, true, 32>), dim3(total), dim3(256), lds, s, ga);
     ICK_LAUNCH_RET();
