@@ -365,9 +365,16 @@ def _context_encoder_bwd(dec, stack, tapes, dx, grads, pkb=None, tag="e"):
             _lin_bwd(grads, dpre, t["x1"].view(M, d), layer.linear1.weight, layer.linear1.bias, need_dx=False)
             _lin_bwd(grads, n1["do"], t["sa"].view(M, d), layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias,
                      need_dx=False)
+            if ops.SIDE is not None:
+                # everything queued so far only needs the chain launch above: it goes out now, beside the attention
+                # backward (the in_proj weight gradient follows with the next group) -- the side stream's last group,
+                # which nothing on the main stream overlaps any more, shrinks to one problem
+                ops.SIDE.flush_group()
             dqkv = ops.attention_bwd_buffer((B, T, 3 * d), T, T, d // H, dev)
             ops.attention_heads_bwd(t["qkv"], t["qkv"], t["sa"], dsa.view(B, T, d), t["lse"], dqkv[:, :, :d],
                                     dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:], H, d // H, T, T, 0, 1, 2, drop=t["d_att"])
+            if ops.SIDE is not None:
+                ops.SIDE.flush()
             if li > 0:
                 # the in_proj data gradient rides on the next launch (the layer below); only its weight gradient here
                 _lin_bwd(grads, dqkv.view(M, 3 * d), t["x"].view(M, d), layer.self_attn.in_proj_weight,
@@ -376,8 +383,8 @@ def _context_encoder_bwd(dec, stack, tapes, dx, grads, pkb=None, tag="e"):
             else:
                 dx = _lin_bwd(grads, dqkv.view(M, 3 * d), t["x"].view(M, d), layer.self_attn.in_proj_weight,
                               layer.self_attn.in_proj_bias, dx=dz_out, acc=True).view(B, T, d)
-            if ops.SIDE is not None:
-                ops.SIDE.flush_group()      # this layer's weight gradients: one grouped launch
+                if ops.SIDE is not None:
+                    ops.SIDE.flush_group()
         return dx
     for layer, t in zip(reversed(layers), reversed(tapes)):
         B, T, _ = t["x"].shape
