@@ -109,9 +109,10 @@ def _context_encoder_fwd(dec, stack, x, tape_list, ds, pk=None, tag="e", out=Non
     return x
 
 
-def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds, side=None, pk=None, qkv=None):
-    """Returns (x, qkv of the next layer or None).  pk: packed weights -> row-chain launches (see above); then the
-    in_proj of layer li + 1 rides on this layer's linear2 + norm3 launch."""
+def _decoder_self_block(dec, li, layer, x, ds, pk=None, qkv=None):
+    """Self-attention block of decoder layer li up to the cross-attention query: in_proj (unless qkv came with the
+    previous layer's last launch), causal attention, out-projection + norm1 + q-projection.  Nothing here reads the
+    memory, so layer 0's block can run beside Encoder.conv1 / the K/V projection.  Returns the layer's tape dict."""
     H, d = dec.num_heads, dec.emb_dim
     dh = d // H
     B, T, _ = x.shape
@@ -125,17 +126,39 @@ def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds, side=None, pk=No
     ops.attention_heads(t["qkv"], t["qkv"], t["sa"], H, dh, T, T, 0, 1, 2, causal=True, lse=t["lse_s"],
                         drop=t["d_sa"])
     ca_w, ca_b = _p(layer.multihead_attn.in_proj_weight), _p(layer.multihead_attn.in_proj_bias)
-    t["ca"] = torch.empty_like(x)
-    t["lse_c"] = torch.empty(B * H * T, device=x.device, dtype=torch.float32)
     if pk is not None:
-        for k in ("o1", "x1", "o2", "x2", "o3"):
+        for k in ("o1", "x1"):
             t[k] = torch.empty_like(x)
         t["qc"] = torch.empty(B, 1, H, T, ops.DHP, device=x.device, dtype=torch.float32)
         t["m1"], t["r1"] = ops.rowchain_fwd(
             t["sa"], pk[("d", li, "so")], _p(layer.self_attn.out_proj.bias), x, _p(layer.norm1.weight),
             _p(layer.norm1.bias), layer.norm1.eps, t["x1"], drop1=t["d1"], o_out=t["o1"], save_stats=True,
             w2p=pk[("d", li, "cq")], b2=ca_b[:d], y2=t["qc"], heads=(1, H, T, 0, T))
+    else:
+        t["o1"] = ops.linear(t["sa"], _p(layer.self_attn.out_proj.weight), _p(layer.self_attn.out_proj.bias))
+        t["x1"], t["m1"], t["r1"] = ops.add_layernorm(t["o1"], x, _p(layer.norm1.weight), _p(layer.norm1.bias),
+                                                      layer.norm1.eps, save_stats=True, drop=t["d1"])
+        t["qc"] = ops.project_heads(t["x1"], ca_w[:d], ca_b[:d], 1, H, T)
+    return t
+
+
+def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds, side=None, pk=None, qkv=None, t=None, early=None):
+    """Returns (x, qkv of the next layer or None).  pk: packed weights -> row-chain launches (see above); then the
+    in_proj of layer li + 1 rides on this layer's linear2 + norm3 launch.  t: the tape dict of a self-attention block
+    that already ran (on the stream `early`, joined here)."""
+    H, d = dec.num_heads, dec.emb_dim
+    dh = d // H
+    B, T, _ = x.shape
+    if t is None:
+        t = _decoder_self_block(dec, li, layer, x, ds, pk, qkv)
+    t["ca"] = torch.empty_like(x)
+    t["lse_c"] = torch.empty(B * H * T, device=x.device, dtype=torch.float32)
+    if pk is not None:
+        for k in ("o2", "x2", "o3"):
+            t[k] = torch.empty_like(x)
         ops.stamp("fwd: layer %d reaches cross-attention" % li)
+        if early is not None:
+            early.join()
         if side is not None:
             side.join()    # the context rows of kv (and of the saved memory) come from the side stream
         ops.attention_heads(t["qc"], kv, t["ca"], H, dh, T, S, 0, 2 * li, 2 * li + 1, lse=t["lse_c"], drop=t["d_ca"])
@@ -156,11 +179,9 @@ def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds, side=None, pk=No
             heads=None if nxt is None else (3, H, T, 0, T))
         tape_list.append(t)
         return x3, qkv_n
-    t["o1"] = ops.linear(t["sa"], _p(layer.self_attn.out_proj.weight), _p(layer.self_attn.out_proj.bias))
-    t["x1"], t["m1"], t["r1"] = ops.add_layernorm(t["o1"], x, _p(layer.norm1.weight), _p(layer.norm1.bias),
-                                                  layer.norm1.eps, save_stats=True, drop=t["d1"])
-    t["qc"] = ops.project_heads(t["x1"], ca_w[:d], ca_b[:d], 1, H, T)
     ops.stamp("fwd: layer %d reaches cross-attention" % li)
+    if early is not None:
+        early.join()
     if side is not None:
         side.join()    # the context rows of kv (and of the saved memory) come from the side stream
     ops.attention_heads(t["qc"], kv, t["ca"], H, dh, T, S, 0, 2 * li, 2 * li + 1, lse=t["lse_c"], drop=t["d_ca"])
@@ -223,7 +244,8 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     # once the context chain is done (it idles until the backward pass).
     chain = dec.chain_supported()
     staged = chain and fresh_pack and overlap
-    pk = dec._chain_pack(fresh=fresh_pack, subset=(lambda k: k[0] != "d") if staged else None) if chain else None
+    first = lambda k: k[0] != "d" or (k[1] == 0 and k[2] in ("so", "cq"))     # context encoders + layer 0's self block
+    pk = dec._chain_pack(fresh=fresh_pack, subset=first if staged else None) if chain else None
     # the context chains run beside Encoder.conv1 and the image K/V projection: 8-wave workgroups find room there
     slim_ctx = overlap and not os.environ.get("ICK_NO_SLIM")
 
@@ -243,6 +265,23 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         ops.project_heads(ctx_f, wkv, bkv, nseg, H, S, out=kv, s0=P + K, grp=Fn)
 
     side = ops.SideStream(priority=-1) if overlap else None
+    # Decoder layer 0's self-attention block (caption embedding, in_proj, causal attention, out-projection + norm1 +
+    # q-projection) reads neither the image nor the context rows, so a third branch could run it beside Encoder.conv1.
+    # Measured and left off (ICK_EARLY_SELF=1 turns it on): with three concurrent branches in the captured graph every
+    # kernel of the step runs ~2x slower on ROCm 7.2 (train step 2.03 -> 3.65 ms).
+    early = ops.SideStream(priority=-1) if (overlap and os.environ.get("ICK_EARLY_SELF")) else None
+    pe = dec.pos_encoder.pe.view(-1, d)
+    head0 = {}
+
+    def layer0_self_block():
+        m["d_pos"] = ds.site(dec.pos_encoder.dropout.p)
+        x0 = ops.caption_embed(captions, caption_masks, _p(dec.word_embedding.weight), ee, fe, pe, V,
+                               dec.word_map["<pad>"], math.sqrt(d), drop=m["d_pos"])
+        head0["x"] = x0
+        head0["t"] = _decoder_self_block(dec, 0, dec.transformer_decoder.layers[0], x0, ds, pk, None)
+
+    if early is not None:
+        early.submit(layer0_self_block, ee, fe, captions, caption_masks)
     if feats is not None:
         img = mem[:, :P]
     else:
@@ -260,8 +299,10 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         mem[:, :P].copy_(img)
     if side is not None:
         side.flush()     # enqueued after the main stream's next kernel (see SideStream)
+    if early is not None:
+        early.flush()
     if staged:
-        dec._chain_pack(fresh=True, subset=lambda k: k[0] == "d")
+        dec._chain_pack(fresh=True, subset=lambda k: not first(k))
     elif pk is not None and dec.chain_bwd_supported():
         m["pkb"] = dec._chain_pack(fresh=fresh_pack, bwd=True)
     if dec.has_facts:
@@ -273,14 +314,14 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     # a 5000-workgroup GEMM beside a chain of small kernels delays the chain by about its own duration either way.
     ops.project_heads(img, wkv, bkv, nseg, H, S, out=kv, s0=0, grp=P)
     ops.stamp("fwd: image K/V projection done")
-    pe = dec.pos_encoder.pe.view(-1, d)
-    m["d_pos"] = ds.site(dec.pos_encoder.dropout.p)
-    x = ops.caption_embed(captions, caption_masks, _p(dec.word_embedding.weight), ee, fe, pe, V,
-                          dec.word_map["<pad>"], math.sqrt(d), drop=m["d_pos"])
+    if early is None:
+        layer0_self_block()
+    x = head0["x"]
     qkv = None
     for li, layer in enumerate(dec.transformer_decoder.layers):
         x, qkv = _decoder_layer_fwd(dec, li, layer, x, kv, S, tape.dec_layers, ds, side=side if li == 0 else None,
-                                    pk=pk, qkv=qkv)
+                                    pk=pk, qkv=qkv, t=head0["t"] if li == 0 else None,
+                                    early=early if li == 0 else None)
     if side is not None:
         side.join()
     ops.stamp("fwd: decoder layers done")
