@@ -20,7 +20,8 @@ namespace {
 
 using namespace rowchain;
 
-constexpr int kMaxK0 = 960;                 // widest pre-GEMM input (in_proj gradient: 3 d)
+constexpr int kMaxK0 = 1920;                // widest pre-GEMM input (in_proj gradient: 3 d; all-layer cross K/V gradient:
+                                            // 2 * layers * d = 1800)
 constexpr int kLdA = kMaxK0 + 4;            // LDS row stride of the wide input buffer
 constexpr int kLdB = kMaxD + 4;             // ... of the d-wide buffers
 constexpr int kMaxN1 = 512;                 // dim_feedforward
@@ -123,7 +124,9 @@ __global__ __launch_bounds__(kThreads) void rowchain_bwd_kernel(ick_rowchain_bwd
         const int K0 = p.K0, K0p = (K0 + 15) & ~15;
         const int r = wave & (kRows - 1), half = wave >> 3;
         const int gr = row0 + r;
-        const float* grow = p.g0 + (int64_t)gr * p.g0_rs;
+        int64_t goff = (int64_t)gr * p.g0_rs;
+        if (p.g0_grp > 0) { const int g = small_div(gr, p.g0_grp); goff = (int64_t)g * p.g0_gs + (int64_t)(gr - g * p.g0_grp) * p.g0_rs; }
+        const float* grow = p.g0 + goff;
         for (int k = lane + 64 * half; k < K0p; k += 128) XA[r * kLdA + k] = (gr < M && k < K0) ? grow[k] : 0.f;
         __syncthreads();
         const Slab w = slab_of(g0p);

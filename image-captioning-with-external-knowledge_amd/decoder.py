@@ -377,12 +377,14 @@ class DecoderTransformer(nn.Module):
             items.append(((key[0], key[1], key[2] + "T"), w.t()))
         return items
 
-    def _chain_pack(self, fresh=False, bwd=False, subset=None):
+    def _chain_pack(self, fresh=False, bwd=False, subset=None, extra=None):
         """Packed copies (ops.pack_weights) of the weights the row-chain launches read, as {key: tensor} views of one
         persistent buffer (bwd: of the transposed weights, for the data-gradient chains).  Refreshed when a parameter's
         version changed, or on every call with fresh=True (inside the captured training step, where the fused Adam
         updates the weights behind torch's version counters); then `subset` (a predicate on the item key) limits the
-        launch to the copies the caller needs first -- the rest follows in a later call."""
+        launch to the copies the caller needs first -- the rest follows in a later call.  extra: (key, 2-D view) of
+        per-call tensors packed in the same launch into persistent buffers of their own (the transposed all-layer cross
+        K/V weight of the backward pass); their copies are returned under `key`."""
         items = self._chain_items_bwd() if bwd else self._chain_items()
         name = "_chain_cache_bwd" if bwd else "_chain_cache"
         cache = self.__dict__.get(name)
@@ -396,11 +398,24 @@ class DecoderTransformer(nn.Module):
                 off += n
             cache = {"ptr": items[0][1].data_ptr(), "buf": buf, "views": views, "key": None}
             self.__dict__[name] = cache
+        more = []
+        for k, w in (extra or []):
+            n = ops.packed_weight_floats(w.shape[0], w.shape[1])
+            buf = cache.setdefault("extra", {}).get(k)
+            if buf is None or buf.numel() != n or buf.device != w.device:
+                buf = cache["extra"][k] = torch.empty(n, device=w.device, dtype=torch.float32)
+            more.append((w.detach(), buf))
         if fresh and subset is not None:
-            ops.pack_weights([(w.detach(), cache["views"][k]) for k, w in items if subset(k)])
+            ops.pack_weights([(w.detach(), cache["views"][k]) for k, w in items if subset(k)] + more)
         elif fresh or cache["key"] != key:
-            ops.pack_weights([(w.detach(), cache["views"][k]) for k, w in items])
+            ops.pack_weights([(w.detach(), cache["views"][k]) for k, w in items] + more)
             cache["key"] = key
+        elif more:
+            ops.pack_weights(more)
+        if extra:
+            views = dict(cache["views"])
+            views.update({k: cache["extra"][k] for k, _ in extra})
+            return views
         return cache["views"]
 
     def chain_bwd_supported(self):
@@ -410,7 +425,7 @@ class DecoderTransformer(nn.Module):
             ff = max(l.linear1.out_features for st in (self.transformer_decoder, self.transformer_encoder_entities)
                      for l in st.layers)
             cached = self.chain_supported() and not os.environ.get("ICK_NO_ROWCHAIN_BWD") and \
-                ops.rowchain_bwd_supported(3 * d, d, ff)
+                ops.rowchain_bwd_supported(max(3, 2 * len(self.transformer_decoder.layers)) * d, d, ff)
             self.__dict__["_chain_bwd_ok"] = cached
         return cached
 

@@ -55,7 +55,7 @@ class RowChainArgs(C.Structure):
 class RowChainBwdArgs(C.Structure):
     _fields_ = [
         ("M", i32), ("d", i32), ("drop_seed", u32), ("drop_epoch", vp),
-        ("g0", vp), ("g0_rs", i64), ("K0", i32), ("w0p", vp),
+        ("g0", vp), ("g0_rs", i64), ("K0", i32), ("w0p", vp), ("g0_grp", i32), ("g0_gs", i64),
         ("dzin", vp), ("dzin_rs", i64),
         ("o1", vp), ("res1", vp), ("mean1", vp), ("rstd1", vp), ("gamma1", vp),
         ("drop1_p", f32), ("drop1_site", u32),

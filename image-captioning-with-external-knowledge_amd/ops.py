@@ -288,9 +288,15 @@ def rowchain_bwd(M, d, norm1, w3p, out3, dz_out, g0=None, w0p=None, dzin=None, f
 
     norm("1", norm1)
     if g0 is not None:
-        g2 = g0.reshape(M, -1)
-        assert g2.stride(1) == 1
-        a.g0, a.g0_rs, a.K0, a.w0p = _p(g2), g2.stride(0), g2.shape[1], _p(w0p)
+        if g0.dim() == 3 and not g0.is_contiguous():
+            # rows of a (B, T, K0) view with a sample stride (the context rows of the cross K/V gradient buffer)
+            assert g0.stride(2) == 1 and g0.shape[0] * g0.shape[1] == M
+            a.g0, a.g0_rs, a.K0, a.w0p = _p(g0), g0.stride(1), g0.shape[2], _p(w0p)
+            a.g0_grp, a.g0_gs = g0.shape[1], g0.stride(0)
+        else:
+            g2 = g0.reshape(M, -1)
+            assert g2.stride(1) == 1
+            a.g0, a.g0_rs, a.K0, a.w0p = _p(g2), g2.stride(0), g2.shape[1], _p(w0p)
     if dzin is not None:
         z2 = dzin.reshape(M, d)
         a.dzin, a.dzin_rs = _p(z2), z2.stride(0)

@@ -257,7 +257,7 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         ops.project_heads(ctx_e, wkv, bkv, nseg, H, S, out=kv, s0=P, grp=K)
         ops.stamp("side: context chain done")
         if staged and dec.chain_bwd_supported():
-            m["pkb"] = dec._chain_pack(fresh=True, bwd=True)
+            m["pkb"] = dec._chain_pack(fresh=True, bwd=True, extra=[(("kv", "T"), wkv.t())])
 
     def fact_chain():
         ctx_f = _context_encoder_fwd(dec, dec.transformer_encoder_facts, fe, tape.enc_layers["facts"], ds, pk=pk,
@@ -304,7 +304,7 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     if staged:
         dec._chain_pack(fresh=True, subset=lambda k: not first(k))
     elif pk is not None and dec.chain_bwd_supported():
-        m["pkb"] = dec._chain_pack(fresh=fresh_pack, bwd=True)
+        m["pkb"] = dec._chain_pack(fresh=fresh_pack, bwd=True, extra=[(("kv", "T"), wkv.t())])
     if dec.has_facts:
         # on the main stream, beside the entity chain on the side stream: two chains of small kernels overlap well
         # (a chain beside the large projection below does not)
@@ -377,15 +377,17 @@ def _norm_args(t, i, res, layer_norm, grads, M, d, dev):
                 part=ops.ln_partials(M, d, dev))
 
 
-def _context_encoder_bwd(dec, stack, tapes, dx, grads, pkb=None, tag="e"):
+def _context_encoder_bwd(dec, stack, tapes, dx, grads, pkb=None, tag="e", g_first=None):
     """pkb: packed transposed weights (dec._chain_pack(bwd=True)) -> one ops.rowchain_bwd launch per layer for
     [in_proj data gradient of the layer above] + norm2' + linear2' + ReLU' + linear1' + norm1' + out_proj' instead
-    of six kernels."""
+    of six kernels.  g_first = (g0 rows view, packed W0^T): the incoming gradient is g0 @ W0 (no dx tensor)."""
     H, d = dec.num_heads, dec.emb_dim
     layers = list(stack.layers)
     if pkb is not None:
-        dev = dx.device
+        dev = tapes[0]["x"].device
         dz, g0, w0p = dx, None, None
+        if g_first is not None:
+            dz, (g0, w0p) = None, g_first
         for li in reversed(range(len(layers))):
             layer, t = layers[li], tapes[li]
             B, T, _ = t["x"].shape
@@ -691,25 +693,32 @@ def _backward_phases(dec, tape, dscores, grads, want_image_grad=False):
     # ---- cross K/V projection: the weight gradients went out with the decoder layers; data gradient for the
     # context rows only (the image rows' gradient would be Encoder.conv1's, which the reference never uses)
     nctx = K + Fn
-    # K = 2 * layers * d = 1800 over only B * nctx x d outputs: split the reduction (40 -> ~15 us with the fill)
-    ksplit = max(1, min(8, (nseg * d) // 450)) if B * nctx * d <= 1280 * 512 else 1
-    dctx = (torch.zeros if ksplit > 1 else torch.empty)(B, nctx, d, device=dev, dtype=torch.float32)
-    ops.gemm_raw(dkv_rows[:, P:], m["wkv"], dctx, B * nctx, d, nseg * d, nseg * d, 1, 1, d, d, a_grp=nctx,
-                 a_gs=S * nseg * d, atomic=ksplit > 1, split_k=ksplit)
+    dkv_ctx = dkv_rows[:, P:]                       # (B, nctx, 2 * layers * d) view of the K/V gradient rows
+    fuse_ctx = pkb is not None and ops.rowchain_bwd_supported(nseg * d, d, 0) and not os.environ.get("ICK_NO_CTX_FUSE")
+    dctx = None
+    if not fuse_ctx:
+        # K = 2 * layers * d = 1800 over only B * nctx x d outputs: split the reduction (40 -> ~15 us with the fill)
+        ksplit = max(1, min(8, (nseg * d) // 450)) if B * nctx * d <= 1280 * 512 else 1
+        dctx = (torch.zeros if ksplit > 1 else torch.empty)(B, nctx, d, device=dev, dtype=torch.float32)
+        ops.gemm_raw(dkv_ctx, m["wkv"], dctx, B * nctx, d, nseg * d, nseg * d, 1, 1, d, d, a_grp=nctx,
+                     a_gs=S * nseg * d, atomic=ksplit > 1, split_k=ksplit)
     if want_image_grad:
         # image rows: d mem[:, :P] = dK/dV rows @ packed K/V weight (the data gradient of the all-layer projection)
         d_img = torch.empty(B, P, d, device=dev, dtype=torch.float32)
         ops.gemm_raw(dkv_rows, m["wkv"], d_img, B * P, d, nseg * d, nseg * d, 1, 1, d, d, a_grp=P, a_gs=S * nseg * d)
         m["d_img"] = d_img
-    # ---- context encoders
+    # ---- context encoders.  With the row chains the data gradient of the K/V projection for the context rows rides on
+    # the first launch of each context encoder's backward (its rows are read straight out of the K/V gradient buffer)
     ops.stamp("bwd: context gradient ready")
     dee_enc = _context_encoder_bwd(dec, dec.transformer_encoder_entities, tape.enc_layers["entities"],
-                                   dctx[:, :K].contiguous(), grads, pkb=pkb, tag="e")
+                                   None if fuse_ctx else dctx[:, :K].contiguous(), grads, pkb=pkb, tag="e",
+                                   g_first=(dkv_ctx[:, :K], pkb[("kv", "T")]) if fuse_ctx else None)
     ops.stamp("bwd: entity context encoder done")
     dee += dee_enc
     if dec.has_facts:
         dfe_enc = _context_encoder_bwd(dec, dec.transformer_encoder_facts, tape.enc_layers["facts"],
-                                       dctx[:, K:].contiguous(), grads, pkb=pkb, tag="f")
+                                       None if fuse_ctx else dctx[:, K:].contiguous(), grads, pkb=pkb, tag="f",
+                                       g_first=(dkv_ctx[:, K:], pkb[("kv", "T")]) if fuse_ctx else None)
         dfe += dfe_enc
     # ---- caption embedding, fact encoder, entity encoder
     gword = _g(grads, dec.word_embedding.weight)

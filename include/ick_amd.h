@@ -156,11 +156,12 @@ int ick_rowchain_fwd(const ick_rowchain_args* args, void* stream);
  * o / res / mean / rstd / gamma are the saved forward tensors of the norms (as for ick_layernorm_bwd); part1 / part2
  * receive the per-workgroup gamma / beta partial sums, ceil(M / 8) x 2d floats each (ick_layernorm_bwd's layout, 8 rows
  * per workgroup).  All row-major with dense rows (d, N1) except g0 / dzin (g0_rs, dzin_rs).
- * Limits: K0 <= 960, d <= 320, N1 <= 512. */
+ * Limits: K0 <= 1920, d <= 320, N1 <= 512. */
 typedef struct {
     int32_t M, d;
     uint32_t drop_seed; const uint32_t* drop_epoch;
     const float* g0; int64_t g0_rs; int32_t K0; const float* w0p;
+    int32_t g0_grp; int64_t g0_gs;     /* g0_grp > 0: row r of g0 at g0 + (r / g0_grp) * g0_gs + (r % g0_grp) * g0_rs */
     const float* dzin; int64_t dzin_rs;
     const float* o1; const float* res1; const float* mean1; const float* rstd1; const float* gamma1;
     float drop1_p; uint32_t drop1_site;

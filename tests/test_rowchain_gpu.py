@@ -164,3 +164,49 @@ def test_backward_chain_matches_reference(M, ffn, pre, p):
         last_do, last_dz = do2, dz2
     assert (dz_out.double() - last_dz).abs().max() < 2 * tol
     assert (out3.double() - last_do @ w3.double()).abs().max() < 2 * tol
+
+
+@pytest.mark.parametrize("d,H,FF,NL,variant", [(300, 10, 512, 3, "geo"), (256, 8, 384, 2, "geo"), (300, 10, 512, 2, "knowledge")])
+def test_model_scores_and_gradients_with_and_without_chains(d, H, FF, NL, variant):
+    """The row chains (forward and backward) against the separate GEMM / add & norm / LayerNorm-backward kernels they
+    replace, through the whole drop-in module (autograd bridge, dropout off): scores and every parameter gradient."""
+    import ick_amd
+    import ick_amd.synth as synth
+    from torch.nn.utils.rnn import pack_padded_sequence
+    B, L, K, V, Fn, seed = 5, 9, 6, 150, 7, 21
+    P = synth.make_params(variant, V, seed, d=d, decoder_dim=FF, encoder_dim=320, num_layers=NL)
+    wm = synth.make_word_map(V)
+    m = ick_amd.load_models(variant)
+    batch = synth.make_batch(variant, B, L, K, V, Fn, seed)
+    enc_out = synth.make_enc_out(B, seed, emb_dim=d).cuda()
+    results = []
+    for chains in (True, False):
+        dec = m.DecoderTransformer(word_map=wm, emb_dim=d, decoder_dim=FF, encoder_dim=320, num_heads=H, num_layers=NL)
+        dec.load_state_dict(P, strict=False)
+        dec = dec.cuda().train()
+        for mod in dec.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+        assert dec.chain_supported() and dec.chain_bwd_supported()
+        if not chains:
+            dec.__dict__["_chain_ok"] = False
+            dec.__dict__["_chain_bwd_ok"] = False
+        args = [batch["captions"].cuda(), enc_out, batch["caption_masks"].cuda(), batch["caption_lengths"].cuda(),
+                batch["entities"]]
+        if "facts" in batch:
+            args.append(batch["facts"].cuda())
+        scores, caps, dl = dec(*args)
+        sp = pack_padded_sequence(scores, dl, batch_first=True).data
+        tp = pack_padded_sequence(caps[:, 1:], dl, batch_first=True).data
+        loss = torch.nn.functional.cross_entropy(sp, tp, ignore_index=wm["<pad>"])
+        loss.backward()
+        results.append((scores.detach(), loss.item(), {k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None}))
+    (s1, l1, g1), (s0, l0, g0) = results
+    assert (s1 - s0).abs().max().item() < 2e-4
+    assert abs(l1 - l0) < 2e-5
+    assert g1.keys() == g0.keys()
+    for k in g1:
+        scale = max(1.0, g0[k].abs().max().item())
+        assert (g1[k] - g0[k]).abs().max().item() < 3e-5 * scale, k
