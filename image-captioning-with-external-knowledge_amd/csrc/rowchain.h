@@ -66,9 +66,12 @@ struct RowGemm {
     }
 
     __device__ __forceinline__ void begin(int K, const float* __restrict__ Wp, const GemmPlan g, const Slab w) {
-        kb = w.h * g.kper;
-        const int ke = min(K, kb + g.kper);
-        nchunk = (w.h < g.splits && kb < ke) ? (ke - kb + 15) >> 4 : 0;     // 0: a wave without work
+        // K split in whole 16-k chunks, as even as they go (19 chunks over 3 splits: 7 + 6 + 6, not 7 + 7 + 5)
+        const int chunks = (K + 15) >> 4;
+        const int per = chunks / g.splits, extra = chunks - per * g.splits;
+        const int c0 = w.h * per + min(w.h, extra);
+        nchunk = w.h < g.splits ? per + (w.h < extra ? 1 : 0) : 0;      // 0: a wave without work
+        kb = nchunk > 0 ? 16 * c0 : 0;
         const int K16 = (K + 15) & ~15;
         slab_bytes = K16 * 64 * 4;                 // one slab of the packed copy
         const int slab = w.h < g.splits ? w.slab : 0;
@@ -80,9 +83,8 @@ struct RowGemm {
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    __device__ __forceinline__ void mfma(const f32x4 (&b)[4], const float* xa, int ldx, int c, f32x4& acc0, f32x4& acc1) {
-        const int k0 = kb + 16 * c;
-        const float a0 = xa[k0], a1 = xa[4 * ldx + k0];
+    // a0 / a1: the A operands of chunk c (X[4 rows][16 k] of the two row groups), read from LDS one chunk ahead
+    __device__ __forceinline__ void mfma(const f32x4 (&b)[4], float a0, float a1, f32x4& acc0, f32x4& acc1) {
         ICK_MF(0) ICK_MF(1) ICK_MF(2) ICK_MF(3) ICK_MF(4) ICK_MF(5) ICK_MF(6) ICK_MF(7)
         ICK_MF(8) ICK_MF(9) ICK_MF(10) ICK_MF(11) ICK_MF(12) ICK_MF(13) ICK_MF(14) ICK_MF(15)
     }
@@ -91,12 +93,20 @@ struct RowGemm {
         const int lane = threadIdx.x & 63;
         acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
         acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* xa = Xs + (lane & 3) * ldx + (lane >> 2);
+        // chunk c of this wave's K range; the pointer stays inside the (zero padded) row for c up to nchunk
+        const float* xa = Xs + (lane & 3) * ldx + (lane >> 2) + kb;
+        const int last = max(nchunk - 1, 0);
+        float a0 = xa[0], a1 = xa[4 * ldx];
         // sched_barrier: the machine scheduler otherwise sinks the prefetches down to their uses (vmcnt(0) per chunk)
-#define ICK_STEP(LD, LC, MF, MC)              \
-    load(bq[LD], LC);                        \
-    __builtin_amdgcn_sched_barrier(0);       \
-    mfma(bq[MF], xa, ldx, MC, acc0, acc1);   \
+#define ICK_STEP(LD, LC, MF, MC)                                                   \
+    load(bq[LD], LC);                                                             \
+    {                                                                             \
+        const int nx = 16 * min((MC) + 1, last);                                  \
+        const float n0 = xa[nx], n1 = xa[4 * ldx + nx];                           \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+        mfma(bq[MF], a0, a1, acc0, acc1);                                         \
+        a0 = n0; a1 = n1;                                                         \
+    }                                                                             \
     __builtin_amdgcn_sched_barrier(0);
         int c = 0;
         for (; c + 3 <= nchunk; c += 3) {
@@ -105,9 +115,11 @@ struct RowGemm {
             ICK_STEP(1, c + 4, 2, c + 2)
         }
         if (c < nchunk) {          // one or two chunks left, already in flight
-            mfma(bq[0], xa, ldx, c, acc0, acc1);
+            const int nx = 16 * min(c + 1, last);
+            const float n0 = xa[nx], n1 = xa[4 * ldx + nx];
+            mfma(bq[0], a0, a1, acc0, acc1);
             __builtin_amdgcn_sched_barrier(0);
-            if (c + 1 < nchunk) mfma(bq[1], xa, ldx, c + 1, acc0, acc1);
+            if (c + 1 < nchunk) mfma(bq[1], n0, n1, acc0, acc1);
         }
 #undef ICK_STEP
     }
