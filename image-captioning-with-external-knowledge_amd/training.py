@@ -197,7 +197,7 @@ def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds, side=None, pk=No
 
 
 def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gmap, seed=0, epoch=None,
-                      fresh_pack=False, overlap=False, feats=None, conv1=None):
+                      fresh_pack=False, overlap=False, feats=None, conv1=None, side_tail=None):
     """Teacher-forced forward on already length-sorted inputs; returns (scores, tape).  Dropout is
     active iff the module is in train() mode (masks derive from `seed` + the device counter `epoch`).
     fresh_pack: rebuild the packed cross-K/V / transposed predicate weights from the live parameters
@@ -206,7 +206,9 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     image-row K/V projection and the first self-attention block (for captured graphs; eager launches are
     host-bound and gain nothing).
     feats + conv1 = (weight, bias): instead of enc_tok, the (B, 2048, 14, 14) feature map; Encoder.conv1 then runs
-    here and writes the image rows straight into the memory buffer (no (B, 196, d) intermediate, no copy)."""
+    here and writes the image rows straight into the memory buffer (no (B, 196, d) intermediate, no copy).
+    side_tail: work of the caller that nothing in the forward pass waits for (TrainStep: zeroing the gradient bucket,
+    the decode lengths); with `overlap` it runs on the side stream once the context chain is done, else right away."""
     tape = Tape()
     m = tape.misc
     ds = DropSites(seed, dec.training, epoch)
@@ -215,20 +217,8 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     P = feats.shape[2] * feats.shape[3] if feats is not None else enc_tok.shape[1]
     K = entities.shape[1]
     dev = captions.device
-    ee = ops.entity_encode(dec.variant, entities, _p(dec.entity_encoder.type_embedding.weight), d,
-                           facts=facts if dec.has_facts else None,
-                           word_emb=_p(dec.word_embedding.weight) if dec.variant == "news" else None)
-    fe, Fn = None, 0
-    if dec.has_facts:
-        Fn = facts.shape[1]
-        fe = ops.fact_encode(facts, ee, _p(dec.predicate_embedding.weight))
-    if fresh_pack:
-        layers_ = dec.transformer_decoder.layers
-        wkv = torch.cat([_p(l.multihead_attn.in_proj_weight)[d:] for l in layers_])
-        bkv = torch.cat([_p(l.multihead_attn.in_proj_bias)[d:] for l in layers_])
-    else:
-        wkv, bkv = dec._packed_cross_kv()
-    nseg = wkv.shape[0] // d
+    Fn = facts.shape[1] if dec.has_facts else 0
+    nseg = 2 * len(dec.transformer_decoder.layers)
     S = P + K + Fn
     # memory rows [image ; entities ; facts], kept contiguous (B, S, d) for the weight gradient of the K/V
     # projection; its three row groups are projected separately (disjoint rows of the head-major kv buffer)
@@ -237,15 +227,50 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     tape.enc_layers["entities"] = []
     if dec.has_facts:
         tape.enc_layers["facts"] = []
+    side = ops.SideStream(priority=-1) if overlap else None
+    if side is None and side_tail is not None:
+        side_tail()
+    # ICK_SIDE_HEAD=1 (measured, left off): the entity / fact encoders, the packed K/V weight and the first packed copies
+    # open the side stream while the main stream starts with Encoder.conv1 at once.  The ~10 small kernels then sit
+    # behind conv1's 490 workgroups: the context chain starts at 158 us instead of 43 us (train step 2.00 -> 2.06 ms).
+    head_on_side = side is not None and feats is not None and bool(os.environ.get("ICK_SIDE_HEAD"))
+    conv1_done = False
+    if head_on_side:
+        ev0 = side.mark()
+        cw, cb = conv1
+        Cc = feats.shape[1]
+        ops.gemm_raw(feats, cw.view(d, Cc), mem, B * P, d, Cc, 1, P, Cc, 1, d, bias=cb, a_grp=P, a_gs=Cc * P,
+                     c_grp=P, c_gs=S * d)
+        conv1_done = True
 
-    # packed weight copies of the row-chain launches.  Inside the captured step they are refreshed in three launches
-    # placed where they cost nothing: the context encoders' copies now (the side chain needs them first), the decoder
-    # layers' after Encoder.conv1 has been enqueued, the transposed copies of the backward chains on the side stream
-    # once the context chain is done (it idles until the backward pass).
     chain = dec.chain_supported()
     staged = chain and fresh_pack and overlap
     first = lambda k: k[0] != "d" or (k[1] == 0 and k[2] in ("so", "cq"))     # context encoders + layer 0's self block
-    pk = dec._chain_pack(fresh=fresh_pack, subset=first if staged else None) if chain else None
+
+    def head():
+        ee = ops.entity_encode(dec.variant, entities, _p(dec.entity_encoder.type_embedding.weight), d,
+                               facts=facts if dec.has_facts else None,
+                               word_emb=_p(dec.word_embedding.weight) if dec.variant == "news" else None)
+        fe = ops.fact_encode(facts, ee, _p(dec.predicate_embedding.weight)) if dec.has_facts else None
+        if fresh_pack:
+            layers_ = dec.transformer_decoder.layers
+            wkv = torch.cat([_p(l.multihead_attn.in_proj_weight)[d:] for l in layers_])
+            bkv = torch.cat([_p(l.multihead_attn.in_proj_bias)[d:] for l in layers_])
+        else:
+            wkv, bkv = dec._packed_cross_kv()
+        # packed weight copies of the row-chain launches.  Inside the captured step they are refreshed in three
+        # launches placed where they cost nothing: the context encoders' copies now (the side chain needs them
+        # first), the decoder layers' after Encoder.conv1 has been enqueued, the transposed copies of the backward
+        # chains on the side stream once the context chain is done (it idles until the backward pass).
+        pk = dec._chain_pack(fresh=fresh_pack, subset=first if staged else None) if chain else None
+        return ee, fe, wkv, bkv, pk
+
+    if head_on_side:
+        with side.fork(after=ev0):
+            ee, fe, wkv, bkv, pk = head()
+            side.signal("head")
+    else:
+        ee, fe, wkv, bkv, pk = head()
     # the context chains run beside Encoder.conv1 and the image K/V projection: 8-wave workgroups find room there
     slim_ctx = overlap and not os.environ.get("ICK_NO_SLIM")
 
@@ -258,13 +283,14 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         ops.stamp("side: context chain done")
         if staged and dec.chain_bwd_supported():
             m["pkb"] = dec._chain_pack(fresh=True, bwd=True, extra=[(("kv", "T"), wkv.t())])
+        if side is not None and side_tail is not None:
+            side_tail()
 
     def fact_chain():
         ctx_f = _context_encoder_fwd(dec, dec.transformer_encoder_facts, fe, tape.enc_layers["facts"], ds, pk=pk,
                                      tag="f", out=mem[:, P + K:], slim=slim_ctx)
         ops.project_heads(ctx_f, wkv, bkv, nseg, H, S, out=kv, s0=P + K, grp=Fn)
 
-    side = ops.SideStream(priority=-1) if overlap else None
     # Decoder layer 0's self-attention block (caption embedding, in_proj, causal attention, out-projection + norm1 +
     # q-projection) reads neither the image nor the context rows, so a third branch could run it beside Encoder.conv1.
     # Measured and left off (ICK_EARLY_SELF=1 turns it on): with three concurrent branches in the captured graph every
@@ -290,7 +316,9 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         side.submit(entity_chain, ee, fe, mem, kv, wkv, bkv, img)
     else:
         entity_chain()
-    if feats is not None:
+    if conv1_done:
+        pass
+    elif feats is not None:
         cw, cb = conv1
         Cc = feats.shape[1]
         ops.gemm_raw(feats, cw.view(d, Cc), mem, B * P, d, Cc, 1, P, Cc, 1, d, bias=cb, a_grp=P, a_gs=Cc * P,
@@ -299,6 +327,8 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         mem[:, :P].copy_(img)
     if side is not None:
         side.flush()     # enqueued after the main stream's next kernel (see SideStream)
+    if head_on_side:
+        side.wait("head")    # the main stream needs the packed K/V weight, the entity rows and the first copies from here on
     if early is not None:
         early.flush()
     if staged:
@@ -844,12 +874,18 @@ class TrainStep:
 
     def _part_a(self, captions, caption_masks, entities, facts, enc_in, gmap, lengths):
         dec = self.dec
-        self.flat_g.zero_()
         ops.stamp("A: start")
-        decode_len = (lengths.reshape(-1) - 1).to(torch.int32)
+        box = {}
+
+        def tail():      # nothing in the forward pass waits for these: they run on the side stream behind the context chain
+            self.flat_g.zero_()
+            box["decode_len"] = (lengths.reshape(-1) - 1).to(torch.int32)
+
         scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, gmap=gmap,
                                          seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
-                                         overlap=(self.use_graph or bool(os.environ.get("ICK_GROUP_SAME_STREAM"))) and not os.environ.get("ICK_NO_FWD_OVERLAP"), **self._enc_kwargs(enc_in))
+                                         overlap=(self.use_graph or bool(os.environ.get("ICK_GROUP_SAME_STREAM"))) and not os.environ.get("ICK_NO_FWD_OVERLAP"),
+                                         side_tail=tail, **self._enc_kwargs(enc_in))
+        decode_len = box["decode_len"]
         ops.stamp("fwd: scores done")
         # the two scalars of the loss go straight into the tail of the gradient bucket (it was zeroed above; nothing else
         # touches those two floats)
@@ -864,11 +900,17 @@ class TrainStep:
     # ---- the same step in two halves (several ranks: the early half's all-reduce overlaps the late half) ----
     def _part_a1(self, captions, caption_masks, entities, facts, enc_in, gmap, lengths):
         dec = self.dec
-        self.flat_g.zero_()
-        decode_len = (lengths.reshape(-1) - 1).to(torch.int32)
+        box = {}
+
+        def tail():
+            self.flat_g.zero_()
+            box["decode_len"] = (lengths.reshape(-1) - 1).to(torch.int32)
+
         scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, gmap=gmap,
                                          seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
-                                         overlap=(self.use_graph or bool(os.environ.get("ICK_GROUP_SAME_STREAM"))) and not os.environ.get("ICK_NO_FWD_OVERLAP"), **self._enc_kwargs(enc_in))
+                                         overlap=(self.use_graph or bool(os.environ.get("ICK_GROUP_SAME_STREAM"))) and not os.environ.get("ICK_NO_FWD_OVERLAP"),
+                                         side_tail=tail, **self._enc_kwargs(enc_in))
+        decode_len = box["decode_len"]
         self._loss = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True,
                                    out_sum=self.flat_g[self.n:self.n + 1], out_count=self.flat_g[self.n + 1:])
         self._bp = BackwardPass(dec, tape, self._loss[2], self.grads,
