@@ -83,11 +83,14 @@ def colsum_problem(a2d, out):
     return a
 
 
-def wgrad_split(rows, n_out, k_in):
+def wgrad_split(rows, n_out, k_in, grouped=False):
     """K split of a weight-gradient GEMM (reduction over `rows`): enough workgroups to fill the GPU (~1600), slices
-    of at least 256 rows.  Measured (probe_ops): vocabulary 10000x300 over 1280 rows 121 us at 5 slices, 91 us at 2."""
+    of at least 256 rows.  Measured (probe_ops): vocabulary 10000x300 over 1280 rows 121 us at 5 slices, 91 us at 2.
+    grouped: the problem goes out in a layer's grouped launch (~1000 workgroups together): two slices are enough, more
+    only add atomics and prologues (train step 2.01 -> 1.98 ms; ICK_WGRAD_SPLIT_MAX overrides the cap)."""
     tiles = ((n_out + 63) // 64) * ((k_in + 63) // 64)
-    return max(1, min(16, rows // 256, (1600 + tiles // 2) // tiles))
+    cap = int(os.environ.get("ICK_WGRAD_SPLIT_MAX", "2" if grouped else "16"))
+    return max(1, min(cap, rows // 256, (1600 + tiles // 2) // tiles))
 
 
 CONV1_TILE = (128, 64)   # workgroup tile ick_gemm picks for Encoder.conv1 at bench size (asserted by the parity tests)
@@ -765,7 +768,7 @@ def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False, gro
     wg = None
     if dw is not None:
         wg = gemm_args(dy, x, dw, N, K, M, 1, dy.stride(0), 1, x.stride(0), dw.stride(0), atomic=True,
-                       split_k=wgrad_split(M, N, K), colsum_a=db)
+                       split_k=wgrad_split(M, N, K, grouped=SIDE is not None), colsum_a=db)
 
     def param_grads():
         if wg is not None:

@@ -589,7 +589,8 @@ def _kv_proj_param_grads(layer, li, dkv_rows, mem2, grads, d):
     rows = mem2.shape[0]
     sl = dkv_rows.view(rows, -1)[:, 2 * li * d:(2 * li + 2) * d]
     if gw is not None:
-        wg = ops.gemm_args(sl, mem2, gw[d:], 2 * d, d, rows, 1, sl.stride(0), 1, d, d, atomic=True, split_k=16,
+        wg = ops.gemm_args(sl, mem2, gw[d:], 2 * d, d, rows, 1, sl.stride(0), 1, d, d, atomic=True,
+                           split_k=int(os.environ.get("ICK_KV_WGRAD_SPLIT", "16")),
                            colsum_a=None if gb is None else gb[d:])
         if ops.SIDE is not None:
             ops.SIDE.add_problem(wg, dkv_rows, mem2)
