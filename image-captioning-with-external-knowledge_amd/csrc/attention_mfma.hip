@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ick_attn_args p, int
 // ---------------------------------------------------------------------------------------------
 template <int NQT, int MAXT>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p, int SP, bool st2) {
-    chain_priority();
+    chain_priority_bwd();
     constexpr int NQ = NQT * 16;
     constexpr int TLD = NQ + 4;          // row stride of the transposed Q / dO tiles ([col][query])
     extern __shared__ __attribute__((aligned(16))) float smem[];

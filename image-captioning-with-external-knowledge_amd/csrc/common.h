@@ -50,9 +50,20 @@ __device__ __forceinline__ float wave_max(float v) {
 // otherwise get a round-robin share of the matrix pipe (measured: the 14 us in_proj GEMM of the context encoder
 // takes 111 us beside Encoder.conv1), while the bulk kernel hardly notices the few cycles they take.
 // ICK_NO_SETPRIO (compile time) turns it off.
+#ifndef ICK_CHAIN_PRIO
+#define ICK_CHAIN_PRIO 3
+#endif
+#ifndef ICK_CHAIN_PRIO_BWD
+#define ICK_CHAIN_PRIO_BWD ICK_CHAIN_PRIO
+#endif
 __device__ __forceinline__ void chain_priority() {
 #ifndef ICK_NO_SETPRIO
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(ICK_CHAIN_PRIO);
+#endif
+}
+__device__ __forceinline__ void chain_priority_bwd() {      // backward-pass chain kernels (they run beside the weight gradients)
+#ifndef ICK_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(ICK_CHAIN_PRIO_BWD);
 #endif
 }
 

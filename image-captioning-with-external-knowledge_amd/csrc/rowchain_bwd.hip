@@ -76,7 +76,7 @@ __device__ __forceinline__ void ln_bwd_row(const LnIn& q, const float (&dx)[5], 
 }
 
 __global__ __launch_bounds__(kThreads) void rowchain_bwd_kernel(ick_rowchain_bwd_args p) {
-    chain_priority();
+    chain_priority_bwd();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* XA = smem;                          // [8][kLdA]  wide GEMM input: g0 rows, later t
     float* XB = XA + kRows * kLdA;             // [8][kLdB]  d-wide GEMM input: do1 / do2

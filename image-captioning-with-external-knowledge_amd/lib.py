@@ -8,6 +8,8 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libick_amd.so")
+if os.environ.get("ICK_LIB_PATH"):      # experiment hook: a library built with other compile-time switches
+    LIB_PATH = os.environ["ICK_LIB_PATH"]
 
 ICK_GEO, ICK_KNOWLEDGE, ICK_NEWS = 0, 1, 2
 VARIANT_ID = {"geo": ICK_GEO, "knowledge": ICK_KNOWLEDGE, "news": ICK_NEWS}

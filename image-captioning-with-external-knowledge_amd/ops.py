@@ -705,6 +705,13 @@ class SideStream:
 
             self.deferred.append((self.mark(), launch, tuple(t for _, ts in late for t in ts)))
 
+    def flush_group_here(self):
+        """The queued problems as one grouped launch on the CALLER's stream, right now: for the tail of a pass, where the
+        main stream has run out of work and the side stream is what finishes last."""
+        if self.group:
+            problems, self.group = self.group, []
+            gemm_grouped(problems)
+
     def mark(self):
         """Event at the current point of the main stream, for a later fork(..., after=event)."""
         ev = torch.cuda.Event()

@@ -415,6 +415,7 @@ def _context_encoder_bwd(dec, stack, tapes, dx, grads, pkb=None, tag="e", g_firs
     layers = list(stack.layers)
     if pkb is not None:
         dev = tapes[0]["x"].device
+        tail_on_main = not os.environ.get("ICK_NO_TAIL_ON_MAIN")
         dz, g0, w0p = dx, None, None
         if g_first is not None:
             dz, (g0, w0p) = None, g_first
@@ -438,7 +439,7 @@ def _context_encoder_bwd(dec, stack, tapes, dx, grads, pkb=None, tag="e", g_firs
             _lin_bwd(grads, dpre, t["x1"].view(M, d), layer.linear1.weight, layer.linear1.bias, need_dx=False)
             _lin_bwd(grads, n1["do"], t["sa"].view(M, d), layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias,
                      need_dx=False)
-            if ops.SIDE is not None:
+            if ops.SIDE is not None and not (li == 0 and tail_on_main):
                 # everything queued so far only needs the chain launch above: it goes out now, beside the attention
                 # backward (the in_proj weight gradient follows with the next group) -- the side stream's last group,
                 # which nothing on the main stream overlaps any more, shrinks to one problem
@@ -457,7 +458,13 @@ def _context_encoder_bwd(dec, stack, tapes, dx, grads, pkb=None, tag="e", g_firs
                 dx = _lin_bwd(grads, dqkv.view(M, 3 * d), t["x"].view(M, d), layer.self_attn.in_proj_weight,
                               layer.self_attn.in_proj_bias, dx=dz_out, acc=True).view(B, T, d)
                 if ops.SIDE is not None:
-                    ops.SIDE.flush_group()
+                    if tail_on_main:
+                        # the stack's first layer is the last thing the backward pass computes: the main stream has
+                        # nothing left while the side stream still works off the layers above -- its weight gradients
+                        # run here instead of queueing behind them
+                        ops.SIDE.flush_group_here()
+                    else:
+                        ops.SIDE.flush_group()
         return dx
     for layer, t in zip(reversed(layers), reversed(tapes)):
         B, T, _ = t["x"].shape
