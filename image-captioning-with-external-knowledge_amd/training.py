@@ -516,12 +516,23 @@ def _decoder_layer_bwd_chain(dec, li, layer, t, state, dkv_rows, kv, S, grads, p
     _lin_bwd(grads, dpre, t["x2"].view(M, d), layer.linear1.weight, layer.linear1.bias, need_dx=False)
     _lin_bwd(grads, n2["do"], t["ca"].view(M, d), layer.multihead_attn.out_proj.weight,
              layer.multihead_attn.out_proj.bias, need_dx=False)
+    # The layer's weight gradients go out in two grouped launches: linear2 / linear1 / cross out-projection + the two
+    # norms' partials right behind the chain launch above, the rest at the layer's end (the side stream finishes last:
+    # starting its work earlier shortens the step, 651 -> 654 k decode-steps/s; a third launch right behind the
+    # cross-attention backward costs more in fork points than it gains: 645 k).  ICK_BWD_SUBGROUPS=0 / 2 for A/B.
+    sub = int(os.environ.get("ICK_BWD_SUBGROUPS", "1")) if ops.SIDE is not None else 0
+    if sub >= 1:
+        ops.SIDE.flush_group()
     dq = torch.empty(B, T, d, device=dev, dtype=torch.float32)
     c0 = 2 * li * d
     ops.attention_heads_bwd(t["qc"], kv, t["ca"], dca.view(B, T, d), t["lse_c"], dq, dkv_rows[:, :, c0:c0 + d],
                             dkv_rows[:, :, c0 + d:c0 + 2 * d], H, dh, T, S, 0, 2 * li, 2 * li + 1, drop=t["d_ca"])
+    if sub >= 1:
+        ops.SIDE.flush()
     if mem2 is not None:
         _kv_proj_param_grads(layer, li, dkv_rows, mem2, grads, d)
+    if sub >= 2:
+        ops.SIDE.flush_group()      # the K/V-projection weight gradient (the heavy one) starts right behind its operand
     n1 = _norm_args(t, 1, t["x"], layer.norm1, grads, M, d, dev)
     dsa = torch.empty(M, d, device=dev, dtype=torch.float32)
     dz_b = torch.empty(M, d, device=dev, dtype=torch.float32)
