@@ -15,10 +15,8 @@ constexpr int kMaxD = 320;        // LayerNorm width (5 columns per lane)
 constexpr int kMaxN2 = 1024;      // widest second GEMM (in_proj: 3 d)
 constexpr int kPartFloats = kRows * 64 * kWaves;   // every (slab, K split) pair is one wave: 8 rows x 64 columns each
 
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-
-struct GemmPlan {   // how the 16 waves cover N columns x K
-    int nslab, splits, kper;
+struct GemmPlan {   // how the 16 (slab, K split) units cover N columns x K
+    int nslab, splits;
 };
 __host__ __device__ __forceinline__ GemmPlan plan_for(int N, int K) {
     GemmPlan g;
@@ -28,7 +26,6 @@ __host__ __device__ __forceinline__ GemmPlan plan_for(int N, int K) {
     const int maxs = (K + 15) / 16;
     if (g.splits > maxs) g.splits = maxs;
     if (g.splits > 4) g.splits = 4;
-    g.kper = (((K + g.splits - 1) / g.splits) + 15) / 16 * 16;
     return g;
 }
 
