@@ -86,3 +86,33 @@ def test_resnet_trunk_layout_matches_torchvision_keys():
     tv["fc.weight"], tv["fc.bias"] = torch.zeros(1000, 2048), torch.zeros(1000)
     load_torchvision_state_dict(trunk, tv)
     assert torch.equal(trunk.state_dict()["7.2.conv3.weight"], sd["7.2.conv3.weight"] + 1)
+
+
+def test_row_chain_weight_items_cover_every_launch():
+    """Host logic of the row chains (no GPU): the packed-copy items name every Linear a chain launch multiplies with,
+    forward and (transposed) backward, and the staged refresh of the captured step partitions them."""
+    import ick_amd
+    import ick_amd.synth as synth
+    for variant, stacks in (("geo", 1), ("knowledge", 2)):
+        m = ick_amd.load_models(variant)
+        dec = m.DecoderTransformer(synth.make_word_map(60), 300, 512, 512, 10, 3)
+        items = dict(dec._chain_items())
+        nl = 3
+        assert len(items) == (6 * nl - 1) + stacks * (4 * nl - 1)
+        d = dec.emb_dim
+        for li in range(nl):
+            assert items[("d", li, "so")].shape == (d, d) and items[("d", li, "cq")].shape == (d, d)
+            assert items[("d", li, "l1")].shape == (512, d) and items[("d", li, "l2")].shape == (d, 512)
+            assert (("d", li, "si") in items) == (li > 0)
+            assert items[("e", li, "l1")].shape == (512, d)
+        assert items[("d", 1, "si")].shape == (3 * d, d)
+        # the q-projection item is the first d rows of the packed in_proj weight (a view, not a copy)
+        w = dec.transformer_decoder.layers[0].multihead_attn.in_proj_weight
+        assert items[("d", 0, "cq")].data_ptr() == w.data_ptr()
+        bwd = dict(dec._chain_items_bwd())
+        assert set(bwd) == {(a, b, c + "T") for (a, b, c) in items}
+        for (a, b, c), v in items.items():
+            assert bwd[(a, b, c + "T")].shape == (v.shape[1], v.shape[0])
+        first = lambda k: k[0] != "d" or (k[1] == 0 and k[2] in ("so", "cq"))
+        assert {k for k in items if first(k)} | {k for k in items if not first(k)} == set(items)
+        assert all(k[0] in ("e", "f") or k[1] == 0 for k in items if first(k))
