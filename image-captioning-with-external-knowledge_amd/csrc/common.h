@@ -28,9 +28,19 @@ inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // operands of the add / max itself (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: one VALU instruction
 // each); the four row results are then read into scalar registers (v_readlane) and combined as (r0 + r1) + (r2 + r3)
 // -- the value the xor-16 / xor-32 butterfly gives, without its two ds_bpermute round trips (~100 cycles each).
+//
+// PRECONDITION: all 64 lanes active (call from wave-uniform control flow only -- every call site in this library
+// does: loops / branches around them depend on blockIdx, kernel arguments or wave indices, never on the lane).  A DPP
+// read of a disabled lane yields the `old` operand, which is the reduction's identity here (0 for the sum, the lane's own
+// value for the maximum), but v_readlane of a disabled lane 0/16/32/48 would return a stale register.
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32_self(float v) {      // a disabled source lane reads as the lane's own value
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, CTRL, 0xF, 0xF, false));
 }
 __device__ __forceinline__ float lane_f32(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
@@ -40,8 +50,8 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (lane_f32(v, 0) + lane_f32(v, 16)) + (lane_f32(v, 32) + lane_f32(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-    v = fmaxf(v, dpp_f32<0xB1>(v)); v = fmaxf(v, dpp_f32<0x4E>(v));
-    v = fmaxf(v, dpp_f32<0x141>(v)); v = fmaxf(v, dpp_f32<0x140>(v));
+    v = fmaxf(v, dpp_f32_self<0xB1>(v)); v = fmaxf(v, dpp_f32_self<0x4E>(v));
+    v = fmaxf(v, dpp_f32_self<0x141>(v)); v = fmaxf(v, dpp_f32_self<0x140>(v));
     return fmaxf(fmaxf(lane_f32(v, 0), lane_f32(v, 16)), fmaxf(lane_f32(v, 32), lane_f32(v, 48)));
 }
 

@@ -914,6 +914,7 @@ __device__ __forceinline__ void block_best(float& v, int& c, float* shv, int* sh
 }
 
 constexpr int kBeamChunk = 1024;      // scores per stage-1 workgroup
+constexpr int kBeamCandPerThread = 16; // stage 2 holds beam^2 x chunks candidates in the registers of 256 threads
 constexpr int kBeamRec = 2 + 2 * kBeamMax;   // floats per (row, chunk) record: max, sum of exp, kBeamMax x (value, index)
 
 // Stage 1 of the beam selection, one workgroup per (chunk of 1024 scores, row): the chunk's maximum, its sum of
@@ -971,7 +972,10 @@ __global__ __launch_bounds__(256) void dec_beam_partial_kernel(BeamPartArgs a) {
 }
 
 __global__ __launch_bounds__(256) void dec_select_beam_kernel(BeamArgs a) {
-    if (*a.n_done >= a.n_total) return;
+    // No exit on *n_done here: other workgroups of this very launch add to it, and the hypothesis tables are
+    // ping-pong buffers -- a step that skipped its carry-copy would leave the previous step's rows (in another
+    // order) in the buffer the caller reads.  The decision below only looks at this caption's own state, which no
+    // other workgroup writes.
     __shared__ float shv[4];
     __shared__ int shc[4];
     __shared__ float cum_s[kBeamMax], lse_s[kBeamMax];
@@ -982,6 +986,19 @@ __global__ __launch_bounds__(256) void dec_select_beam_kernel(BeamArgs a) {
     const int nchunk = (Vx + kBeamChunk - 1) / kBeamChunk;
     if (tid < k) { cum_s[tid] = a.cum[r0 + tid]; fin_s[tid] = a.fin[r0 + tid]; }
     __syncthreads();
+    bool live_any = false;
+    for (int j = 0; j < k; ++j) live_any = live_any || !(fin_s[j] || cum_s[j] == -INFINITY);
+    if (!live_any) {
+        // every hypothesis of this caption has ended: the tables move to the other buffer as they are
+        for (int idx = tid; idx < k * a.max_len; idx += 256) {
+            const int64_t e = r0 * a.max_len + idx;
+            a.seq_out[e] = a.seq_in[e];
+            a.anc_out[e] = a.anc_in[e];
+            if (a.cap_out != nullptr) a.cap_out[e] = a.cap_in[e];
+        }
+        if (tid < k) { a.next_token[r0 + tid] = 0; a.next_mask[r0 + tid] = 0; }
+        return;
+    }
     // log-sum-exp of every live row from its chunk records (wave j handles row j, j + 4)
     for (int j = tid >> 6; j < k; j += 4) {
         if (fin_s[j] || cum_s[j] == -INFINITY) continue;
@@ -999,7 +1016,7 @@ __global__ __launch_bounds__(256) void dec_select_beam_kernel(BeamArgs a) {
     }
     __syncthreads();
     // candidates: k per (live row, chunk), one per ended row; every thread keeps up to NC of them
-    constexpr int NC = 8;
+    constexpr int NC = kBeamCandPerThread;
     float cv[NC]; int cc[NC];
     const int per_row = nchunk * k, total = k * per_row;
 #pragma unroll
@@ -1108,6 +1125,11 @@ extern "C" int ick_decode_supported(int32_t d, int32_t H, int32_t FF, int32_t S,
            S > 0 && S <= kSMax && max_len > 0 && max_len <= kMLMax;
 }
 
+extern "C" int ick_decode_beam_supported(int32_t Vx, int32_t beam) {
+    if (Vx <= 0 || beam < 1 || beam > kBeamMax) return 0;
+    return (int64_t)beam * beam * ceil_div(Vx, kBeamChunk) <= 256 * kBeamCandPerThread;   // candidates the selection holds
+}
+
 extern "C" int ick_decode_layers(const ick_decode_ctx* c, int32_t pos, void* stream) {
     ICK_CHECK_ARG(c && c->R > 0 && c->layers > 0 && c->layers <= ICK_MAX_LAYERS && pos >= 0 && pos < c->max_len);
     ICK_CHECK_ARG(ick_decode_supported(c->d, c->H, c->FF, c->S, c->max_len));
@@ -1187,7 +1209,7 @@ extern "C" int ick_decode_select_beam(const ick_decode_ctx* c, const ick_beam_st
     ICK_CHECK_ARG((bs->cap_in == nullptr) == (bs->cap_out == nullptr));
     ICK_CHECK_ARG(bs->rec != nullptr);
     const int Vx = c->V + c->K + c->F, nchunk = ceil_div(Vx, kBeamChunk);
-    ICK_CHECK_ARG(c->rows_per_sample * nchunk * c->rows_per_sample <= 256 * 8);      // candidates one thread can hold
+    ICK_CHECK_ARG(ick_decode_beam_supported(Vx, c->rows_per_sample));
     BeamPartArgs pa;
     pa.scores = c->scores; pa.ld = c->scores_ld; pa.ptr = c->ptr; pa.cum = bs->cum; pa.fin = bs->fin; pa.rec = bs->rec;
     pa.R = c->R; pa.k = c->rows_per_sample; pa.V = c->V; pa.np = c->K + c->F; pa.nchunk = nchunk;

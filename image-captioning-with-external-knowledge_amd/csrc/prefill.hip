@@ -221,10 +221,11 @@ __global__ __launch_bounds__(256) void context_indicators_kernel(const int64_t* 
         __syncthreads();
         const int n = *nrep;
         for (int c = blockIdx.y * 256 + tid; c < d; c += 256 * gridDim.y) {
-            float acc = bias[c];
+            // wt == nullptr: the dense predicate indicator itself (d == num_pred columns, identity "weight", no bias)
+            float acc = wt ? bias[c] : 0.f;
             int r = 0;
             for (int p = 0; p < T; ++p) {
-                while (r < n && ord_act[r] <= p) { acc += wt[(int64_t)ord_pred[r] * d + c]; ++r; }
+                while (r < n && ord_act[r] <= p) { acc += wt ? wt[(int64_t)ord_pred[r] * d + c] : (ord_pred[r] == c ? 1.f : 0.f); ++r; }
                 gate[((int64_t)b * T + p) * d + c] = acc;
             }
         }
@@ -293,7 +294,7 @@ extern "C" int ick_context_indicators(const int64_t* captions, const int64_t* fa
     using namespace ick;
     ICK_CHECK_ARG(captions && facts && eib && B > 0 && L > 0 && K > 0 && F > 0);
     ICK_CHECK_ARG((mode == 0 && T == L) || (mode == 1 && T == 1));
-    if (gate) ICK_CHECK_ARG(fc_pred_wt && fc_pred_b && num_pred > 0 && d > 0);
+    if (gate) ICK_CHECK_ARG(num_pred > 0 && d > 0 && ((fc_pred_wt && fc_pred_b) || (!fc_pred_wt && d == num_pred)));
     const size_t smem = (size_t)(K + 5 * F + 1) * sizeof(int);
     ICK_CHECK_ARG(smem <= 64 * 1024);
     const int csplit = gate ? std::max(1, std::min(4, ceil_div(d, 256))) : 1;   // workgroups per sample (gate columns)

@@ -180,9 +180,11 @@ class Encoder(nn.Module):
         self.adaptive_pool = nn.AdaptiveAvgPool2d((self.encoded_image_size, self.encoded_image_size))
         if dev is not None:
             self.resnet.to(dev)
-        for p in self.resnet.parameters():
-            p.requires_grad = False
         self.resnet.train(self.training)
+        # a trunk built on first use takes the fine_tune() setting that was asked for before it existed.  Its
+        # parameters are new, so an optimizer built earlier does not hold them: train.py builds the trunk up front
+        # (with_trunk=True) whenever fine_tune_encoder is set.
+        self.fine_tune(self.__dict__.get("_fine_tune", True))
 
     def features(self, images):
         """images (B, 3, H, W) -> (B, 2048, 14, 14): trunk + adaptive pooling (geo-aware/models.py:42-43)."""
@@ -213,7 +215,9 @@ class Encoder(nn.Module):
 
     def fine_tune(self, fine_tune=True):
         """Convolutional blocks 2-4 of the trunk train iff fine_tune (geo-aware/models.py:49-60); conv1 is left
-        as the reference leaves it (always requires_grad).  Without a trunk there is nothing to toggle."""
+        as the reference leaves it (always requires_grad).  Without a trunk the setting is remembered and applied when
+        the trunk is built."""
+        self.__dict__["_fine_tune"] = bool(fine_tune)
         if "resnet" not in self._modules:
             return
         for p in self.resnet.parameters():
@@ -612,6 +616,49 @@ class DecoderTransformer(nn.Module):
             ops.pointer_scores(h, fe, self.fc_fact.weight.detach(), self.fc_fact.bias.detach(), out, V + K, ind=eib)
         return out
 
+    # ------------------------------------------------------------------ public score-head methods
+    @torch.no_grad()
+    def get_context_indicators(self, captions, facts, entity_context_size, out_length):
+        """knowledge-aware/models.py:380-418 (news: same): captions (B, L) token indices, facts (B, F, 3) ->
+        (entity_idx_before (B, out_length, F, 1), predicate_indicator (B, out_length, num_predicates, 1)), dense 0/1
+        float tensors like the reference's.  out_length == 1 is predict()'s form ("mentioned anywhere in the buffer"),
+        otherwise position p sees the mentions strictly before p.  One launch of ick_context_indicators (forward()
+        itself never builds the dense predicate indicator: it uses the kernel's fused fc_predicate form)."""
+        if not self.has_facts:
+            raise AttributeError("the geo variant has no get_context_indicators (geo-aware/models.py)")
+        dev = self.fc_vocab.weight.device
+        captions = captions.to(device=dev, dtype=torch.int64)
+        facts = facts.to(device=dev, dtype=torch.int64).contiguous()
+        B, Lc = captions.shape
+        mode = 1 if out_length == 1 else 0
+        if mode == 0 and out_length > Lc:      # positions past the caption see every mention: pad with <pad> tokens
+            captions = torch.cat([captions, captions.new_full((B, out_length - Lc), self.word_map["<pad>"])], dim=1)
+        eib, pi = ops.context_indicators(captions.contiguous(), facts, entity_context_size, self.vocab_size, mode=mode,
+                                         dense_pred=self.num_predicates)
+        return eib[:, :out_length].unsqueeze(3), pi[:, :out_length].unsqueeze(3)
+
+    @torch.no_grad()
+    def get_scores(self, h, entities_encoded, facts_encoded=None, entity_idx_before=None, predicate_indicator=None):
+        """geo-aware/models.py:291-313 / knowledge-aware/models.py:420-455: h (L, B, d) decoder states,
+        entities_encoded (B, K, d) [, facts_encoded (B, F, d), entity_idx_before (B, L, F, 1), predicate_indicator
+        (B, L, num_predicates, 1)] -> scores (L, B, V+K[+F]).  Runs the score-head kernels (vocabulary GEMM written in
+        place + pointer-score kernels; the predicate gate from the DENSE indicator is one more GEMM).  Inference
+        helper: gradients flow through forward() only."""
+        dev = self.fc_vocab.weight.device
+        hb = h.detach().to(dev, torch.float32).permute(1, 0, 2).contiguous()           # (B, L, d) rows
+        ee = entities_encoded.detach().to(dev, torch.float32).contiguous()
+        fe = eib = gate = None
+        if self.has_facts:
+            if facts_encoded is None or entity_idx_before is None or predicate_indicator is None:
+                raise IckError("%s variant: get_scores(h, entities_encoded, facts_encoded, entity_idx_before, "
+                               "predicate_indicator)" % self.variant)
+            B, T, d = hb.shape
+            fe = facts_encoded.detach().to(dev, torch.float32).contiguous()
+            eib = entity_idx_before.detach().to(dev, torch.float32).reshape(B, T, fe.shape[1]).contiguous()
+            pi = predicate_indicator.detach().to(dev, torch.float32).reshape(B * T, self.num_predicates).contiguous()
+            gate = ops.linear(pi, self.fc_predicate.weight.detach(), self.fc_predicate.bias.detach()).view(B, T, d)
+        return self._score_head(hb, ee, fe, eib, gate).permute(1, 0, 2)
+
     def _prepare_inputs(self, encoder_out, entities, facts):
         dev = self.fc_vocab.weight.device
         if dev.type != "cuda":
@@ -899,8 +946,11 @@ class DecoderTransformer(nn.Module):
         enc_tok = self._token_major(encoder_out).contiguous()
         FF = self.transformer_decoder.layers[0].linear1.out_features
         S_all = enc_tok.shape[1] + entities.shape[1] + (facts.shape[1] if facts is not None else 0)
-        if not (1 < beam_size <= 8) or not ops.decode_supported(self.emb_dim, self.num_heads, FF, S_all, max_pred_len):
-            raise IckError("predict_beam needs 1 <= beam_size <= 8 and sizes the fused decode kernels support")
+        Vx = self.vocab_size + S_all - enc_tok.shape[1]
+        if not (1 < beam_size <= 8) or not ops.decode_supported(self.emb_dim, self.num_heads, FF, S_all, max_pred_len) \
+                or not ops.decode_beam_supported(Vx, beam_size):
+            raise IckError("predict_beam needs 1 <= beam_size <= 8, beam_size^2 * ceil((V+K+F)/1024) <= 4096 and sizes "
+                           "the fused decode kernels support")
         if self.use_hip_graphs:
             key = (tuple(enc_tok.shape), tuple(entities.shape), None if facts is None else tuple(facts.shape),
                    max_pred_len, beam_size)

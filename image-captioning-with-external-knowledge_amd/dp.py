@@ -63,12 +63,61 @@ def broadcast_bucket(flat, group=None, src=0):
     return flat
 
 
+def _outside(t, skip):
+    """Is tensor t outside the byte range (lo, hi) of `skip`?"""
+    if skip is None:
+        return True
+    lo, hi = skip
+    return not (lo <= t.data_ptr() < hi)
+
+
+def module_state(modules, skip_range=None):
+    """Every parameter and buffer of `modules` (deduplicated, in module order) whose storage is not inside
+    skip_range = (first byte, end byte) -- the flat bucket TrainStep broadcasts and checks itself."""
+    seen, out = set(), []
+    for m in modules:
+        if m is None:
+            continue
+        for t in list(m.parameters()) + list(m.buffers()):
+            if id(t) not in seen and t.numel() > 0 and _outside(t, skip_range):
+                seen.add(id(t))
+                out.append(t)
+    return out
+
+
+def broadcast_module_state(modules, skip_range=None, group=None, src=0):
+    """Every rank takes rank `src`'s copy of the state TrainStep's bucket does not cover: the frozen Encoder.conv1 (each
+    process draws its own random initial weights), frozen decoder parameters and buffers.  Without it the ranks would
+    project their images with different conv1 weights and the summed gradient would not be the single-process
+    full-batch gradient."""
+    if world_size(group) <= 1:
+        return 0
+    n = 0
+    for t in module_state(modules, skip_range):
+        dist.broadcast(t.data, src=src, group=group)
+        n += 1
+    return n
+
+
+def module_state_agrees(modules, skip_range=None, group=None):
+    """True when every rank holds bit-identical copies of that state (one checksum all-reduce per tensor dtype)."""
+    if world_size(group) <= 1:
+        return True
+    ok = True
+    for t in module_state(modules, skip_range):
+        if t.dtype == torch.float32:
+            ok = replicas_agree(t, group) and ok
+        else:
+            ok = replicas_agree(t.detach().to(torch.float32), group) and ok
+    return ok
+
+
 def replicas_agree(flat, group=None):
     """True when every rank holds bit-identical `flat` (compares all-reduced MIN and MAX of a 64-bit checksum of the
     raw bits; cheap enough to call once per epoch)."""
     if world_size(group) <= 1:
         return True
-    bits = flat.detach().contiguous().view(torch.int32).to(torch.int64)
+    bits = flat.detach().contiguous().view(-1).view(torch.int32).to(torch.int64)
     w = torch.arange(1, bits.numel() + 1, device=bits.device, dtype=torch.int64) % 1000003
     cs = (bits * w).sum().view(1)
     lo, hi = cs.clone(), cs.clone()

@@ -157,6 +157,7 @@ SIGNATURES = {
     "ick_decode_layers": [C.POINTER(DecodeCtx), i32, vp],
     "ick_decode_select_greedy": [C.POINTER(DecodeCtx), i32, vp],
     "ick_decode_select_beam": [C.POINTER(DecodeCtx), C.POINTER(BeamState), i32, vp],
+    "ick_decode_beam_supported": [i32, i32],
     "ick_attention_bwd": [C.POINTER(AttnBwdArgs), vp],
     "ick_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, f32, u32, u32, vp, vp, vp],
     "ick_layernorm_bwd_rows_per_block": [],

@@ -430,7 +430,10 @@ def caption_embed(captions, masks, word_emb, entities_encoded, facts_encoded, pe
     return (out, emb) if want_emb else out
 
 
-def context_indicators(captions, facts, K, V, fc_pred_wt=None, fc_pred_b=None, mode=0, eib=None, gate=None):
+def context_indicators(captions, facts, K, V, fc_pred_wt=None, fc_pred_b=None, mode=0, eib=None, gate=None,
+                       dense_pred=0):
+    """dense_pred = number of predicates: `gate` becomes the dense (B, T, num_pred) 0/1 predicate indicator instead of
+    fc_predicate applied to it."""
     B, Lc = captions.shape
     F = facts.shape[1]
     T = Lc if mode == 0 else 1
@@ -439,6 +442,10 @@ def context_indicators(captions, facts, K, V, fc_pred_wt=None, fc_pred_b=None, m
     num_pred = d = 0
     if fc_pred_wt is not None:
         num_pred, d = fc_pred_wt.shape
+        if gate is None:
+            gate = torch.empty(B, T, d, device=captions.device, dtype=torch.float32)
+    elif dense_pred:
+        num_pred = d = dense_pred
         if gate is None:
             gate = torch.empty(B, T, d, device=captions.device, dtype=torch.float32)
     L.check(L.load().ick_context_indicators(_p(captions), _p(facts), _p(fc_pred_wt), _p(fc_pred_b), _p(eib),
@@ -487,6 +494,10 @@ def greedy_update(best, second, output, hist, finished, next_token, next_mask, s
 
 def decode_supported(d, H, FF, S, max_len):
     return bool(L.load().ick_decode_supported(d, H, FF, S, max_len))
+
+
+def decode_beam_supported(Vx, beam):
+    return bool(L.load().ick_decode_beam_supported(Vx, beam))
 
 
 def decode_layers(ctx, pos):

@@ -165,6 +165,10 @@ def make_loaders(cfg, rank, world):
     return loaders, samplers, gen
 
 
+def _bucket_range(step):
+    return (step.flat_p.data_ptr(), step.flat_p.data_ptr() + 4 * step.flat_p.numel())
+
+
 def main(cfg=None):
     cfg = cfg or Config()
     world = dp.init_from_env()
@@ -187,7 +191,9 @@ def main(cfg=None):
         if cfg.pretrained_word_embeddings_file:
             decoder.load_pretrained_embeddings(ut.load_embeddings(cfg.pretrained_word_embeddings_file, word_map))
         decoder.fine_tune_embeddings(True)
-        encoder = models.Encoder(emb_dim=cfg.emb_dim)
+        # fine-tuning needs the trunk's parameters to exist before encoder.fine_tune() and the encoder optimizer see them
+        # (a trunk built lazily by the first raw-image batch would be missing from the optimizer)
+        encoder = models.Encoder(emb_dim=cfg.emb_dim, with_trunk=True if cfg.fine_tune_encoder else None)
         decoder_optimizer = encoder_optimizer = None
     else:
         ck = ut.load_checkpoint(cfg.checkpoint, map_location=device)
@@ -198,6 +204,8 @@ def main(cfg=None):
             start_epoch, epochs_since_improvement, best_loss = ck["epoch"] + 1, ck["epochs_since_improvement"], ck["loss"]
     decoder.to(device)
     encoder.to(device)
+    if cfg.fine_tune_encoder and "resnet" not in encoder._modules:      # e.g. a checkpoint saved without the trunk
+        encoder._build_trunk()
     encoder.fine_tune(cfg.fine_tune_encoder)
     if cfg.fine_tune_encoder and encoder_optimizer is None:
         encoder_optimizer = torch.optim.Adam([p for p in encoder.parameters() if p.requires_grad], lr=cfg.encoder_lr)
@@ -213,6 +221,9 @@ def main(cfg=None):
             # back from the pickled optimizer (ours or one written by the reference, geo-aware/utils.py:32-46)
             step.load_state_dict(decoder_optimizer.state_dict())
             decoder_optimizer = None
+        # what the bucket does not cover (frozen Encoder.conv1 and trunk, frozen decoder parameters, buffers) also
+        # starts from rank 0's copy: every process initialised its own
+        dp.broadcast_module_state([encoder, decoder], _bucket_range(step))
     elif decoder_optimizer is None:
         decoder_optimizer = torch.optim.Adam([p for p in decoder.parameters() if p.requires_grad], lr=cfg.decoder_lr)
     criterion = nn.CrossEntropyLoss(ignore_index=word_map["<pad>"]).to(device)
@@ -240,7 +251,8 @@ def main(cfg=None):
         best_loss = min(last_loss, best_loss)
         epochs_since_improvement = 0 if is_best else epochs_since_improvement + 1
         history.append((tr, last_loss))
-        if step is not None and world > 1 and not dp.replicas_agree(step.flat_p):
+        if step is not None and world > 1 and not (dp.replicas_agree(step.flat_p) and
+                                                   dp.module_state_agrees([encoder, decoder], _bucket_range(step))):
             raise RuntimeError("data-parallel replicas diverged (epoch %d): parameters differ between ranks" % epoch)
         if rank == 0:
             opt = step.as_torch_optimizer() if step is not None else decoder_optimizer

@@ -245,6 +245,8 @@ int ick_caption_embed(const int64_t* captions, const int64_t* masks, const float
  *   of fc_predicate.weight[:, pred]  (the dense (B,L,3000) indicator and its GEMM,
  *   knowledge-aware/models.py:436, are never materialised).  fc_pred_wt is the TRANSPOSED weight,
  *   (num_pred, d) row-major, so one predicate is one contiguous row.  gate may be NULL.
+ * With fc_pred_wt == NULL and d == num_pred, `gate` receives the dense 0/1 predicate indicator (B,T,num_pred)
+ *   itself (the public get_context_indicators method returns it).
  * mode 0: teacher-forced (strictly-before semantics), mode 1: predict (whole buffer). */
 int ick_context_indicators(const int64_t* captions, const int64_t* facts, const float* fc_pred_wt,
                            const float* fc_pred_b, float* eib, float* gate, int32_t B, int32_t L,
@@ -350,6 +352,9 @@ typedef struct {
     int32_t start_token;
 } ick_beam_state;
 int ick_decode_select_beam(const ick_decode_ctx* ctx, const ick_beam_state* beam, int32_t pos, void* stream);
+/* 1 when ick_decode_select_beam handles `beam` hypotheses over Vx = V+K+F scores (beam <= 8 and
+ * beam^2 * ceil(Vx / 1024) <= 4096 candidates); callers check this BEFORE capturing a decode graph. */
+int ick_decode_beam_supported(int32_t Vx, int32_t beam);
 
 /* fused token-mean cross entropy over the packed rows of train.py
  * (pack_padded_sequence + CrossEntropyLoss(ignore_index=<pad>), geo-aware/train.py:275-281):

@@ -274,7 +274,7 @@ def context_indicators(cfg, captions, facts, K, out_length):
     subj = facts[:, :, 1].long()
     valid = (subj >= 0) & (subj < K)
     g = torch.gather(seen, 2, subj.clamp(0, K - 1).unsqueeze(1).expand(-1, seen.shape[1], -1))
-    eib = (g & valid.unsqueeze(1)).float()  # (B,T,F)
+    eib = (g & valid.unsqueeze(1)).to(torch.get_default_dtype())  # (B,T,F); float32 unless a test runs the oracle in float64
     pred = facts[:, :, 2].long()
     pi = torch.zeros(B, seen.shape[1], cfg.num_predicates)
     pi.scatter_reduce_(2, pred.unsqueeze(1).expand(-1, seen.shape[1], -1), eib, reduce="amax", include_self=True)

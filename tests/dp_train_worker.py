@@ -29,6 +29,14 @@ if __name__ == "__main__":
             steps.append(self)
 
     tr.TrainStep = Recording
+    mods = []
+    orig_bc = tr.dp.broadcast_module_state
+
+    def spy_bc(modules, *a, **k):
+        mods.extend(modules)
+        return orig_bc(modules, *a, **k)
+
+    tr.dp.broadcast_module_state = spy_bc
     cfg = tr.Config(variant="knowledge", data_dir=data_dir, data_name="toy", epochs=2, batch_size=4, workers=0,
                     print_freq=1000, fused=True, out_dir=out_dir if rank == 0 else os.path.join(out_dir, "r%d" % rank),
                     seed=5)
@@ -40,5 +48,7 @@ if __name__ == "__main__":
     torch.save({"hist": hist, "seen": seen}, os.path.join(out_dir, "rank%d.pt" % rank))
     import torch.distributed as dist
     torch.save(steps[-1].flat_p.detach().cpu().clone(), os.path.join(out_dir, "flat%d.pt" % rank))
+    # the frozen Encoder.conv1 is outside the bucket: it must have been broadcast too
+    torch.save(mods[0].conv1.weight.detach().cpu().clone(), os.path.join(out_dir, "conv%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()

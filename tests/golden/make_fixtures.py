@@ -171,9 +171,86 @@ def round2_cases():
                  with_grads=True, with_enc_grad=True)
 
 
+def digest_columns(Vx, V, n=128, seed=0):
+    """The score columns a big-vocabulary digest keeps: n seeded vocabulary columns + every pointer column."""
+    g = torch.Generator().manual_seed(seed)
+    cols = torch.randperm(V, generator=g)[:n].sort().values
+    return torch.cat([cols, torch.arange(V, Vx)])
+
+
+def big_vocab_digest(name, variant, B, L, K, V, Fn, seed):
+    """The reference's forward at a vocabulary too wide to store whole (cfg4: 64 x 20 x 50 071 floats = 256 MB): the
+    fixture keeps 128 sampled vocabulary columns, every pointer column, and per-row logsumexp / argmax / max over ALL
+    columns (any wrong vocabulary column moves the logsumexp or the argmax), plus the loss of train.py's criterion."""
+    dec, P, wm = build_reference_decoder(variant, V, seed)
+    batch = synth.make_batch(variant, B, L, K, V, Fn, seed)
+    enc_out = synth.make_enc_out(B, seed)
+    args = [batch["captions"], enc_out, batch["caption_masks"], batch["caption_lengths"], batch["entities"]]
+    if variant != "geo":
+        args.append(batch["facts"])
+    with torch.no_grad():
+        scores, caps_sorted, dl = dec(*args)
+        targets = caps_sorted[:, 1:]
+        sp = pack_padded_sequence(scores, dl, batch_first=True).data
+        tp = pack_padded_sequence(targets, dl, batch_first=True).data
+        loss = F.cross_entropy(sp, tp, ignore_index=wm["<pad>"])
+    Vx = scores.shape[2]
+    cols = digest_columns(Vx, V)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), variant=variant, B=B, L=L, K=K, V=V, F=Fn, seed=seed,
+                        param_checksum=checksum(P), cols=cols.numpy(), scores_cols=scores[:, :, cols].numpy(),
+                        lse=scores.double().logsumexp(dim=2).numpy(), argmax=scores.argmax(dim=2).numpy(),
+                        rowmax=scores.max(dim=2).values.numpy(), captions_sorted=caps_sorted.numpy(),
+                        decode_lengths=np.array(dl), loss=np.array([loss.item()]))
+    print("wrote", name, tuple(scores.shape), "loss", loss.item())
+
+
+def score_head_case(name, variant, B, L, K, V, Fn, seed):
+    """The public score-head methods called directly on the real reference (geo-aware/models.py:291-313,
+    knowledge-aware/models.py:380-455): get_context_indicators for the teacher-forced form (out_length = L), a
+    shorter out_length and predict()'s out_length = 1; get_scores on seeded h / encoded contexts."""
+    dec, P, wm = build_reference_decoder(variant, V, seed)
+    ref = sys.modules[type(dec).__module__] if type(dec).__module__ in sys.modules else None
+    batch = synth.make_batch(variant, B, L, K, V, Fn, seed)
+    g = torch.Generator().manual_seed(seed + 1000)
+    h = torch.randn(L, B, 300, generator=g)
+    ee = torch.randn(B, K, 300, generator=g) * 0.3
+    out = dict(variant=variant, B=B, L=L, K=K, V=V, F=Fn, seed=seed, param_checksum=checksum(P), h=h.numpy(),
+               ee=ee.numpy())
+    with torch.no_grad():
+        if variant == "geo":
+            out["scores"] = dec.get_scores(h, ee).numpy()
+        else:
+            fe = torch.randn(B, Fn, 300, generator=g) * 0.3
+            out["fe"] = fe.numpy()
+            caps, facts = batch["captions"], batch["facts"].clone()
+            facts[:, :, 2] %= 3        # many facts share a predicate: the indicator must count a predicate once
+            for tag, ol in (("full", L), ("short", L - 3), ("one", 1)):
+                eib, pi = dec.get_context_indicators(caps, facts, K, ol)
+                out["eib_" + tag] = eib.numpy().astype(np.uint8)
+                out["pi_" + tag] = np.packbits(pi.numpy().astype(np.uint8), axis=2)      # (B, ol, ceil(NP/8), 1)
+            eib, pi = dec.get_context_indicators(caps, facts, K, L)
+            out["scores"] = dec.get_scores(h, ee, fe, eib, pi).numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, out["scores"].shape)
+
+
+def round3_cases():
+    """Added in round 3: the public get_scores / get_context_indicators methods, and digests of the reference's
+    forward at the vocabulary sizes the bench quotes (cfg4 at its full batch, the news variant at V = 50 000)."""
+    score_head_case("score_head_geo", "geo", B=3, L=6, K=7, V=80, Fn=0, seed=23)
+    score_head_case("score_head_knowledge", "knowledge", B=4, L=12, K=6, V=70, Fn=8, seed=32)
+    score_head_case("score_head_news", "news", B=3, L=12, K=5, V=60, Fn=7, seed=30)
+    c = synth.CONFIGS["cfg4"]
+    big_vocab_digest("digest_cfg4_b64", c["variant"], c["B"], c["L"], c["K"], c["V"], c["F"], seed=41)
+    big_vocab_digest("digest_news_v50k", "news", B=8, L=20, K=51, V=50000, Fn=51, seed=42)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(4)
+    if "--round3" in sys.argv:
+        round3_cases()
+        sys.exit(0)
     if "--round2" in sys.argv:
         round2_cases()
         sys.exit(0)

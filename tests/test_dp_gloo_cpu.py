@@ -194,3 +194,40 @@ def test_fused_step_state_is_torch_adam_layout():
     p0.data = p0.data.clone()
     with pytest.raises(IckError):
         ts2._check_views()
+
+
+# ------------------------------------------------------------------------------------------------ round 3
+def _state_worker(rank, world, port, out):
+    """Each rank builds an Encoder.conv1 stand-in and a module with a frozen parameter + a buffer from its OWN seed; the
+    part of the state that lives in the 'bucket' range is skipped, everything else must end as rank 0's copy."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    import ick_amd.dp as dp
+    dp.init_from_env(backend="gloo")
+    torch.manual_seed(100 + rank)
+    enc = torch.nn.Conv2d(8, 4, 1)
+    dec = torch.nn.Linear(6, 3)
+    dec.weight.requires_grad = False
+    dec.register_buffer("pe", torch.randn(5, 3))
+    bucket = torch.randn(64)                                   # stands for TrainStep.flat_p
+    dec.bias.data = bucket[:3]
+    rng = (bucket.data_ptr(), bucket.data_ptr() + 4 * bucket.numel())
+    before = dp.module_state_agrees([enc, dec], rng)
+    n = dp.broadcast_module_state([enc, dec], rng)
+    after = dp.module_state_agrees([enc, dec], rng)
+    torch.save({"before": before, "after": after, "n": n, "conv": enc.weight.detach().clone(), "pe": dec.pe.clone(),
+                "w": dec.weight.detach().clone(), "bias": dec.bias.detach().clone()}, out + str(rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_broadcast_of_state_outside_the_bucket(tmp_path):
+    out = str(tmp_path / "st")
+    mp.spawn(_state_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + "0"), torch.load(out + "1")
+    assert not r0["before"] and not r1["before"]               # per-rank seeds: the replicas start different
+    assert r0["after"] and r1["after"] and r0["n"] == r1["n"] == 4   # conv weight, conv bias, frozen weight, buffer
+    for k in ("conv", "pe", "w"):
+        assert torch.equal(r0[k], r1[k]), k
+    assert not torch.equal(r0["bias"], r1["bias"])             # inside the bucket range: left to TrainStep's broadcast

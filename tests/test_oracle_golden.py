@@ -135,3 +135,62 @@ def test_stock_module_predict_matches_reference(name):
         facts = synth.make_facts(variant, 1, Fn, K, seed) if variant != "geo" else None
         seq = m.predict(synth.make_enc_out(1, seed), max_len, ents, facts)
         assert seq.view(-1).tolist() == g["seq_%d" % seed].reshape(-1).tolist(), (name, seed)
+
+
+# ------------------------------------------------------------------------------------------------ round 3 fixtures
+def check_digest(g, scores, tol=TOL):
+    """A big-vocabulary digest of the real reference (make_fixtures.big_vocab_digest) against full scores."""
+    cols = t(g["cols"])
+    assert (scores[:, :, cols].cpu() - t(g["scores_cols"])).abs().max().item() < tol
+    assert (scores.double().logsumexp(dim=2).cpu() - t(g["lse"])).abs().max().item() < tol
+    assert (scores.max(dim=2).values.cpu() - t(g["rowmax"])).abs().max().item() < tol
+    am = scores.argmax(dim=2).cpu()
+    ref_am = t(g["argmax"])
+    if not torch.equal(am, ref_am):      # a flipped arg-max must be a rounding-level tie
+        bad = (am != ref_am).nonzero()
+        for b, l in bad.tolist():
+            assert abs(scores[b, l, am[b, l]].item() - scores[b, l, ref_am[b, l]].item()) < tol
+        assert len(bad) <= 2
+
+
+@pytest.mark.parametrize("name", ["digest_cfg4_b64", "digest_news_v50k"])
+def test_big_vocab_digest(name):
+    """The oracle at the sizes the bench quotes for cfg4 (B = 64, V = 50 000, F = 51) and for the news variant at
+    V = 50 000, against digests of the real reference's forward."""
+    g = load_golden(name)
+    cfg, P, wm, batch, enc_out = case_from_golden(g)
+    with torch.no_grad():
+        scores, caps, dl = R.forward(cfg, P, batch["captions"], enc_out, batch["caption_masks"],
+                                     batch["caption_lengths"], batch["entities"], batch.get("facts"))
+        loss = R.packed_ce_loss(cfg, scores, caps, dl)
+    assert dl == g["decode_lengths"].tolist() and torch.equal(caps, t(g["captions_sorted"]))
+    check_digest(g, scores)
+    assert abs(loss.item() - float(g["loss"][0])) < 1e-5
+
+
+def unpack_pi(g, tag, num_pred):
+    return t(np.unpackbits(g["pi_" + tag], axis=2)[:, :, :num_pred]).float()
+
+
+@pytest.mark.parametrize("name", ["score_head_geo", "score_head_knowledge", "score_head_news"])
+def test_score_head_methods(name):
+    """get_context_indicators / get_scores called directly on the real reference."""
+    g = load_golden(name)
+    variant = str(g["variant"])
+    B, L, K, V, Fn, seed = (int(g[k]) for k in ("B", "L", "K", "V", "F", "seed"))
+    P = synth.make_params(variant, V, seed)
+    cfg = R.config_from_word_map(variant, synth.make_word_map(V))
+    h, ee = t(g["h"]).permute(1, 0, 2), t(g["ee"])
+    ref = t(g["scores"]).permute(1, 0, 2)
+    if variant == "geo":
+        assert (R.get_scores(cfg, P, h, ee) - ref).abs().max().item() < TOL
+        return
+    batch = synth.make_batch(variant, B, L, K, V, Fn, seed)
+    batch["facts"][:, :, 2] %= 3                  # as the fixture: many facts share a predicate
+    for tag, ol in (("full", L), ("short", L - 3), ("one", 1)):
+        eib, pi = R.context_indicators(cfg, batch["captions"], batch["facts"], K, ol)
+        assert torch.equal(eib, t(g["eib_" + tag]).float().squeeze(3)), tag
+        assert torch.equal(pi, unpack_pi(g, tag, cfg.num_predicates).squeeze(3)), tag
+    eib, pi = R.context_indicators(cfg, batch["captions"], batch["facts"], K, L)
+    assert eib.sum() > pi.sum() > 0              # the case exercises the indicators and shared predicates
+    assert (R.get_scores(cfg, P, h, ee, t(g["fe"]), eib, pi) - ref).abs().max().item() < TOL

@@ -134,6 +134,7 @@ def test_two_rank_train_main(tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
     f0, f1 = torch.load(tmp_path / "flat0.pt"), torch.load(tmp_path / "flat1.pt")
     assert f0 is not None and torch.equal(f0, f1)                                  # bit-identical replicas
+    assert torch.equal(torch.load(tmp_path / "conv0.pt"), torch.load(tmp_path / "conv1.pt"))   # frozen conv1 too
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert r0["hist"] == r1["hist"] or all(abs(a[1] - b[1]) < 1e-9 for a, b in zip(r0["hist"], r1["hist"]))  # same val loss
     assert len(r0["seen"]) == len(r1["seen"]) > 0                                  # same number of steps on both ranks
