@@ -28,6 +28,9 @@
 // depend on it), so a kernel is ~3 memory round trips long.
 #include "common.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 // Diagnostic build (-DICK_DECODE_STAMPS, tools/debug/decode_stamps.py): workgroup (0, 0) of every decode kernel
 // records the shader clock at its phase boundaries.  Compiled out of the product library.
 #ifdef ICK_DECODE_STAMPS
@@ -48,9 +51,13 @@ namespace {
 
 constexpr int kDMax = 320;   // model width limit of this path: 5 float4 per lane of a 16-lane row group
 constexpr int kD4Max = kDMax / 4;
-constexpr int kSMax = 1024;  // memory rows whose scores fit the LDS score buffer
+constexpr int kSMax = 1024;  // memory rows (cross-attention keys)
 constexpr int kMLMax = 128;  // caption positions (self-attention keys)
 constexpr int kDhp = 32;     // padded head width of the head-major K/V layouts
+constexpr int kPartsMax = 16;
+constexpr int kNumCU = 256;
+
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 struct RowSrc {
     const float* res;     // (R, d) residual rows; the input itself when nparts == 0
@@ -63,80 +70,49 @@ struct RowSrc {
     float eps;
 };
 
-// x = LayerNorm(res + bias + sum partials) (or res itself) -> xs[0..kDMax) in LDS, zero beyond d.
-// issue() only starts the loads; the kernels issue them FIRST and their large weight / K / V streams afterwards:
-// vector-memory results return in issue order, so the row is normalised (finish()) and projected while the streams
-// are still arriving.  Every partial row is loaded before the first add (a `for (p < nparts)` load-add loop would wait
-// for each load in turn: ten dependent L2 round trips); the partial rows are then summed in index order.
-constexpr int kPartsMax = 16;
-// The np + 2 rows to add (residual, bias, partials) are dealt out to G = min(4, 256 / (d/4)) thread groups as float4
-// columns: at most 6 + 2 sixteen-byte loads per thread (one dword per element would be 40 load instructions per thread
-// -- with the weight stream behind them more than the 63 a wave can keep in flight, which stalls the issue itself).
-struct RowIn {
-    float4 acc, gm, bt;
-    float4 pv[6];
-    __device__ __forceinline__ void issue(const RowSrc& s, int64_t row, int d) {
-        const int tid = threadIdx.x, np = s.nparts, d4 = d >> 2;
-        const int G = min(256 / d4, 4);
-        const int g = min(tid / d4, G - 1), c4 = min(tid - g * d4, d4 - 1);
-        const int nrows = np > 0 ? np + 2 : 1;
-        gm = bt = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (np > 0) {
-            gm = reinterpret_cast<const float4*>(s.gamma)[c4];
-            bt = reinterpret_cast<const float4*>(s.beta)[c4];
-        }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int q = min(g + G * j, nrows - 1);          // row 0: residual, 1: bias, 2 + p: partial p
-            const float* src = q == 0 ? s.res + row * d : (q == 1 ? s.bias : s.part + (row * np + (q - 2)) * d);
-            pv[j] = reinterpret_cast<const float4*>(src)[c4];
-        }
-    }
-    // scratch: LDS float4[4 * d/4] (the out-projection's exchange buffer, free at this point)
-    __device__ __forceinline__ void finish(const RowSrc& s, int64_t row, int d, float* xs, float* red, float4* scratch,
-                                           bool writer) {
-        const int tid = threadIdx.x, np = s.nparts, d4 = d >> 2;
-        const int G = min(256 / d4, 4);
-        const int g = tid / d4, c4 = tid - g * d4;
-        const int nrows = np > 0 ? np + 2 : 1;
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g < G) {
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                if (g + G * j < nrows) { t.x += pv[j].x; t.y += pv[j].y; t.z += pv[j].z; t.w += pv[j].w; }
-            }
-            scratch[g * d4 + c4] = t;
-        }
-        __syncthreads();
-        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tid < d4) {
-            z = scratch[tid];
-            for (int gg = 1; gg < G; ++gg) {
-                const float4 u = scratch[gg * d4 + tid];
-                z.x += u.x; z.y += u.y; z.z += u.z; z.w += u.w;
-            }
-        }
-        if (np > 0) {
-            const float mean = block_sum<4>((z.x + z.y) + (z.z + z.w), red) / (float)d;
-            float v = 0.f;
-            if (tid < d4) {
-                v = fmaf(z.x - mean, z.x - mean, v); v = fmaf(z.y - mean, z.y - mean, v);
-                v = fmaf(z.z - mean, z.z - mean, v); v = fmaf(z.w - mean, z.w - mean, v);
-            }
-            const float rstd = rsqrtf(block_sum<4>(v, red) / (float)d + s.eps);
-            z.x = (z.x - mean) * rstd * gm.x + bt.x; z.y = (z.y - mean) * rstd * gm.y + bt.y;
-            z.z = (z.z - mean) * rstd * gm.z + bt.z; z.w = (z.w - mean) * rstd * gm.w + bt.w;
-        }
-        if (tid < kD4Max) reinterpret_cast<float4*>(xs)[tid] = tid < d4 ? z : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (writer && s.out != nullptr && tid < d4) reinterpret_cast<float4*>(s.out + row * d)[tid] = z;
-        __syncthreads();
-    }
-};
+// What bounds these kernels (in-kernel stamps + ISA counts, round 3): NOT the bytes -- a workgroup of four waves has one
+// wave per SIMD, and a lone wave issues one instruction per ~4 cycles whatever its type; ~1500 instructions of address
+// arithmetic, loads and reductions in front of the first barrier were 5-6 k cycles.  Hence: (1) 512-thread workgroups
+// (two waves per SIMD share the issue slots, every wave holds half the weight registers: no accumulator-file spills,
+// whose copies wait for the loads they copy); (2) the wave index is read with readfirstlane, so row and weight base
+// addresses are scalar and the loads take the scalar-base + 32-bit-offset form; (3) no branch per source row: clamped
+// loads weighted by 0 / 1; (4) the early-exit word is waited for after the loads have been issued.
+constexpr int kNT = 512;           // threads of a block kernel
+constexpr int kNW = kNT / 64;      // waves
+
+// Workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with its own L2 that starts a kernel cold.
+// The (weight slice, row group) units are therefore numbered so that the workgroups of one XCD are CONSECUTIVE units,
+// slice-major: an XCD then pulls 2-3 heads' weights (or one FFN chunk) through its L2 instead of all of them -- the
+// beyond-L2 traffic of a decode step drops from ~146 MB to ~82 MB.  Placement affects speed only, never results.
+__device__ __forceinline__ void xcd_unit(int& slice, int& group, int ngroups) {
+    const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = lin & 7, slot = lin >> 3;
+    const int u = xcd * (nwg >> 3) + min(xcd, nwg & 7) + slot;          // XCD x owns units [start_x, start_x + count_x)
+    slice = u / ngroups;
+    group = u - slice * ngroups;
+}
+
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// uniform base + 32-bit byte offset: global_load_dwordx4 v, v_off, s[base:base+1]
+__device__ __forceinline__ float4 ld4o(const float* base, uint32_t byteoff) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byteoff);
+}
+__device__ __forceinline__ float4 ld4o_stream(const float* base, uint32_t byteoff) {   // read once per step by one workgroup
+#ifdef ICK_DECODE_NT_KV
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byteoff));
+    return make_float4(v[0], v[1], v[2], v[3]);
+#else
+    return ld4o(base, byteoff);
+#endif
+}
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void f4add(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 
 // Lane exchanges inside a row of 16 lanes as DPP operands (one VALU instruction each) instead of ds_bpermute round
 // trips through the LDS crossbar (~100 cycles each, four in a row per dot product): quad_perm [1,0,3,2] / [2,3,0,1]
 // pair lanes inside a quad, row_half_mirror / row_mirror then pair quads and halves (every lane of a quad / half
-// already holds the same partial result), row_ror:8 swaps the halves of a row.
+// already holds the same partial result), row_ror:8 swaps the halves of a row.  Full waves only (common.h).
 template <int CTRL>
 __device__ __forceinline__ float dppf(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
@@ -153,82 +129,223 @@ __device__ __forceinline__ float sum16(float v) { v = sum8(v); v += dppf<kDppMir
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
     return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
 }
+// two-lane packed form (v_pk_fma_f32): the even and odd elements run as two independent chains
+__device__ __forceinline__ f32x2 pkfma(const float4& a, const float4& b, f32x2 acc) {
+    acc = __builtin_elementwise_fma(f32x2{a.x, a.y}, f32x2{b.x, b.y}, acc);
+    return __builtin_elementwise_fma(f32x2{a.z, a.w}, f32x2{b.z, b.w}, acc);
+}
 
-// Dot products of up to 16 * NPASS weight rows (k contiguous) with the LDS vector xs: 16 lanes per row, four
-// rows per wave and pass.  load() only issues the weight loads (nothing depends on xs), run() consumes them.
+// ---------------------------------------------------------------------------------------------------------
+// "LN-on-load" of the G rows of a workgroup: x = LayerNorm(res + bias + sum_p partial_p) (or res itself when the source
+// has no partial rows).  The NWAVES / G waves of a row each fetch and sum a slice of its source rows (residual, bias,
+// partial 0, 1, ...: lane l holds float4 columns l and 64 + l), leave the slice sums in LDS, and after one barrier the
+// row's first wave adds them in slice order and normalises: mean and variance are wave reductions (DPP + v_readlane).
+// issue() only starts the loads -- the kernels issue them FIRST and their weight / K / V streams afterwards: vector-memory
+// results return in issue order, so the rows are normalised while the streams are still arriving.  Every base address
+// is wave-uniform (scalar); sums run in a fixed order: deterministic.
+// ---------------------------------------------------------------------------------------------------------
+template <int G, int NWAVES>
+struct RowGather {
+    static constexpr int WPR = NWAVES / G;                                  // waves per row (G = 3, 5: some waves idle)
+    static constexpr int NS = (12 + WPR - 1) / WPR < 6 ? (12 + WPR - 1) / WPR : 6;   // source rows per wave and sweep
+    float4 a[NS], b[NS];
+    float4 gm0, gm1, bt0, bt1;
+
+    __device__ __forceinline__ static const float* src_row(const RowSrc& s, int64_t row, int d, int q) {
+        return q == 0 ? s.res + row * d : (q == 1 ? s.bias : s.part + (row * s.nparts + (q - 2)) * d);
+    }
+    // source rows q0 .. q0 + NS - 1 of `row` (past the last: a copy of it, weighted 0 by the sum)
+    __device__ __forceinline__ void sweep(const RowSrc& s, int64_t row, int d, int q0, int nrows) {
+        const int lane = threadIdx.x & 63, d4 = d >> 2;
+        const uint32_t o0 = 16u * (uint32_t)min(lane, d4 - 1), o1 = 16u * (uint32_t)min(64 + lane, d4 - 1);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const float* src = src_row(s, row, d, min(q0 + j, nrows - 1));
+            a[j] = ld4o(src, o0);
+            if (d4 > 64) b[j] = ld4o(src, o1);
+        }
+    }
+    __device__ __forceinline__ void issue(const RowSrc& s, int64_t r0, int R, int d) {
+        const int lane = threadIdx.x & 63, wave = wave_id(), d4 = d >> 2;
+        if (wave >= G * WPR) return;
+        const int g = wave / WPR, wr = wave - g * WPR;
+        const int64_t row = min(r0 + g, (int64_t)R - 1);
+        const uint32_t o0 = 16u * (uint32_t)min(lane, d4 - 1), o1 = 16u * (uint32_t)min(64 + lane, d4 - 1);
+        const int nrows = s.nparts > 0 ? s.nparts + 2 : 1;
+        if (wr * NS < nrows) sweep(s, row, d, wr * NS, nrows);              // this slice holds source rows (uniform)
+        gm0 = gm1 = bt0 = bt1 = f4zero();
+        if (wr == 0 && s.nparts > 0) {
+            gm0 = ld4o(s.gamma, o0); bt0 = ld4o(s.beta, o0);
+            if (d4 > 64) { gm1 = ld4o(s.gamma, o1); bt1 = ld4o(s.beta, o1); }
+        }
+    }
+    // psum: LDS float4 [G][WPR][kD4Max]; follow with a barrier
+    __device__ __forceinline__ void slice_sums(const RowSrc& s, int64_t r0, int R, int d, float4* psum) {
+        const int lane = threadIdx.x & 63, wave = wave_id(), d4 = d >> 2;
+        if (wave >= G * WPR) return;
+        const int g = wave / WPR, wr = wave - g * WPR;
+        const bool wide = d4 > 64;
+        const int nrows = s.nparts > 0 ? s.nparts + 2 : 1;
+        f32x2 z0l = {0.f, 0.f}, z0h = {0.f, 0.f}, z1l = {0.f, 0.f}, z1h = {0.f, 0.f};
+        for (int q0 = wr * NS; q0 < nrows; q0 += WPR * NS) {               // one sweep unless the source has > 12 rows
+            if (q0 >= WPR * NS) sweep(s, min(r0 + g, (int64_t)R - 1), d, q0, nrows);
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const float f = q0 + j < nrows ? 1.f : 0.f;                 // scalar
+                const f32x2 ff = {f, f};
+                z0l = __builtin_elementwise_fma(f32x2{a[j].x, a[j].y}, ff, z0l);
+                z0h = __builtin_elementwise_fma(f32x2{a[j].z, a[j].w}, ff, z0h);
+                if (wide) {
+                    z1l = __builtin_elementwise_fma(f32x2{b[j].x, b[j].y}, ff, z1l);
+                    z1h = __builtin_elementwise_fma(f32x2{b[j].z, b[j].w}, ff, z1h);
+                }
+            }
+        }
+        float4* dst = psum + (g * WPR + wr) * kD4Max;
+        dst[lane] = make_float4(z0l.x, z0l.y, z0h.x, z0h.y);
+        if (lane < kD4Max - 64) dst[64 + lane] = make_float4(z1l.x, z1l.y, z1h.x, z1h.y);
+    }
+    // after the barrier: the first wave of every row normalises it into xs[g] (LDS, kDMax floats, zero beyond d) and,
+    // when `writer`, into s.out; follow with a barrier
+    __device__ __forceinline__ void finish(const RowSrc& s, int64_t r0, int R, int d, const float4* psum, float* xs,
+                                           bool writer) {
+        const int lane = threadIdx.x & 63, wave = wave_id(), d4 = d >> 2;
+        if (wave >= G * WPR) return;
+        const int g = wave / WPR, wr = wave - g * WPR;
+        if (wr != 0) return;
+        const int64_t row = min(r0 + g, (int64_t)R - 1);
+        const bool ok0 = lane < d4, ok1 = 64 + lane < d4;
+        const int l1 = min(64 + lane, kD4Max - 1);
+        float4 z0 = psum[g * WPR * kD4Max + lane], z1 = psum[g * WPR * kD4Max + l1];
+#pragma unroll
+        for (int w = 1; w < WPR; ++w) {
+            f4add(z0, psum[(g * WPR + w) * kD4Max + lane]);
+            f4add(z1, psum[(g * WPR + w) * kD4Max + l1]);
+        }
+        if (!ok0) z0 = f4zero();
+        if (!ok1) z1 = f4zero();
+        if (s.nparts > 0) {
+            const float mean = wave_sum(((z0.x + z0.y) + (z0.z + z0.w)) + ((z1.x + z1.y) + (z1.z + z1.w))) / (float)d;
+            float v = 0.f;
+            if (ok0) {
+                v = fmaf(z0.x - mean, z0.x - mean, v); v = fmaf(z0.y - mean, z0.y - mean, v);
+                v = fmaf(z0.z - mean, z0.z - mean, v); v = fmaf(z0.w - mean, z0.w - mean, v);
+            }
+            if (ok1) {
+                v = fmaf(z1.x - mean, z1.x - mean, v); v = fmaf(z1.y - mean, z1.y - mean, v);
+                v = fmaf(z1.z - mean, z1.z - mean, v); v = fmaf(z1.w - mean, z1.w - mean, v);
+            }
+            const float rstd = rsqrtf(wave_sum(v) / (float)d + s.eps);
+            z0.x = (z0.x - mean) * rstd * gm0.x + bt0.x; z0.y = (z0.y - mean) * rstd * gm0.y + bt0.y;
+            z0.z = (z0.z - mean) * rstd * gm0.z + bt0.z; z0.w = (z0.w - mean) * rstd * gm0.w + bt0.w;
+            z1.x = (z1.x - mean) * rstd * gm1.x + bt1.x; z1.y = (z1.y - mean) * rstd * gm1.y + bt1.y;
+            z1.z = (z1.z - mean) * rstd * gm1.z + bt1.z; z1.w = (z1.w - mean) * rstd * gm1.w + bt1.w;
+            if (!ok0) z0 = f4zero();
+            if (!ok1) z1 = f4zero();
+        }
+        float* x = xs + g * kDMax;
+        reinterpret_cast<float4*>(x)[lane] = z0;
+        if (lane < kD4Max - 64) reinterpret_cast<float4*>(x)[64 + lane] = z1;
+        if (writer && r0 + g < R && s.out != nullptr) {
+            if (ok0) reinterpret_cast<float4*>(s.out + row * d)[lane] = z0;
+            if (ok1) reinterpret_cast<float4*>(s.out + row * d)[64 + lane] = z1;
+        }
+    }
+};
+
+// Dot products of up to 4 * kNW * NPASS weight rows (k contiguous) with the G LDS vectors xs[g]: 16 lanes per weight
+// row, four weight rows per wave and pass; the weights stay in registers for all G rows.  load() only issues the weight
+// loads (nothing depends on xs), run() consumes them.  rowoff(r): element offset of weight row r (and bias index
+// bidx(r)); both are evaluated per lane on 32-bit integers.
 template <int NPASS>
 struct RowDot {
     float4 w[NPASS][5];
     float bv[NPASS];
     template <typename RowIdx>
-    __device__ __forceinline__ void load(const float* __restrict__ W, const float* __restrict__ bias, int64_t ld,
+    __device__ __forceinline__ void load(const float* __restrict__ W, const float* __restrict__ bias, int ld,
                                          RowIdx rowidx, int nrows, int d4) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane >> 4, i = lane & 15;
+        const int lane = threadIdx.x & 63, wave = wave_id(), sub = lane >> 4, i = lane & 15;
+        uint32_t col[5];
+#pragma unroll
+        for (int it = 0; it < 5; ++it) col[it] = 16u * (uint32_t)min(i + 16 * it, d4 - 1);     // beyond d: xs is zero there
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
-            const int r = min(16 * p + 4 * wave + sub, nrows - 1);
-            const float4* wr = reinterpret_cast<const float4*>(W + (int64_t)rowidx(r) * ld);
+            const int r = min(4 * kNW * p + 4 * wave + sub, nrows - 1);
+            const uint32_t ri = (uint32_t)rowidx(r);
+            const uint32_t ro = ri * (uint32_t)ld * 4u;
 #pragma unroll
-            for (int it = 0; it < 5; ++it) w[p][it] = wr[min(i + 16 * it, d4 - 1)];   // beyond d: xs is zero there
-            bv[p] = bias ? bias[rowidx(r)] : 0.f;     // fetched with the weights: a load inside run() would stall it
+            for (int it = 0; it < 5; ++it) w[p][it] = ld4o(W, ro + col[it]);
+            bv[p] = bias ? bias[ri] : 0.f;     // fetched with the weights: a load inside run() would stall it
         }
     }
-    // ys[r] = (dot(W[rowidx(r)], xs) + bias[rowidx(r)]) * scale
-    __device__ __forceinline__ void run(const float* xs, int nrows, float* ys, float scale = 1.f) const {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane >> 4, i = lane & 15;
-        float4 xr[5];
+    // ys[g * ystride + r] = (dot(W[rowidx(r)], xs[g]) + bias[rowidx(r)]) * scale   (relu: max(., 0))
+    template <int G>
+    __device__ __forceinline__ void run(const float* xs, int nrows, float* ys, int ystride, float scale, bool relu) const {
+        const int lane = threadIdx.x & 63, wave = wave_id(), sub = lane >> 4, i = lane & 15;
 #pragma unroll
-        for (int it = 0; it < 5; ++it) xr[it] = reinterpret_cast<const float4*>(xs)[i + 16 * it];
+        for (int g = 0; g < G; ++g) {
+            float4 xr[5];
 #pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-            float acc = 0.f;
+            for (int it = 0; it < 5; ++it) xr[it] = reinterpret_cast<const float4*>(xs + g * kDMax)[i + 16 * it];
 #pragma unroll
-            for (int it = 0; it < 5; ++it) acc += dot4(w[p][it], xr[it]);
-            acc = sum16(acc);
-            const int r = 16 * p + 4 * wave + sub;
-            if (i == 0 && r < nrows) ys[r] = (acc + bv[p]) * scale;
+            for (int p = 0; p < NPASS; ++p) {
+                f32x2 acc = {0.f, 0.f};
+#pragma unroll
+                for (int it = 0; it < 5; ++it) acc = pkfma(w[p][it], xr[it], acc);
+                const float t = sum16(acc.x + acc.y);
+                const int r = 4 * kNW * p + 4 * wave + sub;
+                if (i == 0 && r < nrows) {
+                    const float y = (t + bv[p]) * scale;
+                    ys[g * ystride + r] = relu ? fmaxf(y, 0.f) : y;
+                }
+            }
         }
     }
 };
 
-// out[n] = sum_{j < nj} o[j] * Wt[(j0 + j) * ld + n] for n < d (Wt = transposed weight: one k per row, n contiguous).
-// G = min(4, 256 / (d/4)) thread groups take every G-th j (nj <= 3 * JMAX); their float4 partial sums meet in LDS.
-// o[] must be zero for nj <= j < G * JMAX.
+// out[g][n] = sum_{j < nj} o[g][j] * Wt[(j0 + j) * ld + n] for n < d (Wt = transposed weight: one k per row, n
+// contiguous).  NG = min(8, kNT / (d/4)) thread groups take every NG-th j (nj <= NG * JMAX); their float4 partial
+// sums meet in LDS.  o[g][.] must be zero for nj <= j < NG * JMAX.
 template <int JMAX>
 struct ColDot {
     float4 w[JMAX];
-    __device__ __forceinline__ void load(const float* __restrict__ Wt, int64_t ld, int j0, int nj, int d4) {
-        const int G = min(256 / d4, 4);
-        const int g = min((int)threadIdx.x / d4, G - 1), c = threadIdx.x - g * d4 < d4 ? threadIdx.x - g * d4 : 0;
+    __device__ __forceinline__ void load(const float* __restrict__ Wt, int ld, int j0, int nj, int d4) {
+        const int NG = min(kNT / d4, 8);
+        const int tid = threadIdx.x;
+        const int grp = min(tid / d4, NG - 1), c = tid - grp * d4 < d4 ? tid - grp * d4 : 0;
+        const uint32_t co = 16u * (uint32_t)c;
 #pragma unroll
         for (int jj = 0; jj < JMAX; ++jj) {
-            const int j = min(g + G * jj, nj - 1);
-            w[jj] = reinterpret_cast<const float4*>(Wt + (int64_t)(j0 + j) * ld)[c];
+            const int j = min(grp + NG * jj, nj - 1);
+            w[jj] = ld4o(Wt, (uint32_t)(j0 + j) * (uint32_t)ld * 4u + co);
         }
     }
-    // part: LDS float4[G * d4]; out: global row (d floats)
-    __device__ __forceinline__ void run(const float* o, int d4, float4* part, float* __restrict__ out) const {
-        const int G = min(256 / d4, 4);
+    // o: LDS [G][ostride]; part: LDS float4[NG * G * d4] (<= G * kNT); out row g at out + g * out_gs floats, rows g >= nvalid skipped
+    template <int G>
+    __device__ __forceinline__ void run(const float* o, int ostride, int d4, float4* part, float* __restrict__ out,
+                                        int64_t out_gs, int nvalid) const {
+        const int NG = min(kNT / d4, 8);
         const int tid = threadIdx.x;
-        const int g = tid / d4, c = tid - g * d4;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g < G) {
+        const int grp = tid / d4, c = tid - grp * d4;
+        if (grp < NG) {
 #pragma unroll
-            for (int jj = 0; jj < JMAX; ++jj) {
-                const float oj = o[g + G * jj];
-                acc.x = fmaf(oj, w[jj].x, acc.x); acc.y = fmaf(oj, w[jj].y, acc.y);
-                acc.z = fmaf(oj, w[jj].z, acc.z); acc.w = fmaf(oj, w[jj].w, acc.w);
+            for (int g = 0; g < G; ++g) {
+                f32x2 lo = {0.f, 0.f}, hi = {0.f, 0.f};
+#pragma unroll
+                for (int jj = 0; jj < JMAX; ++jj) {
+                    const float oj = o[g * ostride + grp + NG * jj];
+                    lo = __builtin_elementwise_fma(f32x2{oj, oj}, f32x2{w[jj].x, w[jj].y}, lo);
+                    hi = __builtin_elementwise_fma(f32x2{oj, oj}, f32x2{w[jj].z, w[jj].w}, hi);
+                }
+                part[(grp * G + g) * d4 + c] = make_float4(lo.x, lo.y, hi.x, hi.y);
             }
-            part[g * d4 + c] = acc;
         }
         __syncthreads();
-        if (tid < d4) {
-            float4 s = part[tid];
-            for (int gg = 1; gg < G; ++gg) {
-                const float4 t = part[gg * d4 + tid];
-                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-            }
-            reinterpret_cast<float4*>(out)[tid] = s;
+        for (int idx = tid; idx < G * d4; idx += kNT) {
+            const int g = idx / d4, t = idx - g * d4;
+            float4 s = part[g * d4 + t];
+            for (int gg = 1; gg < NG; ++gg) f4add(s, part[(gg * G + g) * d4 + t]);
+            if (g < nvalid) reinterpret_cast<float4*>(out + g * out_gs)[t] = s;
         }
     }
 };
@@ -242,58 +359,91 @@ __device__ __forceinline__ float4 mask_cols(float4 v, int c, int dh) {   // zero
     return v;
 }
 
-// softmax(q . K^T) V for one (row, head) with the keys / values already in registers: thread (p8 = tid >> 3,
-// c = tid & 7) holds float4 c of positions p0 + 32 q + p8 (q < NP).  Scores never touch LDS; two exchanges between
-// the four waves (running maximum, then sum + weighted values) instead of one barrier per phase.  kreg / vreg must be
-// masked (pad columns zero).  Result: o[0 .. 31] in LDS (zero beyond dh), valid after the function returns.
-template <int NP>
-__device__ __forceinline__ void attend_regs(const float4 (&kreg)[NP], const float4 (&vreg)[NP], const float4& q4, int S,
-                                            int dh, float scale, float* red, float4* pvred, float* o) {
-    const int tid = threadIdx.x, p8 = tid >> 3, c = tid & 7, wave = tid >> 6;
-    float sc[NP];
-    float m = -INFINITY;
+// ---------------------------------------------------------------------------------------------------------
+// Attention of one WAVE over a range of key / value rows: lane (p8 = lane >> 3, c = lane & 7) holds float4 c of the
+// positions p0 + 8 q + p8 (q < NPC) of a chunk in registers.  Scores, softmax and P.V never touch LDS and need no
+// barrier; a range longer than one chunk (8 * NPC positions) continues with a running maximum (the usual rescaling of
+// the sums; with one chunk it is the plain two-pass softmax).  NQ query rows can share the same keys / values (beam
+// search: the hypotheses of a caption).
+// ---------------------------------------------------------------------------------------------------------
+template <int NPC>
+struct KVRegs {
+    float4 k[NPC], v[NPC];
+    // offk(p) / offv(p): byte offset (from kbase / vbase, both wave-uniform) of the 32-float row of position p < len
+    template <bool STREAM, typename OffK, typename OffV>
+    __device__ __forceinline__ void load(const float* kbase, const float* vbase, int p0, int len, OffK offk, OffV offv) {
+        const int lane = threadIdx.x & 63, p8 = lane >> 3, c = lane & 7;
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        const float s = sum8(dot4(q4, kreg[q]));
-        sc[q] = 32 * q + p8 < S ? s * scale : -INFINITY;
-        m = fmaxf(m, sc[q]);
-    }
-    m = fmaxf(m, dppf<kDppRor8>(m));
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    if ((tid & 63) == 0) red[wave] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float lsum = 0.f;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < NPC; ++q) {
+            const uint32_t o = offk(min(p0 + 8 * q + p8, len - 1)) + 16u * (uint32_t)c;    // past the range: a copy of the last row
+            k[q] = STREAM ? ld4o_stream(kbase, o) : ld4o(kbase, o);
+        }
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        const float e = sc[q] == -INFINITY ? 0.f : __expf(sc[q] - m);
-        lsum += e;
-        acc.x = fmaf(e, vreg[q].x, acc.x); acc.y = fmaf(e, vreg[q].y, acc.y);
-        acc.z = fmaf(e, vreg[q].z, acc.z); acc.w = fmaf(e, vreg[q].w, acc.w);
+        for (int q = 0; q < NPC; ++q) {
+            const uint32_t o = offv(min(p0 + 8 * q + p8, len - 1)) + 16u * (uint32_t)c;
+            v[q] = STREAM ? ld4o_stream(vbase, o) : ld4o(vbase, o);
+        }
     }
-    lsum += dppf<kDppRor8>(lsum);
-    acc.x += dppf<kDppRor8>(acc.x); acc.y += dppf<kDppRor8>(acc.y);
-    acc.z += dppf<kDppRor8>(acc.z); acc.w += dppf<kDppRor8>(acc.w);
+};
+
+struct AttnState {      // running softmax state of one query row in one wave
+    float m, l;         // wave-uniform maximum; this lane's share of the sum of weights
+    float4 acc;         // this lane's share of sum of weight x value (columns 4c .. 4c+3)
+    __device__ __forceinline__ void init() { m = -INFINITY; l = 0.f; acc = f4zero(); }
+};
+
+// pnew >= 0: position pnew is not in memory yet -- its key / value (kn, vn: this lane's float4 c) come from registers.
+// The chunk's registers are masked in place (pad columns, rows past the range).
+template <int NPC, int NQ>
+__device__ __forceinline__ void attend_chunk(KVRegs<NPC>& kv, const float4 (&q4)[NQ], int p0, int len, int dh,
+                                             int pnew, const float4& kn, const float4& vn, AttnState (&st)[NQ]) {
+    const int lane = threadIdx.x & 63, p8 = lane >> 3, c = lane & 7;
+    float4 (&kk)[NPC] = kv.k;
+    float4 (&vv)[NPC] = kv.v;
+#pragma unroll
+    for (int q = 0; q < NPC; ++q) {
+        const int p = p0 + 8 * q + p8;
+        // rows past the range were fetched from a clamped address: their bits must not reach the sums
+        kk[q] = p == pnew ? kn : (p < len ? mask_cols(kk[q], c, dh) : f4zero());
+        vv[q] = p == pnew ? vn : (p < len ? mask_cols(vv[q], c, dh) : f4zero());
+    }
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        float sc[NPC];
+        float mc = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < NPC; ++q) {
+            const float s = sum8(dot4(q4[n], kk[q]));
+            sc[q] = p0 + 8 * q + p8 < len ? s : -INFINITY;
+            mc = fmaxf(mc, sc[q]);
+        }
+        mc = wave_max(mc);
+        const float mnew = fmaxf(st[n].m, mc);
+        const float rescale = st[n].m == -INFINITY ? 0.f : __expf(st[n].m - mnew);
+        st[n].l *= rescale;
+        st[n].acc.x *= rescale; st[n].acc.y *= rescale; st[n].acc.z *= rescale; st[n].acc.w *= rescale;
+#pragma unroll
+        for (int q = 0; q < NPC; ++q) {
+            const float e = sc[q] == -INFINITY ? 0.f : __expf(sc[q] - mnew);
+            st[n].l += e;
+            st[n].acc.x = fmaf(e, vv[q].x, st[n].acc.x); st[n].acc.y = fmaf(e, vv[q].y, st[n].acc.y);
+            st[n].acc.z = fmaf(e, vv[q].z, st[n].acc.z); st[n].acc.w = fmaf(e, vv[q].w, st[n].acc.w);
+        }
+        st[n].m = mnew;
+    }
+}
+
+// Sum a wave's shares: afterwards every lane holds the wave's sum of weights and (in acc) the weighted values of its
+// columns 4c .. 4c+3.  A position's weight sits in its 8 column lanes, hence the exact factor 1/8.
+__device__ __forceinline__ void attend_reduce(AttnState& st) {
+    st.l = wave_sum(st.l) * 0.125f;
+    st.acc.x += dppf<kDppRor8>(st.acc.x); st.acc.y += dppf<kDppRor8>(st.acc.y);
+    st.acc.z += dppf<kDppRor8>(st.acc.z); st.acc.w += dppf<kDppRor8>(st.acc.w);
 #pragma unroll
     for (int off = 16; off < 64; off <<= 1) {
-        lsum += __shfl_xor(lsum, off, 64);
-        acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
-        acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
+        st.acc.x += __shfl_xor(st.acc.x, off, 64); st.acc.y += __shfl_xor(st.acc.y, off, 64);
+        st.acc.z += __shfl_xor(st.acc.z, off, 64); st.acc.w += __shfl_xor(st.acc.w, off, 64);
     }
-    if ((tid & 63) < 8) pvred[wave * 8 + c] = acc;
-    if ((tid & 63) == 0) red[4 + wave] = lsum;
-    __syncthreads();
-    if (tid < 8) {
-        float4 t = pvred[tid];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) { const float4 u = pvred[w * 8 + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-        const float inv = 1.f / ((red[4] + red[5]) + (red[6] + red[7]));
-        o[4 * tid + 0] = 4 * tid + 0 < dh ? t.x * inv : 0.f; o[4 * tid + 1] = 4 * tid + 1 < dh ? t.y * inv : 0.f;
-        o[4 * tid + 2] = 4 * tid + 2 < dh ? t.z * inv : 0.f; o[4 * tid + 3] = 4 * tid + 3 < dh ? t.w * inv : 0.f;
-    }
-    __syncthreads();
 }
 
 struct LayerW {
@@ -313,70 +463,86 @@ struct SelfArgs {
 };
 
 // ---------------------------------------------------------------------------------------------------------
-// self-attention block, one workgroup per (head, row)
+// self-attention block, one workgroup per (head, group of G <= 8 rows): the head's q|k|v and out_proj weights are
+// streamed once for the G rows.  Wave w normalises row w and, later, attends for it.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dec_self_kernel(SelfArgs a) {
-    if (a.n_done != nullptr && *a.n_done >= a.n_total) return;     // every caption has ended (uniform)
-    __shared__ __attribute__((aligned(16))) float xs[kDMax];
-    __shared__ __attribute__((aligned(16))) float qkv[96 + 32];    // q | k | v of this head (3 x dh <= 96)
-    __shared__ __attribute__((aligned(16))) float o[64];
-    __shared__ __attribute__((aligned(16))) float4 part[4 * kD4Max];
-    __shared__ float4 pvred[32];
-    __shared__ float red[8];
-    const int h = blockIdx.x, tid = threadIdx.x;
-    const int64_t r = blockIdx.y;
-    const int d = a.d, d4 = d >> 2, dh = a.dh, pos = a.pos, S = pos + 1;
-    auto rowidx = [&](int rr) { const int seg = rr / dh; return seg * d + h * dh + (rr - seg * dh); };
+constexpr int kOPad = 48;          // attention output row in LDS: head width + the zero tail the out-projection reads
+template <int G>
+__global__ __launch_bounds__(kNT) void dec_self_kernel(SelfArgs a) {
+    static_assert(G <= kNW, "one wave per row");
+    __shared__ __attribute__((aligned(16))) float xs[G][kDMax];
+    __shared__ __attribute__((aligned(16))) float qkv[G][128];     // q | k | v of this head (3 x dh <= 96), zero tail
+    __shared__ __attribute__((aligned(16))) float o[G][kOPad];
+    __shared__ __attribute__((aligned(16))) float4 part[G * kNT];
+    int h, grp;
+    xcd_unit(h, grp, gridDim.y);
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
+    const int64_t r0 = (int64_t)grp * G;
+    const int d = a.d, d4 = d >> 2, dh = a.dh, pos = a.pos, R = a.R;
+    const int done = a.n_done != nullptr ? *a.n_done : 0;           // waited for only after the loads are out
+    const int64_t myrow = min(r0 + wave, (int64_t)R - 1);
+    const bool have_row = wave < G && r0 + wave < R;                // wave-uniform
     ICK_STAMP(0, 0);
-    RowIn in;
-    in.issue(a.w.src, r, d);
-    RowDot<6> qd;
-    qd.load(a.w.in_w, a.w.in_b, d, rowidx, 3 * dh, d4);
-    // cached keys / values of positions < pos: 8 lanes per position (float4 each), 32 positions per pass
-    const int p8 = tid >> 3, c = tid & 7;
-    constexpr int NP = kMLMax / 32;
-    float4 kreg[NP], vreg[NP];
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        const int p = min(32 * q + p8, max(pos - 1, 0));
-        const int64_t cr = a.anc ? (int64_t)a.anc[r * a.ML + p] : r;
-        const int64_t off = ((cr * a.H + h) * a.ML + p) * kDhp + 4 * c;
-        if (32 * q < pos) {           // uniform per pass
-            kreg[q] = *reinterpret_cast<const float4*>(a.kc + off);
-            vreg[q] = *reinterpret_cast<const float4*>(a.vc + off);
-        } else {
-            kreg[q] = vreg[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    ColDot<11> od;
-    od.load(a.w.out_wt, d, h * dh, dh, d4);
+    RowGather<G, kNW> in;
+    in.issue(a.w.src, r0, R, d);
+    RowDot<3> qd;
+    qd.load(a.w.in_w, a.w.in_b, d,
+            [&](int rr) { const int seg = (rr >= dh) + (rr >= 2 * dh); return seg * (d - dh) + h * dh + rr; }, 3 * dh, d4);
+    if (done >= a.n_total) return;                                   // every caption has ended (uniform)
     ICK_STAMP(0, 1);
-    in.finish(a.w.src, r, d, xs, red, part, h == 0);
+    in.slice_sums(a.w.src, r0, R, d, part);
+    for (int idx = tid; idx < G * 32; idx += kNT) qkv[idx >> 5][96 + (idx & 31)] = 0.f;
+    for (int idx = tid; idx < G * kOPad; idx += kNT) (&o[0][0])[idx] = 0.f;
+    __syncthreads();
+    in.finish(a.w.src, r0, R, d, part, &xs[0][0], h == 0);
+    __syncthreads();
     ICK_STAMP(0, 2);
-    if (tid < 32) { qkv[96 + tid] = 0.f; o[32 + tid] = 0.f; }
-    qd.run(xs, 3 * dh, qkv);
+    // the cached keys / values of this wave's row and the out-projection slice are requested before the products run
+    constexpr int NPC = 4;
+    KVRegs<NPC> kv;
+    const int p8 = lane >> 3, c = lane & 7;
+    const int plast = max(pos - 1, 0);                               // position `pos` itself is not in the cache yet
+    auto cache_off = [&](int p) {
+        p = min(p, plast);
+        const int64_t cr = a.anc ? (int64_t)a.anc[myrow * a.ML + p] : myrow;
+        return (uint32_t)(((cr * a.H + h) * a.ML + p) * kDhp) * 4u;
+    };
+    if (have_row) kv.template load<false>(a.kc, a.vc, 0, pos + 1, cache_off, cache_off);
+    ColDot<6> od;
+    od.load(a.w.out_wt, d, h * dh, dh, d4);
+    qd.template run<G>(&xs[0][0], 3 * dh, &qkv[0][0], 128, 1.f, false);
     __syncthreads();
     ICK_STAMP(0, 3);
-    // the new key / value row joins the cache (pad columns stay unwritten and are masked by every reader)
-    if (tid < dh) a.kc[((r * a.H + h) * a.ML + pos) * kDhp + tid] = qkv[dh + tid];
-    else if (tid >= 32 && tid < 32 + dh) a.vc[((r * a.H + h) * a.ML + pos) * kDhp + tid - 32] = qkv[2 * dh + tid - 32];
-    // attention over positions 0 .. pos: cached rows from the registers, the new row from LDS
-    float4 q4, kn, vn;
-    q4.x = 4 * c + 0 < dh ? qkv[4 * c + 0] : 0.f; q4.y = 4 * c + 1 < dh ? qkv[4 * c + 1] : 0.f;
-    q4.z = 4 * c + 2 < dh ? qkv[4 * c + 2] : 0.f; q4.w = 4 * c + 3 < dh ? qkv[4 * c + 3] : 0.f;
-    kn.x = 4 * c + 0 < dh ? qkv[dh + 4 * c + 0] : 0.f; kn.y = 4 * c + 1 < dh ? qkv[dh + 4 * c + 1] : 0.f;
-    kn.z = 4 * c + 2 < dh ? qkv[dh + 4 * c + 2] : 0.f; kn.w = 4 * c + 3 < dh ? qkv[dh + 4 * c + 3] : 0.f;
-    vn.x = 4 * c + 0 < dh ? qkv[2 * dh + 4 * c + 0] : 0.f; vn.y = 4 * c + 1 < dh ? qkv[2 * dh + 4 * c + 1] : 0.f;
-    vn.z = 4 * c + 2 < dh ? qkv[2 * dh + 4 * c + 2] : 0.f; vn.w = 4 * c + 3 < dh ? qkv[2 * dh + 4 * c + 3] : 0.f;
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        const int p = 32 * q + p8;
-        kreg[q] = p == pos ? kn : (p < pos ? mask_cols(kreg[q], c, dh) : make_float4(0.f, 0.f, 0.f, 0.f));
-        vreg[q] = p == pos ? vn : (p < pos ? mask_cols(vreg[q], c, dh) : make_float4(0.f, 0.f, 0.f, 0.f));
+    if (have_row) {                                                   // wave-uniform
+        const int g = wave;
+        // the new key / value row joins the cache (pad columns stay unwritten and are masked by every reader)
+        if (lane < dh) a.kc[((myrow * a.H + h) * a.ML + pos) * kDhp + lane] = qkv[g][dh + lane];
+        else if (lane >= 32 && lane < 32 + dh) a.vc[((myrow * a.H + h) * a.ML + pos) * kDhp + lane - 32] = qkv[g][2 * dh + lane - 32];
+        float4 q4[1], kn, vn;
+        const float sc = a.scale;
+        q4[0].x = 4 * c + 0 < dh ? qkv[g][4 * c + 0] * sc : 0.f; q4[0].y = 4 * c + 1 < dh ? qkv[g][4 * c + 1] * sc : 0.f;
+        q4[0].z = 4 * c + 2 < dh ? qkv[g][4 * c + 2] * sc : 0.f; q4[0].w = 4 * c + 3 < dh ? qkv[g][4 * c + 3] * sc : 0.f;
+        kn.x = 4 * c + 0 < dh ? qkv[g][dh + 4 * c + 0] : 0.f; kn.y = 4 * c + 1 < dh ? qkv[g][dh + 4 * c + 1] : 0.f;
+        kn.z = 4 * c + 2 < dh ? qkv[g][dh + 4 * c + 2] : 0.f; kn.w = 4 * c + 3 < dh ? qkv[g][dh + 4 * c + 3] : 0.f;
+        vn.x = 4 * c + 0 < dh ? qkv[g][2 * dh + 4 * c + 0] : 0.f; vn.y = 4 * c + 1 < dh ? qkv[g][2 * dh + 4 * c + 1] : 0.f;
+        vn.z = 4 * c + 2 < dh ? qkv[g][2 * dh + 4 * c + 2] : 0.f; vn.w = 4 * c + 3 < dh ? qkv[g][2 * dh + 4 * c + 3] : 0.f;
+        AttnState st[1];
+        st[0].init();
+        // positions 0 .. pos; loads cover the cached ones (< pos), the new row comes from the registers above
+        for (int p0 = 0; p0 <= pos; p0 += 8 * NPC) {
+            if (p0 > 0) kv.template load<false>(a.kc, a.vc, p0, pos + 1, cache_off, cache_off);
+            attend_chunk<NPC, 1>(kv, q4, p0, pos + 1, dh, pos, kn, vn, st);
+        }
+        attend_reduce(st[0]);
+        if (p8 == 0) {
+            const float inv = 1.f / st[0].l;
+            reinterpret_cast<float4*>(&o[g][0])[c] = make_float4(st[0].acc.x * inv, st[0].acc.y * inv, st[0].acc.z * inv,
+                                                                  st[0].acc.w * inv);
+        }
     }
-    attend_regs<NP>(kreg, vreg, q4, S, dh, a.scale, red, pvred, o);
+    __syncthreads();
     ICK_STAMP(0, 4);
-    od.run(o, d4, part, a.w.part + (r * a.H + h) * d);
+    od.template run<G>(&o[0][0], kOPad, d4, part, a.w.part + (r0 * a.H + h) * d, (int64_t)a.H * d, (int)min((int64_t)G, R - r0));
     ICK_STAMP(0, 5);
 }
 
@@ -390,125 +556,113 @@ struct CrossArgs {
 };
 
 // ---------------------------------------------------------------------------------------------------------
-// cross-attention block, one workgroup per (head, row): K and V of (sample, head) are read exactly once
+// cross-attention block, one workgroup per (head, group of G rows).  SHARED: the G rows are hypotheses of one caption
+// (beam search) -- its K and V are read once for all of them, each of the eight waves taking an eighth of the S memory
+// rows; otherwise the waves are dealt out as (row, part of S).  Every wave keeps its part's keys and values in
+// registers; the parts of a row meet in LDS as (maximum, sum, weighted values) records.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dec_cross_kernel(CrossArgs a) {
-    if (a.n_done != nullptr && *a.n_done >= a.n_total) return;
-    __shared__ __attribute__((aligned(16))) float xs[kDMax];
-    __shared__ __attribute__((aligned(16))) float qs[32];
-    __shared__ __attribute__((aligned(16))) float sc[kSMax];
-    __shared__ __attribute__((aligned(16))) float o[64];
-    __shared__ __attribute__((aligned(16))) float4 part[4 * kD4Max];
-    __shared__ float4 pvred[32];
-    __shared__ float red[8];
-    const int h = blockIdx.x, tid = threadIdx.x;
-    const int64_t r = blockIdx.y;
-    const int d = a.d, d4 = d >> 2, dh = a.dh, S = a.S;
-    auto rowidx = [&](int rr) { return h * dh + rr; };
+template <int G, bool SHARED>
+__global__ __launch_bounds__(kNT) void dec_cross_kernel(CrossArgs a) {
+    constexpr int PARTS = SHARED ? kNW : kNW / G;       // waves per row
+    constexpr int NQ = SHARED ? G : 1;                  // query rows per wave
+    constexpr int NPC = 7;                              // 56 memory rows per chunk and wave
+    static_assert(SHARED || G == 1 || G == 2 || G == 4 || G == 8, "rows of different captions: 1, 2, 4 or 8 per workgroup");
+    static_assert(G <= kNW, "one wave per row");
+    __shared__ __attribute__((aligned(16))) float xs[G][kDMax];
+    __shared__ __attribute__((aligned(16))) float qs[G][32];
+    __shared__ __attribute__((aligned(16))) float o[G][kOPad];
+    __shared__ __attribute__((aligned(16))) float4 part[G * kNT];
+    __shared__ __attribute__((aligned(16))) float4 pacc[G][kNW][8];
+    __shared__ float pm[G][kNW], pl[G][kNW];
+    int h, grp;
+    xcd_unit(h, grp, gridDim.y);
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
+    const int64_t r0 = (int64_t)grp * G;
+    const int d = a.d, d4 = d >> 2, dh = a.dh, S = a.S, R = a.R;
+    const int done = a.n_done != nullptr ? *a.n_done : 0;
     ICK_STAMP(1, 0);
-    RowIn in;
-    in.issue(a.w.src, r, d);
-    RowDot<2> qd;
-    qd.load(a.w.in_w, a.w.in_b, d, rowidx, dh, d4);
-    const int p8 = tid >> 3, c = tid & 7;
-    const int64_t b = r / a.rows_per_sample;
-    const float* Kb = a.Kmem + b * a.kv_bs + (int64_t)h * S * kDhp;
-    const float* Vb = a.Vmem + b * a.kv_bs + (int64_t)h * S * kDhp;
-    constexpr int NP = 8;            // 256 memory rows per sweep
-    float4 kreg[NP], vreg[NP];
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        const int p = min(32 * q + p8, S - 1);
-        kreg[q] = *reinterpret_cast<const float4*>(Kb + (int64_t)p * kDhp + 4 * c);
-    }
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        const int p = min(32 * q + p8, S - 1);
-        vreg[q] = *reinterpret_cast<const float4*>(Vb + (int64_t)p * kDhp + 4 * c);
-    }
-    ColDot<11> od;
-    od.load(a.w.out_wt, d, h * dh, dh, d4);
+    RowGather<G, kNW> in;
+    in.issue(a.w.src, r0, R, d);
     ICK_STAMP(1, 1);
-    in.finish(a.w.src, r, d, xs, red, part, h == 0);
+    RowDot<1> qd;
+    qd.load(a.w.in_w, a.w.in_b, d, [&](int rr) { return h * dh + rr; }, dh, d4);
     ICK_STAMP(1, 2);
-    if (tid < 32) { qs[tid] = 0.f; o[32 + tid] = 0.f; }
-    __syncthreads();
-    qd.run(xs, dh, qs, a.scale);     // q * 1/sqrt(dh), as nn.MultiheadAttention scales it
-    __syncthreads();
+    // this wave's part of the memory
+    const int g_mine = SHARED ? 0 : wave / PARTS, prt = SHARED ? wave : wave % PARTS;
+    const int Sp = ((S + PARTS - 1) / PARTS + 7) & ~7;
+    const int lo = prt * Sp, len = max(0, min(S - lo, Sp));
+    const int64_t b = min(r0 + g_mine, (int64_t)R - 1) / a.rows_per_sample;
+    const float* Kb = a.Kmem + b * a.kv_bs + ((int64_t)h * S + min(lo, S - 1)) * kDhp;
+    const float* Vb = a.Vmem + b * a.kv_bs + ((int64_t)h * S + min(lo, S - 1)) * kDhp;
+    auto kv_off = [&](int p) { return (uint32_t)p * (kDhp * 4u); };
+    KVRegs<NPC> kv;
+    kv.template load<true>(Kb, Vb, 0, max(len, 1), kv_off, kv_off);
     ICK_STAMP(1, 3);
-    const float4 q4 = reinterpret_cast<const float4*>(qs)[c];   // pad entries are zero; already scaled by 1/sqrt(dh)
-    if (S <= 32 * NP) {
-        // the whole memory is in the registers: scores, softmax and P.V without an LDS score buffer
-#pragma unroll
-        for (int q = 0; q < NP; ++q) { kreg[q] = mask_cols(kreg[q], c, dh); vreg[q] = mask_cols(vreg[q], c, dh); }
-        attend_regs<NP>(kreg, vreg, q4, S, dh, 1.f, red, pvred, o);
-    } else {
-        for (int s0 = 0; s0 < S; s0 += 32 * NP) {
-            if (s0 > 0) {
-    #pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    const int p = min(s0 + 32 * q + p8, S - 1);
-                    kreg[q] = *reinterpret_cast<const float4*>(Kb + (int64_t)p * kDhp + 4 * c);
-                }
-            }
-    #pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                const int p = s0 + 32 * q + p8;
-                float s = dot4(q4, mask_cols(kreg[q], c, dh));
-                s += __shfl_xor(s, 1, 64);
-                s += __shfl_xor(s, 2, 64);
-                s += __shfl_xor(s, 4, 64);
-                if (c == 0 && p < S) sc[p] = s;
-            }
-        }
-        __syncthreads();
-        ICK_STAMP(1, 4);
-        float m = -INFINITY;
-        for (int p = tid; p < S; p += 256) m = fmaxf(m, sc[p]);
-        m = block_max<4>(m, red);
-        float e = 0.f;
-        for (int p = tid; p < S; p += 256) { const float t = __expf(sc[p] - m); sc[p] = t; e += t; }
-        const float denom = block_sum<4>(e, red);
-        __syncthreads();
-        ICK_STAMP(1, 5);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s0 = 0; s0 < S; s0 += 32 * NP) {
-            if (s0 > 0) {
-    #pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    const int p = min(s0 + 32 * q + p8, S - 1);
-                    vreg[q] = *reinterpret_cast<const float4*>(Vb + (int64_t)p * kDhp + 4 * c);
-                }
-            }
-    #pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                const int p = s0 + 32 * q + p8;
-                const float pr = p < S ? sc[p] : 0.f;
-                const float4 v4 = mask_cols(vreg[q], c, dh);
-                acc.x = fmaf(pr, v4.x, acc.x); acc.y = fmaf(pr, v4.y, acc.y);
-                acc.z = fmaf(pr, v4.z, acc.z); acc.w = fmaf(pr, v4.w, acc.w);
-            }
-        }
-    #pragma unroll
-        for (int off = 8; off < 64; off <<= 1) {
-            acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
-            acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
-        }
-        if ((tid & 63) < 8) pvred[(tid >> 6) * 8 + c] = acc;
-        __syncthreads();
-        if (tid < 8) {
-            float4 t = pvred[tid];
-    #pragma unroll
-            for (int w = 1; w < 4; ++w) { const float4 u = pvred[w * 8 + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-            const float inv = 1.f / denom;
-            o[4 * tid + 0] = 4 * tid + 0 < dh ? t.x * inv : 0.f; o[4 * tid + 1] = 4 * tid + 1 < dh ? t.y * inv : 0.f;
-            o[4 * tid + 2] = 4 * tid + 2 < dh ? t.z * inv : 0.f; o[4 * tid + 3] = 4 * tid + 3 < dh ? t.w * inv : 0.f;
-        }
-        __syncthreads();
-    }
+    ColDot<6> od;
+    od.load(a.w.out_wt, d, h * dh, dh, d4);
+    ICK_STAMP(1, 4);
+    if (done >= a.n_total) return;
+    ICK_STAMP(1, 5);
+    in.slice_sums(a.w.src, r0, R, d, part);
     ICK_STAMP(1, 6);
-    od.run(o, d4, part, a.w.part + (r * a.H + h) * d);
+    for (int idx = tid; idx < G * 32; idx += kNT) (&qs[0][0])[idx] = 0.f;
+    for (int idx = tid; idx < G * kOPad; idx += kNT) (&o[0][0])[idx] = 0.f;
+    __syncthreads();
     ICK_STAMP(1, 7);
+    in.finish(a.w.src, r0, R, d, part, &xs[0][0], h == 0);
+    ICK_STAMP(1, 8);
+    __syncthreads();
+    ICK_STAMP(1, 9);
+    qd.template run<G>(&xs[0][0], dh, &qs[0][0], 32, a.scale, false);     // q * 1/sqrt(dh), as nn.MultiheadAttention scales it
+    ICK_STAMP(1, 10);
+    __syncthreads();
+    ICK_STAMP(1, 11);
+    const int p8 = lane >> 3, c = lane & 7;
+    {
+        float4 q4[NQ];
+        AttnState st[NQ];
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+            q4[n] = reinterpret_cast<const float4*>(&qs[SHARED ? n : g_mine][0])[c];   // pad entries are zero
+            st[n].init();
+        }
+        const float4 none = f4zero();
+        for (int p0 = 0; p0 < len; p0 += 8 * NPC) {
+            if (p0 > 0) kv.template load<true>(Kb, Vb, p0, len, kv_off, kv_off);
+            attend_chunk<NPC, NQ>(kv, q4, p0, len, dh, -1, none, none, st);
+        }
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+            attend_reduce(st[n]);
+            const int g = SHARED ? n : g_mine;
+            if (p8 == 0) pacc[g][prt][c] = st[n].acc;
+            if (lane == 0) { pm[g][prt] = st[n].m; pl[g][prt] = st[n].l; }
+        }
+    }
+    ICK_STAMP(1, 12);
+    __syncthreads();
+    ICK_STAMP(1, 13);
+    if (tid < G * 8) {
+        const int g = tid >> 3, cc = tid & 7;
+        float M = pm[g][0];
+#pragma unroll
+        for (int w = 1; w < PARTS; ++w) M = fmaxf(M, pm[g][w]);
+        float L = 0.f;
+        float4 t = f4zero();
+#pragma unroll
+        for (int w = 0; w < PARTS; ++w) {
+            const float f = pm[g][w] == -INFINITY ? 0.f : __expf(pm[g][w] - M);
+            L = fmaf(pl[g][w], f, L);
+            const float4 u = pacc[g][w][cc];
+            t.x = fmaf(u.x, f, t.x); t.y = fmaf(u.y, f, t.y); t.z = fmaf(u.z, f, t.z); t.w = fmaf(u.w, f, t.w);
+        }
+        const float inv = 1.f / L;
+        reinterpret_cast<float4*>(&o[g][0])[cc] = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+    }
+    __syncthreads();
+    ICK_STAMP(1, 14);
+    od.template run<G>(&o[0][0], kOPad, d4, part, a.w.part + (r0 * a.H + h) * d, (int64_t)a.H * d, (int)min((int64_t)G, R - r0));
+    ICK_STAMP(1, 15);
 }
 
 struct FfnArgs {
@@ -521,37 +675,40 @@ struct FfnArgs {
 };
 
 // ---------------------------------------------------------------------------------------------------------
-// feed-forward block, one workgroup per (64 hidden units, row)
+// feed-forward block, one workgroup per (64 hidden units, group of G rows)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dec_ffn_kernel(FfnArgs a) {
-    if (a.n_done != nullptr && *a.n_done >= a.n_total) return;
-    __shared__ __attribute__((aligned(16))) float xs[kDMax];
-    __shared__ __attribute__((aligned(16))) float f[96];
-    __shared__ __attribute__((aligned(16))) float4 part[4 * kD4Max];
-    __shared__ float red[8];
-    const int ch = blockIdx.x, tid = threadIdx.x, nch = gridDim.x;
-    const int64_t r = blockIdx.y;
-    const int d = a.d, d4 = d >> 2;
+template <int G>
+__global__ __launch_bounds__(kNT) void dec_ffn_kernel(FfnArgs a) {
+    static_assert(G <= kNW, "one wave per row");
+    __shared__ __attribute__((aligned(16))) float xs[G][kDMax];
+    __shared__ __attribute__((aligned(16))) float f[G][96];
+    __shared__ __attribute__((aligned(16))) float4 part[G * kNT];
+    int ch, grp;
+    xcd_unit(ch, grp, gridDim.y);
+    const int tid = threadIdx.x, nch = gridDim.x;
+    const int64_t r0 = (int64_t)grp * G;
+    const int d = a.d, d4 = d >> 2, R = a.R;
     const int j0 = ch * 64, nj = min(64, a.FF - j0);
-    auto rowidx = [&](int rr) { return j0 + rr; };
+    const int done = a.n_done != nullptr ? *a.n_done : 0;
     ICK_STAMP(2, 0);
-    RowIn in;
-    in.issue(a.src, r, d);
-    RowDot<4> fd;
-    fd.load(a.w1, a.b1, d, rowidx, nj, d4);
-    ColDot<22> od;
+    RowGather<G, kNW> in;
+    in.issue(a.src, r0, R, d);
+    RowDot<2> fd;
+    fd.load(a.w1, a.b1, d, [&](int rr) { return j0 + rr; }, nj, d4);
+    ColDot<11> od;
     od.load(a.w2t, d, j0, nj, d4);
+    if (done >= a.n_total) return;
     ICK_STAMP(2, 1);
-    in.finish(a.src, r, d, xs, red, part, ch == 0);
-    ICK_STAMP(2, 2);
-    if (tid < 96) f[tid] = 0.f;
+    in.slice_sums(a.src, r0, R, d, part);
+    for (int idx = tid; idx < G * 96; idx += kNT) (&f[0][0])[idx] = 0.f;
     __syncthreads();
-    fd.run(xs, nj, f);
+    in.finish(a.src, r0, R, d, part, &xs[0][0], ch == 0);
+    __syncthreads();
+    ICK_STAMP(2, 2);
+    fd.template run<G>(&xs[0][0], nj, &f[0][0], 96, 1.f, true);
     __syncthreads();
     ICK_STAMP(2, 3);
-    if (tid < nj) f[tid] = fmaxf(f[tid], 0.f);
-    __syncthreads();
-    od.run(f, d4, part, a.part + (r * nch + ch) * d);
+    od.template run<G>(&f[0][0], 96, d4, part, a.part + (r0 * nch + ch) * d, (int64_t)nch * d, (int)min((int64_t)G, R - r0));
     ICK_STAMP(2, 4);
 }
 
@@ -568,37 +725,60 @@ struct HeadArgs {
 };
 
 __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
-    if (a.n_done != nullptr && *a.n_done >= a.n_total) return;
     __shared__ __attribute__((aligned(16))) float xs[kDMax];
-    __shared__ __attribute__((aligned(16))) float4 part[4 * kD4Max];
-    __shared__ float red[8];
     const int tid = threadIdx.x;
     const int64_t r = blockIdx.x;
     const int d = a.d, d4 = d >> 2;
     const int64_t b = r / a.rows_per_sample;
-    RowIn in;
-    in.issue(a.src, r, d);
-    in.finish(a.src, r, d, xs, red, part, true);
+    const int lane = tid & 63, wave = wave_id(), sub = lane >> 4, i = lane & 15;
+    const int done = a.n_done != nullptr ? *a.n_done : 0;
+    __shared__ __attribute__((aligned(16))) float4 psum[4 * kD4Max];
+    RowGather<1, 4> in;
+    in.issue(a.src, r, a.R, d);
+    const float* wq[2] = {a.we, a.fe != nullptr && a.F > 0 ? a.wf : a.we};
+    float4 wr2[2][5];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int it = 0; it < 5; ++it) wr2[pp][it] = ld4(wq[pp] + 4 * min(i + 16 * it, d4 - 1));
+    const float bias2[2] = {a.be[0], a.fe != nullptr && a.F > 0 ? a.bf[0] : 0.f};
+    if (done >= a.n_total) return;
+    in.slice_sums(a.src, r, a.R, d, psum);
+    // the first context rows are requested while wave 0 normalises
+    const float* ctx0 = a.ee;
+    const int n0 = a.K;
+    float4 cv0[5];
+    {
+        const float* cr = ctx0 + (b * n0 + min(4 * wave + sub, n0 - 1)) * d;
+#pragma unroll
+        for (int it = 0; it < 5; ++it) cv0[it] = ld4(cr + 4 * min(i + 16 * it, d4 - 1));
+    }
+    __syncthreads();
+    in.finish(a.src, r, a.R, d, psum, xs, true);
+    __syncthreads();
     for (int c = tid; c < d; c += 256) a.hv[r * d + c] = a.gate ? xs[c] * a.gate[r * d + c] : xs[c];
-    const int lane = tid & 63, wave = tid >> 6, sub = lane >> 4, i = lane & 15;
+    float4 xr[5];
+#pragma unroll
+    for (int it = 0; it < 5; ++it) xr[it] = reinterpret_cast<const float4*>(xs)[i + 16 * it];      // zero beyond d
     for (int part = 0; part < 2; ++part) {
         const float* ctx = part == 0 ? a.ee : a.fe;
         const int n = part == 0 ? a.K : a.F;
         if (ctx == nullptr || n <= 0) continue;
-        const float* w = part == 0 ? a.we : a.wf;
-        float4 xr[5], wr[5];
+        float4 wr[5];
 #pragma unroll
-        for (int it = 0; it < 5; ++it) {
-            xr[it] = reinterpret_cast<const float4*>(xs)[i + 16 * it];      // zero beyond d
-            wr[it] = reinterpret_cast<const float4*>(w)[min(i + 16 * it, d4 - 1)];
-        }
-        const float bias = part == 0 ? a.be[0] : a.bf[0];
+        for (int it = 0; it < 5; ++it) wr[it] = wr2[part][it];
+        const float bias = bias2[part];
         for (int k0 = 0; k0 < n; k0 += 16) {
             const int k = k0 + 4 * wave + sub;
-            const float4* cr = reinterpret_cast<const float4*>(ctx + (b * n + min(k, n - 1)) * d);
             float4 cv[5];
+            if (part == 0 && k0 == 0) {
 #pragma unroll
-            for (int it = 0; it < 5; ++it) cv[it] = cr[min(i + 16 * it, d4 - 1)];
+                for (int it = 0; it < 5; ++it) cv[it] = cv0[it];
+            } else {
+                const float* cr = ctx + (b * n + min(k, n - 1)) * d;
+#pragma unroll
+                for (int it = 0; it < 5; ++it) cv[it] = ld4(cr + 4 * min(i + 16 * it, d4 - 1));
+            }
             float acc = 0.f;
 #pragma unroll
             for (int it = 0; it < 5; ++it) {
@@ -652,78 +832,92 @@ __device__ __forceinline__ Top2 top2_merge_dpp(Top2 t) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// vocabulary logits: workgroup = 16 words x 32 rows, the four waves split K; fp32 MFMA 16x16x4
+// vocabulary logits: workgroup = kVocabTile words x all rows (blocks of 32), the eight waves split K; fp32 MFMA
+// 16x16x4.  One workgroup per CU at V = 10 000 (209 of them): its 58 KB weight slice is fetched once and stays in
+// registers for every block of 32 rows (beam search decodes captions x beams rows).
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dec_vocab_kernel(VocabArgs a) {
-    if (a.n_done != nullptr && *a.n_done >= a.n_total) return;
-    __shared__ __attribute__((aligned(16))) float red[4][2][16][17];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+constexpr int kVocabTile = 48;
+constexpr int kVocabCT = kVocabTile / 16;     // 16-word column tiles per workgroup
+constexpr int kVocabKC = 3;                   // 16-wide k chunks per wave: 8 x 3 x 16 = 384 >= kDMax
+__global__ __launch_bounds__(kNT) void dec_vocab_kernel(VocabArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[kNW][2][kVocabCT][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int fi = lane & 15, fq = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    const int n0 = blockIdx.x * kVocabTile;
     const int d = a.d;
-    const int nchunk = (d + 15) >> 4;                  // 16-wide k chunks; <= 20
-    const int per = (nchunk + 3) >> 2;                 // chunks per wave; <= 5
-    const int c0 = wave * per, c1 = min(nchunk, c0 + per);
-    const int64_t rb = (int64_t)min(n0 + fi, a.V - 1) * d;
+    const int done = a.n_done != nullptr ? *a.n_done : 0;
     ICK_STAMP(3, 0);
-    const int row = tid >> 3, cp = tid & 7;          // epilogue role: one row, two columns
-    float bias2[2];
+    // this wave's K slice of the 48 weight rows
+    float4 bw[kVocabCT][kVocabKC];
+    uint32_t koff[kVocabKC];
+    bool kok[kVocabKC];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) bias2[e] = a.bv[min(n0 + 2 * cp + e, a.V - 1)];
-    // this wave's K slice of the 16 weight rows: fetched once, reused for every block of 32 rows (beam search
-    // decodes captions x beams rows; the vocabulary matrix is the large operand)
-    float4 bw[5];
-    int koff[5];
-    bool kok[5];
-#pragma unroll
-    for (int t = 0; t < 5; ++t) {
-        const int k = 16 * (c0 + t) + 4 * fq;
-        kok[t] = c0 + t < c1 && k < d;               // d % 4 == 0: a float4 is entirely inside or outside
-        koff[t] = kok[t] ? k : 0;
-        bw[t] = *reinterpret_cast<const float4*>(a.wv + rb + koff[t]);
-        if (!kok[t]) bw[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < kVocabKC; ++t) {
+        const int k = 16 * (kVocabKC * wave + t) + 4 * fq;
+        kok[t] = k < d;                              // d % 4 == 0: a float4 is entirely inside or outside
+        koff[t] = kok[t] ? 4u * (uint32_t)k : 0u;
     }
-    for (int m0 = 0; m0 < a.R; m0 += 32) {
-        const int64_t ra0 = (int64_t)min(m0 + fi, a.R - 1) * d, ra1 = (int64_t)min(m0 + 16 + fi, a.R - 1) * d;
-        float4 av0[5], av1[5];
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            av0[t] = *reinterpret_cast<const float4*>(a.hv + ra0 + koff[t]);
-            av1[t] = *reinterpret_cast<const float4*>(a.hv + ra1 + koff[t]);
-            if (!kok[t]) av0[t] = av1[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ct = 0; ct < kVocabCT; ++ct) {
+        const uint32_t rb = (uint32_t)min(n0 + 16 * ct + fi, a.V - 1) * (uint32_t)d * 4u;
+#pragma unroll
+        for (int t = 0; t < kVocabKC; ++t) {
+            bw[ct][t] = ld4o(a.wv, rb + koff[t]);
+            if (!kok[t]) bw[ct][t] = f4zero();
+        }
+    }
+    const int row = tid >> 4, cp = tid & 15;         // epilogue role: one row, three columns
+    constexpr int kCols = kVocabTile / 16;
+    float biasv[kCols];
+#pragma unroll
+    for (int e = 0; e < kCols; ++e) biasv[e] = a.bv[min(n0 + kCols * cp + e, a.V - 1)];
+    if (done >= a.n_total) return;
+    for (int m0 = 0; m0 < a.R; m0 += 32) {
+        const uint32_t ra0 = (uint32_t)min(m0 + fi, a.R - 1) * (uint32_t)d * 4u,
+                       ra1 = (uint32_t)min(m0 + 16 + fi, a.R - 1) * (uint32_t)d * 4u;
+        float4 av0[kVocabKC], av1[kVocabKC];
+#pragma unroll
+        for (int t = 0; t < kVocabKC; ++t) {
+            av0[t] = ld4o(a.hv, ra0 + koff[t]);
+            av1[t] = ld4o(a.hv, ra1 + koff[t]);
+            if (!kok[t]) av0[t] = av1[t] = f4zero();
         }
         ICK_STAMP(3, 1);
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t].x, bw[t].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t].x, bw[t].x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t].y, bw[t].y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t].y, bw[t].y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t].z, bw[t].z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t].z, bw[t].z, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t].w, bw[t].w, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t].w, bw[t].w, acc1, 0, 0, 0);
-        }
-        // C/D map: col = lane & 15, row = (lane >> 4) * 4 + reg
+        for (int ct = 0; ct < kVocabCT; ++ct) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            red[wave][0][fq * 4 + rg][fi] = acc0[rg];
-            red[wave][1][fq * 4 + rg][fi] = acc1[rg];
+            for (int t = 0; t < kVocabKC; ++t) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t].x, bw[ct][t].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t].x, bw[ct][t].x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t].y, bw[ct][t].y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t].y, bw[ct][t].y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t].z, bw[ct][t].z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t].z, bw[ct][t].z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t].w, bw[ct][t].w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t].w, bw[ct][t].w, acc1, 0, 0, 0);
+            }
+            // C/D map: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                red[wave][0][ct][fq * 4 + rg][fi] = acc0[rg];
+                red[wave][1][ct][fq * 4 + rg][fi] = acc1[rg];
+            }
         }
         ICK_STAMP(3, 2);
         __syncthreads();
         ICK_STAMP(3, 3);
-        // thread (row = tid >> 3, two columns): sum the four K slices in a fixed order, add the bias
+        // thread (row = tid >> 4, three columns): sum the eight K slices in a fixed order, add the bias
         const int gr = m0 + row;
         Top2 t2{-INFINITY, -INFINITY, kNone, kNone};
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int col = 2 * cp + e, n = n0 + col;
-            float v = ((red[0][row >> 4][row & 15][col] + red[1][row >> 4][row & 15][col]) +
-                       red[2][row >> 4][row & 15][col]) + red[3][row >> 4][row & 15][col];
+        for (int e = 0; e < kCols; ++e) {
+            const int col = kCols * cp + e, n = n0 + col, ct = col >> 4, cc = col & 15;
+            float v = red[0][row >> 4][ct][row & 15][cc];
+#pragma unroll
+            for (int w = 1; w < kNW; ++w) v += red[w][row >> 4][ct][row & 15][cc];
             if (n < a.V) {
-                v += bias2[e];
+                v += biasv[e];
                 if (a.scores != nullptr && gr < a.R) a.scores[(int64_t)gr * a.ld + n] = v;
                 top2_push(t2, v, n);
             }
@@ -731,6 +925,7 @@ __global__ __launch_bounds__(256) void dec_vocab_kernel(VocabArgs a) {
         t2 = top2_merge_dpp<kDppXor1>(t2);      // empty slots carry (-inf, kNone): they never displace anything
         t2 = top2_merge_dpp<kDppXor2>(t2);
         t2 = top2_merge_dpp<kDppHalfMirror>(t2);
+        t2 = top2_merge_dpp<kDppMirror>(t2);
         if (cp == 0 && gr < a.R)
             a.cand[(int64_t)gr * a.ntiles + blockIdx.x] =
                 make_float4(t2.v1, __int_as_float(t2.i1), t2.v2, __int_as_float(t2.i2));
@@ -1119,6 +1314,80 @@ static RowSrc make_src(const ick_decode_ctx* c, const float* res, const float* p
     return s;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// How many rows a workgroup takes.  The decode step is bound by what every CU pulls through its L1 (a head's q|k|v +
+// out_proj slices are 144 KB, a 64-unit FFN chunk 154 KB, a (row, head) of cross K/V 55 KB at S = 216): rows that share
+// a workgroup share that stream, and the grid should not exceed one workgroup per CU.  ICK_DEC_G="self,cross,ffn"
+// overrides the choice (tuning).
+// ---------------------------------------------------------------------------------------------------------
+struct GroupPlan { int g_self, g_cross, g_ffn; bool cross_shared; };
+static int pick_group(int units_per_row_group, int R, const int* cand, int ncand) {
+    int g = cand[ncand - 1];
+    for (int i = 0; i < ncand; ++i)
+        if (units_per_row_group * ceil_div(R, cand[i]) <= kNumCU) { g = cand[i]; break; }
+    return g;
+}
+static GroupPlan plan_groups(const ick_decode_ctx* c) {
+    static const int pow2[] = {1, 2, 4, 8};
+    GroupPlan p;
+    const int R = c->R, rps = c->rows_per_sample;
+    p.g_self = pick_group(c->H, R, pow2, 4);
+    p.g_ffn = pick_group(ceil_div(c->FF, 64), R, pow2, 4);
+    p.cross_shared = false;
+    p.g_cross = pick_group(c->H, R, pow2, 4);
+    if (rps > 1) {
+        // hypotheses of one caption read the same K / V: the largest group that divides the beam
+        static const int shared[] = {8, 5, 4, 3, 2};
+        p.g_cross = 1;
+        for (int g : shared)
+            if (rps % g == 0) { p.g_cross = g; p.cross_shared = true; break; }
+    }
+    if (const char* e = getenv("ICK_DEC_G")) {
+        int a = 0, b = 0, f = 0;
+        if (sscanf(e, "%d,%d,%d", &a, &b, &f) == 3) {
+            if (a == 1 || a == 2 || a == 4 || a == 8) p.g_self = a;
+            if (f == 1 || f == 2 || f == 4 || f == 8) p.g_ffn = f;
+            if (!p.cross_shared && (b == 1 || b == 2 || b == 4 || b == 8)) p.g_cross = b;
+        }
+    }
+    return p;
+}
+static void launch_self(int g, dim3 grid, hipStream_t s, const SelfArgs& a) {
+    switch (g) {
+    case 1: hipLaunchKernelGGL(dec_self_kernel<1>, grid, dim3(kNT), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(dec_self_kernel<2>, grid, dim3(kNT), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(dec_self_kernel<4>, grid, dim3(kNT), 0, s, a); break;
+    default: hipLaunchKernelGGL(dec_self_kernel<8>, grid, dim3(kNT), 0, s, a); break;
+    }
+}
+static void launch_ffn(int g, dim3 grid, hipStream_t s, const FfnArgs& a) {
+    switch (g) {
+    case 1: hipLaunchKernelGGL(dec_ffn_kernel<1>, grid, dim3(kNT), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(dec_ffn_kernel<2>, grid, dim3(kNT), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(dec_ffn_kernel<4>, grid, dim3(kNT), 0, s, a); break;
+    default: hipLaunchKernelGGL(dec_ffn_kernel<8>, grid, dim3(kNT), 0, s, a); break;
+    }
+}
+static void launch_cross(int g, bool shared, dim3 grid, hipStream_t s, const CrossArgs& a) {
+    if (!shared) {
+        switch (g) {
+        case 1: hipLaunchKernelGGL((dec_cross_kernel<1, false>), grid, dim3(kNT), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((dec_cross_kernel<2, false>), grid, dim3(kNT), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((dec_cross_kernel<4, false>), grid, dim3(kNT), 0, s, a); break;
+        default: hipLaunchKernelGGL((dec_cross_kernel<8, false>), grid, dim3(kNT), 0, s, a); break;
+        }
+        return;
+    }
+    switch (g) {
+    case 2: hipLaunchKernelGGL((dec_cross_kernel<2, true>), grid, dim3(kNT), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((dec_cross_kernel<3, true>), grid, dim3(kNT), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((dec_cross_kernel<4, true>), grid, dim3(kNT), 0, s, a); break;
+    case 5: hipLaunchKernelGGL((dec_cross_kernel<5, true>), grid, dim3(kNT), 0, s, a); break;
+    default: hipLaunchKernelGGL((dec_cross_kernel<8, true>), grid, dim3(kNT), 0, s, a); break;
+    }
+}
+
 extern "C" int ick_decode_supported(int32_t d, int32_t H, int32_t FF, int32_t S, int32_t max_len) {
     return d > 0 && d % 4 == 0 && d <= kDMax && d >= 64 && H > 0 && H <= kPartsMax && d % H == 0 && d / H <= 32 && FF > 0 &&
            FF % 4 == 0 && FF <= 64 * kPartsMax &&
@@ -1130,7 +1399,8 @@ extern "C" int ick_decode_beam_supported(int32_t Vx, int32_t beam) {
     return (int64_t)beam * beam * ceil_div(Vx, kBeamChunk) <= 256 * kBeamCandPerThread;   // candidates the selection holds
 }
 
-extern "C" int ick_decode_layers(const ick_decode_ctx* c, int32_t pos, void* stream) {
+// which: bit 0 self, 1 cross, 2 ffn, 3 head, 4 vocabulary (all set in the product path; the diagnostic build times subsets)
+static int decode_layers_impl(const ick_decode_ctx* c, int32_t pos, void* stream, unsigned which) {
     ICK_CHECK_ARG(c && c->R > 0 && c->layers > 0 && c->layers <= ICK_MAX_LAYERS && pos >= 0 && pos < c->max_len);
     ICK_CHECK_ARG(ick_decode_supported(c->d, c->H, c->FF, c->S, c->max_len));
     ICK_CHECK_ARG(c->rows_per_sample > 0 && c->R % c->rows_per_sample == 0 && c->R <= 65535);
@@ -1140,6 +1410,7 @@ extern "C" int ick_decode_layers(const ick_decode_ctx* c, int32_t pos, void* str
     const int d = c->d, H = c->H, dh = d / H, R = c->R;
     const int nch = ceil_div(c->FF, 64);
     const float scale = 1.f / sqrtf((float)dh);
+    const GroupPlan plan = plan_groups(c);
     RowSrc src = make_src(c, c->x0, nullptr, 0, nullptr, nullptr, nullptr, c->xa);
     for (int l = 0; l < c->layers; ++l) {
         const ick_decode_layer& w = c->layer[l];
@@ -1151,7 +1422,7 @@ extern "C" int ick_decode_layers(const ick_decode_ctx* c, int32_t pos, void* str
         sa.kc = w.self_k; sa.vc = w.self_v; sa.anc = c->anc;
         sa.R = R; sa.d = d; sa.H = H; sa.dh = dh; sa.ML = c->max_len; sa.pos = pos; sa.scale = scale;
         sa.n_done = c->n_done; sa.n_total = R;
-        hipLaunchKernelGGL(dec_self_kernel, dim3(H, R), dim3(256), 0, s, sa);
+        if (which & 1u) launch_self(plan.g_self, dim3(H, ceil_div(R, plan.g_self)), s, sa);
         CrossArgs ca;
         ca.w.in_w = w.ca_in_w; ca.w.in_b = w.ca_in_b; ca.w.out_wt = w.ca_out_wt;
         ca.w.src = make_src(c, c->xa, c->p1, H, w.sa_out_b, w.n1_g, w.n1_b, c->xb);
@@ -1159,12 +1430,12 @@ extern "C" int ick_decode_layers(const ick_decode_ctx* c, int32_t pos, void* str
         ca.Kmem = w.cross_k; ca.Vmem = w.cross_v; ca.kv_bs = c->kv_bs;
         ca.R = R; ca.rows_per_sample = c->rows_per_sample; ca.d = d; ca.H = H; ca.dh = dh; ca.S = c->S; ca.scale = scale;
         ca.n_done = c->n_done; ca.n_total = R;
-        hipLaunchKernelGGL(dec_cross_kernel, dim3(H, R), dim3(256), 0, s, ca);
+        if (which & 2u) launch_cross(plan.g_cross, plan.cross_shared, dim3(H, ceil_div(R, plan.g_cross)), s, ca);
         FfnArgs fa;
         fa.w1 = w.w1; fa.b1 = w.b1; fa.w2t = w.w2t;
         fa.src = make_src(c, c->xb, c->p2, H, w.ca_out_b, w.n2_g, w.n2_b, c->xc);
         fa.part = c->p3; fa.R = R; fa.d = d; fa.FF = c->FF; fa.n_done = c->n_done; fa.n_total = R;
-        hipLaunchKernelGGL(dec_ffn_kernel, dim3(nch, R), dim3(256), 0, s, fa);
+        if (which & 4u) launch_ffn(plan.g_ffn, dim3(nch, ceil_div(R, plan.g_ffn)), s, fa);
         // the next consumer normalises: LayerNorm3(xc + b2 + sum of the chunk partials)
         src = make_src(c, c->xc, c->p3, nch, w.b2, w.n3_g, w.n3_b, l + 1 < c->layers ? c->xa : c->hfin);
     }
@@ -1175,21 +1446,36 @@ extern "C" int ick_decode_layers(const ick_decode_ctx* c, int32_t pos, void* str
     ha.fe = c->F > 0 ? c->fe : nullptr; ha.wf = c->wf; ha.bf = c->bf; ha.eib = c->eib; ha.ptr = c->ptr;
     ha.R = R; ha.rows_per_sample = c->rows_per_sample; ha.d = d; ha.K = c->K; ha.F = c->F;
     ha.n_done = c->n_done; ha.n_total = R;
-    hipLaunchKernelGGL(dec_head_kernel, dim3(R), dim3(256), 0, s, ha);
+    if (which & 8u) hipLaunchKernelGGL(dec_head_kernel, dim3(R), dim3(256), 0, s, ha);
     VocabArgs va;
     va.hv = c->hv; va.wv = c->wv; va.bv = c->bv; va.scores = c->scores; va.ld = c->scores_ld;
-    va.cand = reinterpret_cast<float4*>(c->cand); va.R = R; va.d = d; va.V = c->V; va.ntiles = ceil_div(c->V, 16);
+    va.cand = reinterpret_cast<float4*>(c->cand); va.R = R; va.d = d; va.V = c->V; va.ntiles = ceil_div(c->V, kVocabTile);
     va.n_done = c->n_done; va.n_total = R;
-    hipLaunchKernelGGL(dec_vocab_kernel, dim3(va.ntiles), dim3(256), 0, s, va);
+    if (which & 16u) hipLaunchKernelGGL(dec_vocab_kernel, dim3(va.ntiles), dim3(kNT), 0, s, va);
     ICK_LAUNCH_RET();
 }
+
+extern "C" int ick_decode_layers(const ick_decode_ctx* c, int32_t pos, void* stream) {
+    return decode_layers_impl(c, pos, stream, 31u);
+}
+
+#ifdef ICK_DECODE_STAMPS
+// diagnostic build only: `reps` passes over a subset of the step's kernels (tools/debug/decode_repeat.py)
+extern "C" int ick_debug_decode_subset(const ick_decode_ctx* c, int32_t pos, unsigned which, int32_t reps, void* stream) {
+    for (int i = 0; i < reps; ++i) {
+        const int rc = decode_layers_impl(c, pos, stream, which);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+#endif
 
 extern "C" int ick_decode_select_greedy(const ick_decode_ctx* c, int32_t pos, void* stream) {
     ICK_CHECK_ARG(c && c->R > 0 && pos >= 0 && pos < c->max_len);
     ICK_CHECK_ARG(c->output && c->hist && c->finished && c->n_done && c->next_token && c->next_mask && c->word_emb &&
                   c->pe && c->x0 && c->cand && c->ptr && c->ee);
     SelectArgs a;
-    a.cand = reinterpret_cast<const float4*>(c->cand); a.ntiles = ceil_div(c->V, 16); a.ptr = c->ptr;
+    a.cand = reinterpret_cast<const float4*>(c->cand); a.ntiles = ceil_div(c->V, kVocabTile); a.ptr = c->ptr;
     a.output = c->output; a.hist = c->hist; a.finished = c->finished; a.n_done = c->n_done;
     a.next_token = c->next_token; a.next_mask = c->next_mask; a.cap_buf = c->cap_buf;
     a.word_emb = c->word_emb; a.ee = c->ee; a.fe = c->F > 0 ? c->fe : nullptr; a.pe = c->pe; a.x0 = c->x0;

@@ -26,10 +26,11 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 128)()
 lib = ctypes.CDLL(dbg)
 assert lib.ick_debug_read_stamps(buf) == 0
-names = {0: ("self", ["loads issued", "LN on load", "qkv GEMV", "attention", "out-proj"]),
-         1: ("cross", ["loads issued", "LN on load", "q GEMV"]),
-         2: ("ffn", ["loads issued", "LN on load", "linear1 GEMV", "relu+linear2"]),
-         3: ("vocab", ["loads issued", "MFMA + LDS write", "barrier", "reduce + candidates"])}
+names = {0: ("self", ["loads issued", "LN on load + barrier", "cache/out loads issued + qkv GEMV + barrier", "attention + barrier", "out-proj"]),
+         1: ("cross", ["row loads issued", "q weights issued", "K/V issued", "out weights issued", "n_done arrived", "rows arrived + slice sums",
+                       "barrier", "LN finish", "barrier", "q GEMV", "barrier", "attention", "barrier", "combine + barrier", "out-proj"]),
+         2: ("ffn", ["loads issued", "LN on load + barrier", "linear1 GEMV + barrier", "linear2"]),
+         3: ("vocab", ["weights + rows issued", "MFMA + LDS write", "barrier", "reduce + candidates"])}
 for k, (nm, ph) in names.items():
     t = [buf[k * 16 + i] for i in range(len(ph) + 1)]
     print(nm, "total %d cycles:" % (t[-1] - t[0]), ", ".join("%s %d" % (p, t[i + 1] - t[i]) for i, p in enumerate(ph)))
