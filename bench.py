@@ -1,6 +1,6 @@
 """bench.py -- decode-steps/s of the caption-decoder hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W] [--mode train|forward|greedy|beam] [--config cfg2]
+    python bench.py [--gpus N --steps K --warmup W] [--mode train|forward|greedy|beam] [--config cfg2] [--no-modes]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One *step* = one pass of the hot path over one batch of synthetic input resident in HBM, on cfg2 =
@@ -12,17 +12,24 @@ per step and per GPU (weak scaling: every rank owns its own 64-sample shard, SUR
   --mode forward          Encoder.conv1 + teacher-forced forward only (validate(), no collective)
   --mode greedy           Encoder.conv1 + predict() greedy decode, KV-cached (eval.py path; cfg5)
   --mode beam             Encoder.conv1 + predict_beam() (beam 5, batch 32: north_star cfg5; parity-unpinned)
+Timing: W warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both sides (max
+over ranks); blocks are repeated until 2 s of timed device work and the MEDIAN block is reported (`repeats`).
 Rank 0 prints ONE JSON line with the whole-job rate plus
   roofline      by_kernel: every kernel class of the step (launches per step, mean duration from HIP events on
                 the launch stream in an eager single-stream pass, algorithmic FLOP or bytes, fraction of the fp32
                 MFMA / HBM peak); the headline kernel/achieved/frac describe the class with the LARGEST share of
-                the step's kernel time; pass_frac = the whole step against the bound of its algorithmic work
+                the step's kernel time; pass_frac_executed = the whole step's EXECUTED FLOPs (or algorithmic bytes)
+                per second against the peak
+  modes         (one GPU, unless --no-modes) the other workloads of SURVEY.md §8(d) in the same run: forward cfg2,
+                greedy cfg5, beam cfg5, train cfg4 -- ms_per_step, decode-steps/s, pass_frac, dominant kernel class
   cpu_baseline  the same workload on the host cores through oracle/stock.py (a port of the reference's
                 PyTorch-CPU path): all usable cores and a 1-thread leg, each bounded to a few seconds.
 """
 import argparse
+import gc
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -34,6 +41,15 @@ sys.path.insert(0, ROOT)
 TRAFFIC_TABLE = os.path.join(ROOT, "profiles", "r02_traffic.json")   # PMC bytes per launch, see its "_source"
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_GBS = 8000.0
+BEAM = 5
+
+# FLOPs one step EXECUTES (SURVEY.md §8(d) closed forms; train = 3 x forward minus what the step skips: Encoder.conv1's
+# backward, which the reference computes but never uses with fine_tune_encoder=False, and the image rows' data gradient)
+EXECUTED_GFLOP = {("cfg2", "forward"): 50.85, ("cfg2", "train"): 3 * 50.85 - 2 * 15.41 - 13.5,
+                  ("cfg4", "forward"): 101.3, ("cfg4", "train"): 3 * 101.3 - 2 * 15.41 - 13.5}
+# algorithmic HBM bytes per decoded token step of the whole batch (cross + self K/V, per-step weights,
+# logits); beam 5: the hypotheses of a caption share its cross K/V, 160 rows of logits
+ALGO_MB_PER_TOKEN = {("cfg5", "greedy"): 75.6, ("cfg5", "beam"): 53.1 + 22.3 + 160 * 10020 * 4 / 1e6}
 
 
 def parse():
@@ -47,6 +63,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-profile", action="store_true", help="skip the eager per-kernel pass (roofline.by_kernel)")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--no-modes", action="store_true", help="headline only: skip the forward / greedy / beam / cfg4 legs")
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the K-step block until this much timed work")
     return ap.parse_args()
 
 
@@ -146,6 +164,159 @@ def cpu_baseline(cfg, seed, budget_s, mode="forward"):
             "threads": full["threads"], "one_thread": {"value": single["value"], "cores": 1, "sample": single["sample"]}}
 
 
+class Workload:
+    """One (mode, config) on this rank's GPU: synthetic batch resident in HBM, random-init weights of the reference's
+    architecture (same seed on every rank), the step function and its eager twin for the per-kernel pass."""
+
+    def __init__(self, mode, cfgname, rank):
+        import ick_amd
+        import ick_amd.synth as synth
+        self.mode, self.cfgname, self.rank = mode, cfgname, rank
+        self.cfg = cfg = dict(synth.CONFIGS[cfgname])
+        variant, B, L, K, V, Fn = cfg["variant"], cfg["B"], cfg["L"], cfg["K"], cfg["V"], cfg["F"]
+        self.seed = seed = 100 + rank            # every rank owns a different shard of the global batch
+        m = ick_amd.load_models(variant)
+        dec = m.DecoderTransformer(synth.make_word_map(V), 300, 512, 512, 10, 3)
+        dec.load_state_dict(synth.make_params(variant, V, 0), strict=False)      # same weights on every rank
+        dec = dec.cuda()
+        self.dec = dec.train() if mode == "train" else dec.eval()
+        enc = m.Encoder(emb_dim=300)
+        cw, cb = synth.make_conv1(0)
+        with torch.no_grad():
+            enc.conv1.weight.copy_(cw)
+            enc.conv1.bias.copy_(cb)
+        self.enc = enc.cuda().eval()
+        self.batch = {k: v.cuda() for k, v in synth.make_batch(variant, B, L, K, V, Fn, seed).items()}
+        self.feats = synth.make_feats(B, seed).cuda()
+        self.extra = [self.batch["facts"]] if variant != "geo" else []
+        self.units_per_step = B * L
+        self.train_step = None
+
+    def describe(self):
+        c = self.cfg
+        return "%s: %s variant, per-GPU batch %d x %d decode positions, 14x14x2048 features, K=%d knowledge rows%s, vocab %d" % (
+            self.cfgname, c["variant"], c["B"], c["L"], c["K"], (", F=%d facts" % c["F"]) if c["F"] else "", c["V"])
+
+    def make_step(self, use_graph=True):
+        mode, dec, enc, batch, feats, extra, L = self.mode, self.dec, self.enc, self.batch, self.feats, self.extra, self.cfg["L"]
+        if mode == "train":
+            from ick_amd.training import TrainStep
+            # encoder=: the step takes the feature map itself; Encoder.conv1 runs inside the captured step and writes
+            # the image rows straight into the decoder's memory buffer.  All-reduces its bucket when world > 1.
+            ts = TrainStep(dec, lr=4e-4, grad_clip=5.0, seed=self.rank, use_graph=use_graph, encoder=enc)
+            if use_graph:
+                self.train_step = ts
+            live = (batch["captions"], feats, batch["caption_masks"], batch["caption_lengths"], batch["entities"], *extra)
+            state = {"args": live}
+            legacy = os.environ.get("ICK_BENCH_SEPARATE_ENCODER") == "1"   # A/B: eager Encoder + per-step input copies
+
+            def step():
+                if legacy:
+                    with torch.no_grad():
+                        e = enc(feats)
+                    return ts(batch["captions"], e, batch["caption_masks"], batch["caption_lengths"],
+                              batch["entities"], *extra)
+                out = ts(*state["args"])
+                if state["args"] is live and ts.use_graph:
+                    # from now on the (HBM-resident) batch lives in the step's own input buffers -- where a loader's
+                    # host-to-device copy would put the next batch -- so no per-step device-to-device input copy
+                    state["args"] = ts.input_buffers()
+                return out
+        elif mode == "forward":
+            def step():
+                with torch.no_grad():
+                    e = enc(feats)
+                    return dec(batch["captions"], e, batch["caption_masks"], batch["caption_lengths"],
+                               batch["entities"], *extra)
+        elif mode == "greedy":
+            def step():
+                e = enc(feats)
+                return dec.predict(e, L, batch["entities"], *extra)
+        else:
+            def step():
+                e = enc(feats)
+                return dec.predict_beam(e, L, batch["entities"], *extra, beam_size=BEAM)
+        return step
+
+    def graph_in_use(self):
+        """Did the timed steps replay captured hipGraphs (True) or fall back to eager launches (False)?"""
+        if self.mode == "train":
+            return bool(self.train_step is not None and self.train_step.use_graph and self.train_step._graphs)
+        return bool(self.dec.use_hip_graphs and self.dec.__dict__.get("_graphs"))
+
+
+def run_workload(wl, steps, warmup, min_seconds, world, profile_steps, max_repeats=400):
+    """-> dict(ms_per_step, value, repeats, timed_region_s, graph, by_kernel)."""
+    import torch.distributed as dist
+    import ick_amd.profiling as prof
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def block(step):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        dt = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return dt.item()
+
+    step = wl.make_step()
+    for _ in range(warmup):
+        step()
+    times = [block(step)]
+    # every rank derives the same repeat count from the (max-reduced) first block
+    repeats = int(min(max_repeats, max(1, -(-min_seconds // max(times[0], 1e-6)))))
+    for _ in range(repeats - 1):
+        times.append(block(step))
+    dt = statistics.median(times)
+    graph = wl.graph_in_use()
+
+    # ---- per-kernel pass: the same step launched eagerly on one stream, every C-ABI launch bracketed by HIP events
+    # (every rank runs it -- the train step holds a collective -- but only rank 0 records)
+    by_kernel = []
+    if profile_steps > 0:
+        wl.dec.use_hip_graphs = False
+        os.environ["ICK_GROUP_SAME_STREAM"] = "1"     # the captured step's launches (grouped weight gradients, staged
+                                                       # packs, 8-wave context chains), one stream
+        pstep = wl.make_step(use_graph=False)
+        pstep()
+        fence()
+        if wl.rank == 0:
+            prof.start()
+        for _ in range(profile_steps):
+            pstep()
+        if wl.rank == 0:
+            by_kernel = prof.summarise(prof.stop(), profile_steps)
+        fence()
+        os.environ.pop("ICK_GROUP_SAME_STREAM", None)
+        wl.dec.use_hip_graphs = True
+    return {"ms_per_step": dt / steps * 1e3, "value": world * wl.units_per_step * steps / dt, "repeats": len(times),
+            "timed_region_s": sum(times), "block_s_min_median_max": [min(times), dt, max(times)], "graph": graph,
+            "by_kernel": by_kernel}
+
+
+def pass_fraction(cfgname, mode, ms_per_step, L):
+    """The whole step against the peak for the work it executes: FLOPs for the teacher-forced passes (fp32 MFMA
+    peak), algorithmic bytes per token step for the KV-cached decodes (HBM peak).  None when no closed form is kept."""
+    ex = EXECUTED_GFLOP.get((cfgname, mode))
+    if ex is not None:
+        return {"bound": "mfma", "frac": ex * 1e9 / (ms_per_step * 1e-3) / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+                "executed_gflop_per_step": ex}
+    mb = ALGO_MB_PER_TOKEN.get((cfgname, mode))
+    if mb is not None:
+        # one bench step = conv1 + prefill + L token steps; the bound counts the token steps only
+        return {"bound": "hbm", "frac": mb * 1e6 * L / (ms_per_step * 1e-3) / (PEAK_HBM_GBS * 1e9),
+                "algorithmic_mb_per_token_step": mb}
+    return None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -170,138 +341,33 @@ def main():
         assert probe.item() == world, "all-reduce probe returned %s for %d ranks" % (probe.item(), world)
         backend = dist.get_backend()
 
-    import ick_amd
-    import ick_amd.profiling as prof
-    import ick_amd.synth as synth
-
     cfgname = args.config or ("cfg5" if args.mode in ("greedy", "beam") else "cfg2")
-    cfg = dict(synth.CONFIGS[cfgname])
-    variant, B, L, K, V, Fn = cfg["variant"], cfg["B"], cfg["L"], cfg["K"], cfg["V"], cfg["F"]
-    seed = 100 + rank  # every rank owns a different shard of the global batch
-    m = ick_amd.load_models(variant)
-    dec = m.DecoderTransformer(synth.make_word_map(V), 300, 512, 512, 10, 3)
-    dec.load_state_dict(synth.make_params(variant, V, 0), strict=False)  # same weights on every rank
-    dec = dec.cuda()
-    dec = dec.train() if args.mode == "train" else dec.eval()
-    enc = m.Encoder(emb_dim=300)
-    cw, cb = synth.make_conv1(0)
-    with torch.no_grad():
-        enc.conv1.weight.copy_(cw)
-        enc.conv1.bias.copy_(cb)
-    enc = enc.cuda().eval()
-    batch = {k: v.cuda() for k, v in synth.make_batch(variant, B, L, K, V, Fn, seed).items()}
-    feats = synth.make_feats(B, seed).cuda()
-    extra = [batch["facts"]] if variant != "geo" else []
-    beam = 5
-
-    def make_step(use_graph=True):
-        if args.mode == "train":
-            from ick_amd.training import TrainStep
-            # encoder=: the step takes the feature map itself; Encoder.conv1 runs inside the captured step and writes
-            # the image rows straight into the decoder's memory buffer.  All-reduces its bucket when world > 1.
-            ts = TrainStep(dec, lr=4e-4, grad_clip=5.0, seed=rank, use_graph=use_graph, encoder=enc)
-            live = (batch["captions"], feats, batch["caption_masks"], batch["caption_lengths"], batch["entities"], *extra)
-            state = {"args": live}
-
-            legacy = os.environ.get("ICK_BENCH_SEPARATE_ENCODER") == "1"   # A/B: eager Encoder + per-step input copies
-
-            def step():
-                if legacy:
-                    with torch.no_grad():
-                        e = enc(feats)
-                    return ts(batch["captions"], e, batch["caption_masks"], batch["caption_lengths"],
-                              batch["entities"], *extra)
-                out = ts(*state["args"])
-                if state["args"] is live and ts.use_graph:
-                    # from now on the (HBM-resident) batch lives in the step's own input buffers -- where a loader's
-                    # host-to-device copy would put the next batch -- so no per-step device-to-device input copy
-                    state["args"] = ts.input_buffers()
-                return out
-        elif args.mode == "forward":
-            def step():
-                with torch.no_grad():
-                    e = enc(feats)
-                    return dec(batch["captions"], e, batch["caption_masks"], batch["caption_lengths"],
-                               batch["entities"], *extra)
-        elif args.mode == "greedy":
-            def step():
-                e = enc(feats)
-                return dec.predict(e, L, batch["entities"], *extra)
-        else:
-            def step():
-                e = enc(feats)
-                return dec.predict_beam(e, L, batch["entities"], *extra, beam_size=beam)
-        return step
-
-    step = make_step()
-    units_per_step = B * L
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = tmax.item()
-
-    # ---- per-kernel pass: the same step launched eagerly on one stream, every C-ABI launch bracketed by HIP events
-    # (every rank runs it -- the train step holds a collective -- but only rank 0 records)
-    by_kernel = []
-    if not args.no_profile:
-        dec.use_hip_graphs = False
-        os.environ["ICK_GROUP_SAME_STREAM"] = "1"     # the captured step's launches (grouped weight gradients, staged
-                                                       # packs, 8-wave context chains), one stream
-        pstep = make_step(use_graph=False)
-        pstep()
-        fence()
-        if rank == 0:
-            prof.start()
-        for _ in range(args.profile_steps):
-            pstep()
-        if rank == 0:
-            by_kernel = prof.summarise(prof.stop(), args.profile_steps)
-        fence()
-        os.environ.pop("ICK_GROUP_SAME_STREAM", None)
-        dec.use_hip_graphs = True
+    wl = Workload(args.mode, cfgname, rank)
+    res = run_workload(wl, args.steps, args.warmup, args.min_seconds, world, 0 if args.no_profile else args.profile_steps)
+    cfg, seed = wl.cfg, wl.seed
+    B, L = cfg["B"], cfg["L"]
 
     if rank == 0:
         out = {
-            "metric": "decode_steps_per_sec", "value": world * units_per_step * args.steps / dt,
+            "metric": "decode_steps_per_sec", "value": res["value"],
             "unit": "decode-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "timed_region_s": dt, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": res["ms_per_step"], "repeats": res["repeats"], "timed_region_s": res["timed_region_s"],
+            "block_s_min_median_max": res["block_s_min_median_max"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %s variant, per-GPU batch %d x %d decode positions, 14x14x2048 features, "
-                                   "K=%d knowledge rows%s, vocab %d" % (cfgname, variant, B, L, K,
-                                                                         (", F=%d facts" % Fn) if Fn else "", V),
+            "config": {"workload": wl.describe(),
                        "mode": {"train": "train_step (Encoder.conv1 + forward + packed CE + backward + gradient "
                                          "all-reduce + clamp + Adam; dropout 0.5/0.5/0.1 as the reference's train.py "
                                          "builds it)",
                                 "forward": "teacher_forced_forward (Encoder.conv1 + DecoderTransformer.forward)",
                                 "greedy": "greedy_decode (Encoder.conv1 + predict, KV-cached)",
-                                "beam": "beam_decode (Encoder.conv1 + predict_beam, beam %d, KV-cached)" % beam}[args.mode],
+                                "beam": "beam_decode (Encoder.conv1 + predict_beam, beam %d, KV-cached)" % BEAM}[args.mode],
                        "global_batch": world * B,
+                       "graph": res["graph"],      # False = hipGraph capture failed and the steps were launched eagerly
                        "collective_backend": backend if args.mode == "train" else "none",
                        "parallelism": ("dp%d (one flat-bucket all-reduce per step)" if args.mode == "train"
                                        else "dp%d (independent shards)") % world},
         }
-        # whole-pass view: measured decode-steps/s against the bound of the pass's algorithmic work
-        # at the same peaks -- teacher-forced passes are MFMA-bound (a train step is counted as 3x the forward FLOPs;
-        # the step EXECUTES less: no conv1 backward, no data gradient into the image rows), the KV-cached greedy
-        # decode is HBM-bound
-        bounds = {("cfg2", "forward"): 3.96e6, ("cfg2", "train"): 3.96e6 / 3, ("cfg4", "forward"): 1.99e6,
-                  ("cfg4", "train"): 1.99e6 / 3, ("cfg5", "greedy"): 3.39e6}
-        executed_gflop = {("cfg2", "train"): 108.0, ("cfg2", "forward"): 50.85, ("cfg4", "forward"): 101.3}
+        by_kernel = res["by_kernel"]
         roof = {}
         traffic = {}
         if os.path.exists(TRAFFIC_TABLE):
@@ -322,14 +388,53 @@ def main():
                     "how": "HIP events on the launch stream around every C-ABI launch of %d eager single-stream steps "
                            "after the timed region; work = algorithmic FLOP (fp32 MFMA peak %.1f TFLOP/s) or bytes "
                            "(HBM peak %.0f GB/s)" % (args.profile_steps, PEAK_FP32_MFMA_TFLOPS, PEAK_HBM_GBS)}
-        bnd = bounds.get((cfgname, args.mode))
-        if bnd is not None:
-            roof["pass_bound_steps_per_s"] = bnd * world
-            roof["pass_frac"] = out["value"] / (bnd * world)
-        ex = executed_gflop.get((cfgname, args.mode))
-        if ex is not None:
-            roof["pass_frac_executed"] = ex * 1e9 * world / (dt / args.steps) / (PEAK_FP32_MFMA_TFLOPS * 1e12 * world)
+        pf = pass_fraction(cfgname, args.mode, res["ms_per_step"], L)
+        if pf is not None:
+            roof["pass_frac_executed"] = pf["frac"]
+            roof["pass_bound"] = pf["bound"]
+            roof.update({k: v for k, v in pf.items() if k not in ("frac", "bound")})
         out["roofline"] = roof
+
+    # ---- the other workloads of SURVEY.md 8(d), one GPU only (no collective inside; kept off for N > 1 so that the
+    # scaling runs stay short).  Each runs in a child process of its own: several workloads in ONE process slow each
+    # other down (measured: greedy 9.3 ms instead of 2.4 ms per decode behind a train workload -- the streams and
+    # graphs of the earlier workloads stay with the HIP runtime), and a child's number is the number a user of that
+    # mode alone would see.
+    if world == 1 and not args.no_modes:
+        import subprocess
+        modes = {}
+        del wl
+        gc.collect()
+        torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+        for name, mode, cname, steps in (("forward_cfg2", "forward", "cfg2", 50), ("greedy_cfg5", "greedy", "cfg5", 20),
+                                         ("beam5_cfg5", "beam", "cfg5", 10), ("train_cfg4", "train", "cfg4", 20)):
+            if (mode, cname) == (args.mode, cfgname):
+                continue
+            cmd = [sys.executable, os.path.abspath(__file__), "--mode", mode, "--config", cname, "--steps", str(steps),
+                   "--warmup", "3", "--min-seconds", "0.5", "--no-modes", "--no-cpu-baseline", "--profile-steps",
+                   "0" if args.no_profile else "2"] + (["--no-profile"] if args.no_profile else [])
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+            r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                modes[name] = {"error": (r.stderr or r.stdout)[-400:]}
+                continue
+            c = json.loads(lines[-1])
+            entry = {"workload": c["config"]["workload"], "mode": mode, "steps": steps, "repeats": c["repeats"],
+                     "ms_per_step": c["ms_per_step"], "value": c["value"], "unit": c["unit"], "graph": c["config"]["graph"]}
+            rf = c.get("roofline", {})
+            if "pass_frac_executed" in rf:
+                entry["pass_frac"] = rf["pass_frac_executed"]
+                entry["pass_bound"] = rf["pass_bound"]
+            if rf.get("kernel"):
+                entry["dominant_kernel"] = {"name": rf["kernel"], "avg_us": rf["kernel_avg_us"],
+                                            "launches_per_step": rf["launches_per_step"], "frac": rf.get("frac"),
+                                            "bound": rf.get("bound"), "share_of_kernel_time": rf["share_of_kernel_time"]}
+            modes[name] = entry
+        out["modes"] = modes
+
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, seed, args.cpu_seconds,
                                                {"train": "train", "greedy": "greedy", "beam": "greedy"}.get(args.mode, "forward"))

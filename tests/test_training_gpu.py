@@ -415,13 +415,15 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     env = dict(os.environ, ICK_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "2", "--no-cpu-baseline"]
+           "--warmup", "2", "--no-cpu-baseline", "--min-seconds", "0.2"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["graph"] is True and d["repeats"] >= 1 and d["steps"] == 3 and "modes" not in d
+    assert "pass_frac" not in d["roofline"] and d["roofline"]["pass_frac_executed"] > 0
 
 
 def test_train_step_from_features_and_in_place_input_buffers():

@@ -10,4 +10,4 @@ import ick_amd.build as b
 out = os.path.join("$root", "gpurun_out", "lib_$tag.so")
 subprocess.check_call([b.HIPCC] + b.FLAGS + "$flags".split() + ["-shared", "-o", out] + b.sources())
 PY
-ICK_LIB_PATH=$root/gpurun_out/lib_$tag.so python3 $root/bench.py "$@" --no-cpu-baseline --no-profile | cut -c1-160
+ICK_LIB_PATH=$root/gpurun_out/lib_$tag.so python3 $root/bench.py "$@" --no-cpu-baseline --no-profile --no-modes | cut -c1-160

@@ -9,7 +9,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
   i=$((i+1))
   out=$root/gpurun_out/pmc_${tag}_$i
   rm -rf $out
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out -o run -- python3 $root/bench.py --mode $mode --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $out.log 2>&1 || { tail -5 $out.log; continue; }
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out -o run -- python3 $root/bench.py --mode $mode --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-modes --min-seconds 0 > $out.log 2>&1 || { tail -5 $out.log; continue; }
 done
 python3 - <<PY > $root/gpurun_out/${tag}_pmc_decode.txt
 import collections, csv, glob

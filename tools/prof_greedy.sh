@@ -2,5 +2,5 @@ set -e
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_greedy_$1
 rm -rf $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o runc -- python3 $GRAFT_REPO_ROOT/bench.py --mode greedy --steps 5 --warmup 2 --no-cpu-baseline > $out.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o runc -- python3 $GRAFT_REPO_ROOT/bench.py --mode greedy --steps 5 --warmup 2 --no-cpu-baseline --no-modes --min-seconds 0 > $out.log 2>&1
 tail -1 $out.log | cut -c1-100
