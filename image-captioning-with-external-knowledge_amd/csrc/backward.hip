@@ -9,8 +9,6 @@
 namespace ick {
 namespace {
 
-constexpr int kMaxPerLane = 16;
-
 // ---------------------------------------------------------------------------------------------
 // LayerNorm backward for y = LN(z) * gamma + beta with z = x + res (recomputed here):
 //   zh = (z - mean) * rstd;  g = dy * gamma
@@ -31,11 +29,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             float* __restrict__ dx_drop, DropArg darg,
                                                             float* __restrict__ partials) {
     chain_priority();
-    extern __shared__ float sm[];  // 2 * d partial sums
+    extern __shared__ float sm[];  // 4 waves x 2 * d partial sums, added in wave order (no LDS atomics: deterministic)
     const Dropout drop = darg.get();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 2 * d; i += 256) sm[i] = 0.f;
-    __syncthreads();
     float ag[NJ], ab[NJ], gm[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -101,19 +97,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int j = 0; j < NJ; ++j) {
         const int c = lane + 64 * j;
         if (c < d) {
-            atomicAdd(&sm[c], ag[j]);
-            atomicAdd(&sm[d + c], ab[j]);
+            sm[wave * 2 * d + c] = ag[j];
+            sm[wave * 2 * d + d + c] = ab[j];
         }
     }
     __syncthreads();
     if (partials) {
         float* pr = partials + (int64_t)blockIdx.x * 2 * d;
-        for (int i = threadIdx.x; i < 2 * d; i += 256) pr[i] = sm[i];
+        for (int i = threadIdx.x; i < 2 * d; i += 256) pr[i] = (sm[i] + sm[2 * d + i]) + (sm[4 * d + i] + sm[6 * d + i]);
         return;
     }
     for (int i = threadIdx.x; i < d; i += 256) {
-        atomicAdd(dgamma + i, sm[i]);
-        atomicAdd(dbeta + i, sm[d + i]);
+        atomicAdd(dgamma + i, (sm[i] + sm[2 * d + i]) + (sm[4 * d + i] + sm[6 * d + i]));
+        atomicAdd(dbeta + i, (sm[d + i] + sm[3 * d + i]) + (sm[5 * d + i] + sm[7 * d + i]));
     }
 }
 
@@ -186,6 +182,117 @@ __global__ __launch_bounds__(256) void caption_embed_bwd_kernel(const float* __r
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Deterministic forms of the scatter-adds above (ick_set_deterministic / ICK_DETERMINISTIC=1).  A float atomic lets the
+// hardware pick the order in which a destination row receives its terms; here the SOURCE rows are walked in index order
+// by every workgroup, and workgroup p applies only the terms whose destination row r has r % kDetParts == p: one
+// thread owns one column of a destination row for the whole launch, so its terms arrive in source order.
+// ---------------------------------------------------------------------------------------------
+constexpr int kDetParts = 32;
+
+__global__ __launch_bounds__(256) void caption_embed_bwd_det_kernel(const float* __restrict__ dx,
+                                                                    const int64_t* __restrict__ captions,
+                                                                    const int64_t* __restrict__ masks,
+                                                                    float* __restrict__ dword, float* __restrict__ dee,
+                                                                    float* __restrict__ dfe, int B, int L, int K, int F,
+                                                                    int V, int d, int pad_token, float scale,
+                                                                    DropArg darg) {
+    const Dropout drop = darg.get();
+    const int p = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    for (int row = 0; row < B * L; ++row) {
+        const int b = row / L;
+        const int64_t tok = captions[row];
+        const int64_t m = masks[row];
+        float* dst;
+        int64_t key;
+        if (m == 1) {
+            int64_t ei = tok - V;
+            if (ei < 0 || ei >= K) ei = K - 1;
+            key = (int64_t)b * K + ei;
+            dst = dee + key * d;
+        } else if (m == 2 && dfe != nullptr) {
+            int64_t fi = tok - V - K;
+            if (fi < 0 || fi >= F) fi = F - 1;
+            key = (int64_t)b * F + fi;
+            dst = dfe + key * d;
+            key += 11;
+        } else {
+            if (dword == nullptr) continue;
+            int64_t w = tok >= V ? (int64_t)pad_token : tok;
+            if (w < 0) w = pad_token;
+            key = w + 23;
+            dst = dword + w * d;
+        }
+        if ((int)(key % kDetParts) != p || c >= d) continue;       // uniform per workgroup except the column guard
+        float v = dx[(int64_t)row * d + c] * scale;
+        if (drop.on()) v *= drop.mask((uint32_t)row * (uint32_t)d + (uint32_t)c);
+        if (v != 0.f) dst[c] += v;
+    }
+}
+
+__global__ __launch_bounds__(256) void entity_encode_bwd_det_kernel(int variant, const float* __restrict__ dee,
+                                                                    const float* __restrict__ ent, int cols,
+                                                                    const float* __restrict__ ee,
+                                                                    const float* __restrict__ word_emb, int vocab,
+                                                                    float* __restrict__ dtype_emb, int ntypes,
+                                                                    float* __restrict__ dword, int B, int K, int d) {
+    const int p = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    const int type_off = variant == ICK_GEO ? 4 : (variant == ICK_KNOWLEDGE ? 6 : 5);
+    for (int row = 0; row < B * K; ++row) {
+        const float* e = ent + (int64_t)row * cols;
+        int ty = (int)e[4];
+        ty = ty < 0 ? 0 : (ty >= ntypes ? ntypes - 1 : ty);
+        int name[5] = {0, 0, 0, 0, 0};
+        bool mine = ty % kDetParts == p;
+        if (variant == ICK_NEWS) {
+#pragma unroll
+            for (int w = 0; w < 5; ++w) {
+                int n = (int)e[5 + w];
+                name[w] = n < 0 ? 0 : (n >= vocab ? vocab - 1 : n);
+                mine = mine || (dword != nullptr && name[w] % kDetParts == p);
+            }
+        }
+        if (!mine || c >= d) continue;
+        float g = dee[(int64_t)row * d + c];
+        if (variant == ICK_NEWS) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 5; ++w) s += word_emb[(int64_t)name[w] * d + c];
+            const float avg = s / 5.0f;
+            const float enc_g = g * avg;
+            if (dword) {
+                const float enc = avg != 0.f ? ee[(int64_t)row * d + c] / avg : 0.f;
+                const float gw = g * enc / 5.0f;
+#pragma unroll
+                for (int w = 0; w < 5; ++w)
+                    if (name[w] % kDetParts == p) dword[(int64_t)name[w] * d + c] += gw;
+            }
+            g = enc_g;
+        }
+        if (c >= type_off && ty % kDetParts == p) dtype_emb[(int64_t)ty * (d - type_off) + (c - type_off)] += g;
+    }
+}
+
+__global__ __launch_bounds__(256) void fact_encode_bwd_det_kernel(const float* __restrict__ dfe,
+                                                                  const int64_t* __restrict__ facts, float* __restrict__ dee,
+                                                                  float* __restrict__ dpred, int num_pred, int B, int K,
+                                                                  int F, int d) {
+    const int p = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    for (int row = 0; row < B * F; ++row) {
+        const int b = row / F;
+        int subj = (int)facts[(int64_t)row * 3 + 1];
+        int pred = (int)facts[(int64_t)row * 3 + 2];
+        subj = subj < 0 ? 0 : (subj >= K ? K - 1 : subj);
+        pred = pred < 0 ? 0 : (pred >= num_pred ? num_pred - 1 : pred);
+        const bool e_mine = (b * K + subj) % kDetParts == p, p_mine = pred % kDetParts == p;
+        if ((!e_mine && !p_mine) || c >= d) continue;
+        const float g = dfe[(int64_t)row * d + c];
+        if (e_mine) dee[((int64_t)b * K + subj) * d + c] += g;
+        if (p_mine) dpred[(int64_t)pred * d + c] += g;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Pointer-score backward.  s[b,t,k] = ind * sum_d h*ctx*w + bias
 //   dh[b,t,:]   += sum_k ds*ind * ctx[b,k,:] * w        (one workgroup per (b,t))
@@ -226,16 +333,20 @@ __global__ __launch_bounds__(256) void pointer_bwd_dh_kernel(const float* __rest
 // One workgroup per (sample, 64 columns): the (T x Kc) score gradients of the sample sit in LDS, lane <-> column,
 // the four waves share the Kc context rows.  d w and d bias leave the workgroup as one float atomic per column /
 // one per sample (a workgroup per (sample, row) made 1280 workgroups fight over the same 300 addresses: 59 us).
+// SEQ (deterministic mode): one workgroup per column block walks the samples in order and adds its d w / d bias terms
+// with plain read-modify-writes instead of one float atomic per sample.
+template <bool SEQ>
 __global__ __launch_bounds__(256) void pointer_bwd_dctx_kernel(const float* __restrict__ ds, int64_t ds_ld, int col0,
                                                                const float* __restrict__ h, const float* __restrict__ ctx,
                                                                const float* __restrict__ w, const float* __restrict__ ind,
                                                                float* __restrict__ dctx, float* __restrict__ dw,
-                                                               float* __restrict__ dbias, int T, int Kc, int d) {
+                                                               float* __restrict__ dbias, int B, int T, int Kc, int d) {
     chain_priority();
     extern __shared__ float gs[];   // T * Kc gradients (indicator applied), 4 floats of scratch, 4 x 64 partial d w
     float* red = gs + T * Kc;
     float* dwp = red + 4;
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b = SEQ ? 0 : blockIdx.x; b < (SEQ ? B : (int)blockIdx.x + 1); ++b) {
     float bsum = 0.f;
     for (int idx = threadIdx.x; idx < T * Kc; idx += 256) {
         const int t = idx / Kc, k = idx - t * Kc;
@@ -245,7 +356,7 @@ __global__ __launch_bounds__(256) void pointer_bwd_dctx_kernel(const float* __re
         gs[idx] = g;
     }
     bsum = block_sum<4>(bsum, red);   // contains the barriers that publish gs
-    if (threadIdx.x == 0 && blockIdx.y == 0) atomicAdd(dbias, bsum);
+    if (threadIdx.x == 0 && blockIdx.y == 0) { if (SEQ) dbias[0] += bsum; else atomicAdd(dbias, bsum); }
     const int c = blockIdx.y * 64 + lane;
     const bool ok = c < d;
     const float* hb = h + (int64_t)b * T * d + (ok ? c : 0);
@@ -262,7 +373,12 @@ __global__ __launch_bounds__(256) void pointer_bwd_dctx_kernel(const float* __re
     }
     dwp[wave * 64 + lane] = dwl;
     __syncthreads();
-    if (wave == 0 && ok) atomicAdd(dw + c, (dwp[lane] + dwp[64 + lane]) + (dwp[128 + lane] + dwp[192 + lane]));
+    if (wave == 0 && ok) {
+        const float t = (dwp[lane] + dwp[64 + lane]) + (dwp[128 + lane] + dwp[192 + lane]);
+        if (SEQ) dw[c] += t; else atomicAdd(dw + c, t);
+    }
+    if (SEQ) __syncthreads();          // the LDS buffers are rewritten for the next sample
+  }
 }
 
 // EntityEncoder backward: only the type embedding is trainable (feature slots are inputs).  News:
@@ -336,17 +452,19 @@ __global__ __launch_bounds__(256) void fact_encode_bwd_kernel(const float* __res
 // => dW[:, pred] += sum over positions where pred is active of dgate[b,p,:];  dbias += sum dgate.
 // Same activation / representative logic as context_indicators_kernel (prefill.hip).
 constexpr int kInf = 0x3fffffff;
+template <bool SEQ>
 __global__ __launch_bounds__(256) void context_gate_bwd_kernel(const int64_t* __restrict__ captions,
                                                                const int64_t* __restrict__ facts,
                                                                const float* __restrict__ dgate, float* __restrict__ dw,
-                                                               float* __restrict__ dbias, int L, int T, int K, int F,
+                                                               float* __restrict__ dbias, int B, int L, int T, int K, int F,
                                                                int V, int num_pred, int d, int mode) {
     extern __shared__ int smi[];
     int* first = smi;
     int* act = first + K;
     int* pred = act + F;
     int* rep = pred + F;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+  for (int b = SEQ ? 0 : blockIdx.x; b < (SEQ ? B : (int)blockIdx.x + 1); ++b) {
     for (int k = tid; k < K; k += 256) first[k] = kInf;
     __syncthreads();
     for (int t = tid; t < L; t += 256) {
@@ -381,12 +499,15 @@ __global__ __launch_bounds__(256) void context_gate_bwd_kernel(const int64_t* __
             run += dgate[((int64_t)b * T + p) * d + c];
             suf[p * 256 + tid] = run;
         }
-        atomicAdd(dbias + c, run);
+        if (SEQ) dbias[c] += run; else atomicAdd(dbias + c, run);
         for (int j = 0; j < F; ++j) {
             if (!rep[j] || act[j] >= T) continue;
-            atomicAdd(dw + (int64_t)c * num_pred + pred[j], suf[act[j] * 256 + tid]);  // fc_predicate.weight is (d, num_pred)
+            float* dst = dw + (int64_t)c * num_pred + pred[j];             // fc_predicate.weight is (d, num_pred)
+            if (SEQ) *dst += suf[act[j] * 256 + tid]; else atomicAdd(dst, suf[act[j] * 256 + tid]);
         }
     }
+    if (SEQ) __syncthreads();          // the LDS tables are rebuilt for the next sample
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -445,12 +566,13 @@ extern "C" int ick_layernorm_bwd(const float* dy, const float* x, const float* r
                                  uint32_t drop_site, const uint32_t* drop_epoch, float* partials, void* stream) {
     ICK_CHECK_ARG(dy && x && gamma && mean && rstd && dz && rows > 0 && d > 0 && d <= 1024);
     ICK_CHECK_ARG(partials || (dgamma && dbeta));
+    ICK_CHECK_ARG(partials || !deterministic());       // without a workspace the workgroups meet in float atomics
     ICK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || dx_drop != nullptr));
     const int rpb = ick_layernorm_bwd_rows_per_block();   // two rows per wave: 160 workgroups for the 1280 rows of a layer (one row per wave measured slower: 10.0 vs 8.4 us)
     const DropArg dr{drop_p, drop_seed, drop_site, drop_epoch};
     float* dxd = dx_drop;   // written whenever given: dz * mask, or a plain copy of dz without dropout
     const dim3 grid(ceil_div(rows, rpb));
-    const size_t sm = 2 * d * sizeof(float);
+    const size_t sm = 8 * d * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     if (d <= 320)
         hipLaunchKernelGGL(layernorm_bwd_kernel<5>, grid, dim3(256), sm, s, dy, x, res, gamma, mean, rstd, dz, dgamma,
@@ -473,7 +595,7 @@ extern "C" int ick_relu_bwd(const float* dy, const float* act, float* dx, int64_
 
 extern "C" int ick_colsum(const float* a, int64_t M, int32_t N, int64_t ld, float* out, void* stream) {
     ICK_CHECK_ARG(a && out && M > 0 && N > 0 && ld >= N);
-    const int rpb = 64;
+    const int rpb = deterministic() ? (int)std::min<int64_t>(M, 1 << 30) : 64;     // one slab: no atomics between slabs
     ICK_CHECK_ARG(ceil_div(M, rpb) <= 65535);
     hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64), ceil_div(M, rpb)), dim3(256), 0, (hipStream_t)stream, a, M,
                        N, ld, out, rpb);
@@ -485,9 +607,14 @@ extern "C" int ick_caption_embed_bwd(const float* dx, const int64_t* captions, c
                                      int32_t d, int32_t pad_token, float scale, float drop_p, uint32_t drop_seed,
                                      uint32_t drop_site, const uint32_t* drop_epoch, void* stream) {
     ICK_CHECK_ARG(dx && captions && masks && dee && B > 0 && L > 0 && K > 0 && d > 0);
-    hipLaunchKernelGGL(caption_embed_bwd_kernel, dim3(ceil_div((int64_t)B * L, 4)), dim3(256), 0, (hipStream_t)stream,
-                       dx, captions, masks, dword, dee, dfe, B, L, K, F, V, d, pad_token, scale,
-                       DropArg{drop_p, drop_seed, drop_site, drop_epoch});
+    if (deterministic())
+        hipLaunchKernelGGL(caption_embed_bwd_det_kernel, dim3(kDetParts, ceil_div(d, 256)), dim3(256), 0,
+                           (hipStream_t)stream, dx, captions, masks, dword, dee, dfe, B, L, K, F, V, d, pad_token, scale,
+                           DropArg{drop_p, drop_seed, drop_site, drop_epoch});
+    else
+        hipLaunchKernelGGL(caption_embed_bwd_kernel, dim3(ceil_div((int64_t)B * L, 4)), dim3(256), 0, (hipStream_t)stream,
+                           dx, captions, masks, dword, dee, dfe, B, L, K, F, V, d, pad_token, scale,
+                           DropArg{drop_p, drop_seed, drop_site, drop_epoch});
     ICK_LAUNCH_RET();
 }
 
@@ -499,8 +626,12 @@ extern "C" int ick_pointer_scores_bwd(const float* ds, int64_t ds_ld, int32_t co
     hipLaunchKernelGGL(pointer_bwd_dh_kernel, dim3(T, B), dim3(256), 0, s, ds, ds_ld, col0, ctx, w, ind, dh, T, Kc, d);
     const size_t smem = ((size_t)T * Kc + 4 + 256) * sizeof(float);
     ICK_CHECK_ARG(smem <= 64 * 1024);
-    hipLaunchKernelGGL(pointer_bwd_dctx_kernel, dim3(B, ceil_div(d, 64)), dim3(256), smem, s, ds, ds_ld, col0, h, ctx, w,
-                       ind, dctx, dw, dbias, T, Kc, d);
+    if (deterministic())
+        hipLaunchKernelGGL(pointer_bwd_dctx_kernel<true>, dim3(1, ceil_div(d, 64)), dim3(256), smem, s, ds, ds_ld, col0, h,
+                           ctx, w, ind, dctx, dw, dbias, B, T, Kc, d);
+    else
+        hipLaunchKernelGGL(pointer_bwd_dctx_kernel<false>, dim3(B, ceil_div(d, 64)), dim3(256), smem, s, ds, ds_ld, col0, h,
+                           ctx, w, ind, dctx, dw, dbias, B, T, Kc, d);
     ICK_LAUNCH_RET();
 }
 
@@ -509,16 +640,25 @@ extern "C" int ick_entity_encode_bwd(int32_t variant, const float* dee, const fl
                                      int32_t ntypes, float* dword, int32_t B, int32_t K, int32_t d, void* stream) {
     ICK_CHECK_ARG(dee && entities && dtype_emb && B > 0 && K > 0 && d > 6);
     if (variant == ICK_NEWS) ICK_CHECK_ARG(ee && word_emb && vocab > 0);
-    hipLaunchKernelGGL(entity_encode_bwd_kernel, dim3(ceil_div((int64_t)B * K, 4)), dim3(256), 0, (hipStream_t)stream,
-                       variant, dee, entities, ent_cols, ee, word_emb, vocab, dtype_emb, ntypes, dword, B, K, d);
+    if (deterministic())
+        hipLaunchKernelGGL(entity_encode_bwd_det_kernel, dim3(kDetParts, ceil_div(d, 256)), dim3(256), 0,
+                           (hipStream_t)stream, variant, dee, entities, ent_cols, ee, word_emb, vocab, dtype_emb, ntypes,
+                           dword, B, K, d);
+    else
+        hipLaunchKernelGGL(entity_encode_bwd_kernel, dim3(ceil_div((int64_t)B * K, 4)), dim3(256), 0, (hipStream_t)stream,
+                           variant, dee, entities, ent_cols, ee, word_emb, vocab, dtype_emb, ntypes, dword, B, K, d);
     ICK_LAUNCH_RET();
 }
 
 extern "C" int ick_fact_encode_bwd(const float* dfe, const int64_t* facts, float* dee, float* dpred, int32_t num_pred,
                                    int32_t B, int32_t K, int32_t F, int32_t d, void* stream) {
     ICK_CHECK_ARG(dfe && facts && dee && dpred && B > 0 && K > 0 && F > 0 && d > 0);
-    hipLaunchKernelGGL(fact_encode_bwd_kernel, dim3(ceil_div((int64_t)B * F, 4)), dim3(256), 0, (hipStream_t)stream,
-                       dfe, facts, dee, dpred, num_pred, B, K, F, d);
+    if (deterministic())
+        hipLaunchKernelGGL(fact_encode_bwd_det_kernel, dim3(kDetParts, ceil_div(d, 256)), dim3(256), 0, (hipStream_t)stream,
+                           dfe, facts, dee, dpred, num_pred, B, K, F, d);
+    else
+        hipLaunchKernelGGL(fact_encode_bwd_kernel, dim3(ceil_div((int64_t)B * F, 4)), dim3(256), 0, (hipStream_t)stream,
+                           dfe, facts, dee, dpred, num_pred, B, K, F, d);
     ICK_LAUNCH_RET();
 }
 
@@ -529,8 +669,12 @@ extern "C" int ick_context_gate_bwd(const int64_t* captions, const int64_t* fact
     ICK_CHECK_ARG((mode == 0 && T == L) || (mode == 1 && T == 1));
     const size_t smem = (size_t)(K + 3 * F) * sizeof(int) + (size_t)T * 256 * sizeof(float);
     ICK_CHECK_ARG(smem <= 64 * 1024);
-    hipLaunchKernelGGL(context_gate_bwd_kernel, dim3(B, ceil_div(d, 256)), dim3(256), smem, (hipStream_t)stream, captions,
-                       facts, dgate, dw, dbias, L, T, K, F, V, num_pred, d, mode);
+    if (deterministic())
+        hipLaunchKernelGGL(context_gate_bwd_kernel<true>, dim3(1, ceil_div(d, 256)), dim3(256), smem, (hipStream_t)stream,
+                           captions, facts, dgate, dw, dbias, B, L, T, K, F, V, num_pred, d, mode);
+    else
+        hipLaunchKernelGGL(context_gate_bwd_kernel<false>, dim3(B, ceil_div(d, 256)), dim3(256), smem, (hipStream_t)stream,
+                           captions, facts, dgate, dw, dbias, B, L, T, K, F, V, num_pred, d, mode);
     ICK_LAUNCH_RET();
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "ick_amd.h"
 
@@ -12,6 +13,15 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int kWave = 64;
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+extern int g_deterministic;     // misc.hip: -1 = not set yet (read ICK_DETERMINISTIC), 0 / 1
+inline bool deterministic() {
+    if (g_deterministic < 0) {
+        const char* e = getenv("ICK_DETERMINISTIC");
+        g_deterministic = (e && e[0] && e[0] != '0') ? 1 : 0;
+    }
+    return g_deterministic == 1;
+}
 
 #define ICK_CHECK_ARG(cond)          \
     do {                             \

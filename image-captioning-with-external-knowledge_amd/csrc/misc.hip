@@ -5,6 +5,13 @@
 
 extern "C" int ick_version(void) { return 100; }
 
+// Deterministic mode (ICK_DETERMINISTIC=1 in the environment, or ick_set_deterministic): every gradient reduction that
+// otherwise lets float atomics decide the order of its terms runs in a fixed order instead (backward.hip); the Python
+// side then keeps every GEMM unsplit and the step on one stream.  Slower; bit-reproducible.
+namespace ick { int g_deterministic = -1; }
+extern "C" int ick_set_deterministic(int on) { ick::g_deterministic = on ? 1 : 0; return ICK_OK; }
+extern "C" int ick_get_deterministic(void) { return ick::deterministic() ? 1 : 0; }
+
 extern "C" int ick_device_info(int* num_cu, int* wave_size, char* arch_name, int arch_name_len) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);

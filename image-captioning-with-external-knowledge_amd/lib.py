@@ -130,6 +130,8 @@ class BeamState(C.Structure):
 # name -> argtypes; every entry returns int (0 ok, <0 ICK_E*, >0 hipError_t)
 SIGNATURES = {
     "ick_version": [],
+    "ick_set_deterministic": [C.c_int],
+    "ick_get_deterministic": [],
     "ick_device_info": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int],
     "ick_gemm": [C.POINTER(GemmArgs), vp],
     "ick_gemm_plan": [C.POINTER(GemmArgs), C.POINTER(GemmPlanInfo)],

@@ -83,11 +83,24 @@ def colsum_problem(a2d, out):
     return a
 
 
+def set_deterministic(on=True):
+    """Deterministic mode of the library (ick_set_deterministic): scatter-adds and column sums of the backward pass in a
+    fixed order instead of float atomics; every split below collapses to 1.  training.TrainStep(deterministic=True) and
+    the autograd bridge also keep the step on one stream.  Slower, bit-reproducible run to run."""
+    L.check(L.load().ick_set_deterministic(1 if on else 0), "ick_set_deterministic")
+
+
+def is_deterministic():
+    return bool(L.load().ick_get_deterministic())
+
+
 def wgrad_split(rows, n_out, k_in, grouped=False):
     """K split of a weight-gradient GEMM (reduction over `rows`): enough workgroups to fill the GPU (~1600), slices
     of at least 256 rows.  Measured (probe_ops): vocabulary 10000x300 over 1280 rows 121 us at 5 slices, 91 us at 2.
     grouped: the problem goes out in a layer's grouped launch (~1000 workgroups together): two slices are enough, more
     only add atomics and prologues (train step 2.01 -> 1.98 ms; ICK_WGRAD_SPLIT_MAX overrides the cap)."""
+    if is_deterministic():
+        return 1       # slices of one reduction meet in float atomics: their order would decide the rounding
     tiles = ((n_out + 63) // 64) * ((k_in + 63) // 64)
     cap = int(os.environ.get("ICK_WGRAD_SPLIT_MAX", "2" if grouped else "16"))
     return max(1, min(cap, rows // 256, (1600 + tiles // 2) // tiles))
@@ -810,7 +823,9 @@ def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False, gro
     if need_dx:
         # a long reduction (the vocabulary: N = 10k..50k) over few output tiles is split over workgroups
         split = max(1, min(16, N // 1024)) if (M * K) <= 1280 * 512 else 1
-        if accumulate_dx and split == 1 and N >= 512 and (M * K) <= 1280 * 512:
+        if is_deterministic():
+            split = 1
+        elif accumulate_dx and split == 1 and N >= 512 and (M * K) <= 1280 * 512:
             # the output already holds the residual-path gradient: K slices of ~300 can simply add to it
             # (1280 x 300 x 900: 22 -> ~10 us; the kernel is bound by the latency of its K loop)
             split = max(1, min(8, (N + 150) // 300))

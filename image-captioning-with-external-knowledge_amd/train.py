@@ -20,7 +20,7 @@ from torch.nn.utils.rnn import pack_padded_sequence
 
 from . import dp, load_models, ops
 from . import utils as ut
-from .datasets import CaptionDataset
+from .datasets import CaptionDataset, collated
 from .training import TrainStep
 
 
@@ -51,6 +51,8 @@ class Config:
     out_dir: str = "."
     max_batches: int = 0                               # >0: stop an epoch early (smoke runs)
     seed: int = 0                                      # shuffling seed shared by all ranks (torchrun)
+    prefetch: bool = True                              # fused path: next batch's host-to-device copy on a copy stream
+    half_features: bool = True                         # float16 feature files travel as float16, widened on the device
 
 
 def _batch_to_device(batch, device, has_facts):
@@ -58,6 +60,64 @@ def _batch_to_device(batch, device, has_facts):
     facts = batch[6].to(device) if has_facts else None
     # entity features stay on the host exactly as in geo-aware/train.py:263-266; the decoder moves them
     return imgs.to(device), caps.to(device), caplens.to(device), capmasks.to(device), ent, facts
+
+
+STATS = {}     # "last_epoch_steps_per_s": optimizer steps per second of the last pipelined training epoch (tools/train_rate.py)
+
+
+def _batch_hook(batch):
+    """Called with every host batch the Prefetcher takes from the loader (tests observe the shards through it)."""
+
+
+class Prefetcher:
+    """The next batch's host-to-device copies run on a copy stream while the current step computes (the loop of
+    geo-aware/train.py:263-270 moves each batch synchronously in front of its step: 102.8 MB of fp32 features per 64
+    samples, as long over PCIe as the whole fused step on the GPU).  Batches come out of the DataLoader pinned
+    (pin_memory=True); float16 feature maps are widened on the device.  Yields the tuples _batch_to_device yields, plus
+    the token count (taken from the host copy: no synchronisation)."""
+
+    def __init__(self, loader, device, has_facts):
+        self.it = iter(loader)
+        self.device, self.has_facts = device, has_facts
+        self.stream = torch.cuda.Stream(device)
+        self.next = None
+        self._load()
+
+    def _load(self):
+        try:
+            batch = next(self.it)
+        except StopIteration:
+            self.next = None
+            return
+        _batch_hook(batch)
+        n_tok = int((batch[2] - 1).sum())
+        with torch.cuda.stream(self.stream):
+            imgs = batch[0].to(self.device, non_blocking=True)
+            if imgs.dtype != torch.float32:
+                imgs = imgs.float()
+            caps = batch[1].to(self.device, non_blocking=True)
+            caplens = batch[2].to(self.device, non_blocking=True)
+            capmasks = batch[3].to(self.device, non_blocking=True)
+            ent = batch[4].to(self.device, non_blocking=True)            # the fused step reads them on the device
+            facts = batch[6].to(self.device, non_blocking=True) if self.has_facts else None
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.next = ((imgs, caps, caplens, capmasks, ent, facts), n_tok, ev, batch)   # batch: keeps the pinned source alive
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.next is None:
+            raise StopIteration
+        tensors, n_tok, ev, _ = self.next
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ev)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(cur)
+        self._load()
+        return tensors, n_tok
 
 
 def packed_loss(criterion, scores, caps_sorted, decode_lengths):
@@ -72,8 +132,12 @@ def train(loader, encoder, decoder, criterion, decoder_optimizer, step, epoch, c
     encoder.train()
     batch_time, losses = ut.AverageMeter(), ut.AverageMeter()
     has_facts = decoder.has_facts
-    start = time.time()
+    start = t_epoch = time.time()
+    if step is not None and cfg.prefetch:
+        return _train_fused_pipelined(loader, encoder, step, epoch, cfg, device, has_facts)
+    n_steps = 0
     for i, batch in enumerate(loader):
+        n_steps = i + 1
         imgs, caps, caplens, capmasks, ent, facts = _batch_to_device(batch, device, has_facts)
         extra = (facts,) if has_facts else ()
         if encoder_optimizer is not None:
@@ -107,7 +171,39 @@ def train(loader, encoder, decoder, criterion, decoder_optimizer, step, epoch, c
                   (epoch, i, len(loader), batch_time.val, batch_time.avg, losses.val, losses.avg))
         if cfg.max_batches and i + 1 >= cfg.max_batches:
             break
+    STATS["last_epoch_steps_per_s"] = n_steps / max(time.time() - t_epoch, 1e-9)
     return losses.avg
+
+
+def _train_fused_pipelined(loader, encoder, step, epoch, cfg, device, has_facts):
+    """The fused step fed by the Prefetcher: no host synchronisation inside the loop except when a line is printed --
+    the token-weighted loss sum stays on the device until the epoch ends.  When the step owns the (frozen) encoder it
+    takes the feature map itself and Encoder.conv1 runs inside the captured step."""
+    loss_sum = torch.zeros(1, device=device)
+    tok_sum, start, t_epoch = 0, time.time(), time.time()
+    n = 0
+    for i, (tensors, n_tok) in enumerate(Prefetcher(loader, device, has_facts)):
+        imgs, caps, caplens, capmasks, ent, facts = tensors
+        extra = (facts,) if has_facts else ()
+        if step.enc is not None and imgs.dim() == 4 and imgs.shape[1] == step.enc.encoder_dim:
+            loss = step(caps, imgs, capmasks, caplens, ent, *extra)
+        else:
+            with torch.no_grad():
+                enc = encoder(imgs)
+            loss = step(caps, enc, capmasks, caplens, ent, *extra)
+        loss_sum += loss * float(n_tok)
+        tok_sum += n_tok
+        n = i + 1
+        if i % cfg.print_freq == 0:
+            now = time.time()
+            print("Epoch: [%d][%d/%d]\tBatch Time %.3f\tLoss %.4f (%.4f)" %
+                  (epoch, i, len(loader), now - start, loss.item(), loss_sum.item() / max(tok_sum, 1)))
+        start = time.time()
+        if cfg.max_batches and i + 1 >= cfg.max_batches:
+            break
+    avg = loss_sum.item() / max(tok_sum, 1)            # the epoch's one synchronisation
+    STATS["last_epoch_steps_per_s"] = n / max(time.time() - t_epoch, 1e-9)
+    return avg
 
 
 def validate(loader, encoder, decoder, criterion, cfg, device):
@@ -148,7 +244,8 @@ def make_loaders(cfg, rank, world):
     """TRAIN: one permutation per epoch shared by all ranks (seed + epoch), dealt out in disjoint equal shards --
     DistributedSampler pads by wrapping around so that every rank runs the same number of steps (each step holds a
     collective).  The global batch is cfg.batch_size * world samples.  VAL: disjoint unpadded shards."""
-    data = {s: CaptionDataset(cfg.data_dir, cfg.data_name, s) for s in ("TRAIN", "VAL")}
+    data = {s: CaptionDataset(cfg.data_dir, cfg.data_name, s, keep_half=cfg.half_features and cfg.fused and cfg.prefetch
+                              and s == "TRAIN") for s in ("TRAIN", "VAL")}
     samplers = {"TRAIN": None, "VAL": None}
     if world > 1:
         samplers["TRAIN"] = torch.utils.data.distributed.DistributedSampler(
@@ -159,9 +256,10 @@ def make_loaders(cfg, rank, world):
     loaders = {
         "TRAIN": torch.utils.data.DataLoader(data["TRAIN"], batch_size=cfg.batch_size, shuffle=samplers["TRAIN"] is None,
                                              sampler=samplers["TRAIN"], num_workers=cfg.workers, pin_memory=True,
-                                             generator=gen),
+                                             generator=gen, collate_fn=collated),
         "VAL": torch.utils.data.DataLoader(data["VAL"], batch_size=cfg.batch_size, shuffle=False,
-                                           sampler=samplers["VAL"], num_workers=cfg.workers, pin_memory=True)}
+                                           sampler=samplers["VAL"], num_workers=cfg.workers, pin_memory=True,
+                                           collate_fn=collated)}
     return loaders, samplers, gen
 
 
@@ -215,7 +313,9 @@ def main(cfg=None):
     if fused:
         # seed: the dropout stream, one per rank (the ranks hold different samples); the constructor broadcasts rank
         # 0's weights, so a decoder that was randomly initialised per process starts identical everywhere
-        step = TrainStep(decoder, lr=cfg.decoder_lr, grad_clip=cfg.grad_clip, seed=cfg.seed * 1000 + rank)
+        # encoder=: with the frozen encoder the step takes the feature map itself (Encoder.conv1 inside the captured step)
+        step = TrainStep(decoder, lr=cfg.decoder_lr, grad_clip=cfg.grad_clip, seed=cfg.seed * 1000 + rank,
+                         encoder=encoder if cfg.prefetch else None)
         if decoder_optimizer is not None:
             # resume: Adam moments, step count (bias correction + dropout stream position) and the decayed lr come
             # back from the pickled optimizer (ours or one written by the reference, geo-aware/utils.py:32-46)

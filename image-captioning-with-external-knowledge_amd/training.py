@@ -608,7 +608,7 @@ def _kv_proj_param_grads(layer, li, dkv_rows, mem2, grads, d):
     sl = dkv_rows.view(rows, -1)[:, 2 * li * d:(2 * li + 2) * d]
     if gw is not None:
         wg = ops.gemm_args(sl, mem2, gw[d:], 2 * d, d, rows, 1, sl.stride(0), 1, d, d, atomic=True,
-                           split_k=int(os.environ.get("ICK_KV_WGRAD_SPLIT", "16")),
+                           split_k=1 if ops.is_deterministic() else int(os.environ.get("ICK_KV_WGRAD_SPLIT", "16")),
                            colsum_a=None if gb is None else gb[d:])
         if ops.SIDE is not None:
             ops.SIDE.add_problem(wg, dkv_rows, mem2)
@@ -748,6 +748,8 @@ def _backward_phases(dec, tape, dscores, grads, want_image_grad=False):
     if not fuse_ctx:
         # K = 2 * layers * d = 1800 over only B * nctx x d outputs: split the reduction (40 -> ~15 us with the fill)
         ksplit = max(1, min(8, (nseg * d) // 450)) if B * nctx * d <= 1280 * 512 else 1
+        if ops.is_deterministic():
+            ksplit = 1
         dctx = (torch.zeros if ksplit > 1 else torch.empty)(B, nctx, d, device=dev, dtype=torch.float32)
         ops.gemm_raw(dkv_ctx, m["wkv"], dctx, B * nctx, d, nseg * d, nseg * d, 1, 1, d, d, a_grp=nctx,
                      a_gs=S * nseg * d, atomic=ksplit > 1, split_k=ksplit)
@@ -798,7 +800,8 @@ class DecoderGraphFn(torch.autograd.Function):
         dec, params = ctx.dec, ctx.params
         grads = {id(p): torch.zeros_like(p) for p in params if p.requires_grad}
         want_img = ctx.needs_input_grad[5]      # fine_tune_encoder=True: the loss reaches Encoder.conv1 through enc_tok
-        d_img = backward_from_tape(dec, ctx.tape, dscores.contiguous(), grads, want_image_grad=want_img)
+        d_img = backward_from_tape(dec, ctx.tape, dscores.contiguous(), grads, overlap=not ops.is_deterministic(),
+                                   want_image_grad=want_img)
         d_enc = None
         if want_img:                            # the forward gathered the samples into length order through gmap
             d_enc = torch.empty(ctx.enc_shape, device=d_img.device, dtype=torch.float32)
@@ -835,8 +838,15 @@ class TrainStep:
     replays advance without re-capturing."""
 
     def __init__(self, decoder, lr=4e-4, grad_clip=5.0, betas=(0.9, 0.999), eps=1e-8, process_group=None, seed=0,
-                 use_graph=True, encoder=None):
+                 use_graph=True, encoder=None, deterministic=None):
         self.dec = decoder
+        # deterministic (default: ICK_DETERMINISTIC=1 in the environment): the library's fixed-order reductions, no
+        # split GEMMs, everything on one stream -- two runs of the same steps end bit-identical (cost: DESIGN.md)
+        if deterministic is None:
+            deterministic = os.environ.get("ICK_DETERMINISTIC", "0") not in ("", "0")
+        self.deterministic = bool(deterministic)
+        if self.deterministic or ops.is_deterministic():
+            ops.set_deterministic(self.deterministic)
         # with an encoder the step also accepts the (B, 2048, 14, 14) feature map: Encoder.conv1 (frozen, as in the
         # reference's default fine_tune_encoder=False) then runs inside graph A straight into the memory buffer
         self.enc = encoder
@@ -878,13 +888,24 @@ class TrainStep:
         # several ranks: every replica starts from rank 0's weights (a freshly built decoder is randomly initialised
         # per process; the reference has a single process, geo-aware/train.py:16-18).  One broadcast of the bucket.
         dp.broadcast_bucket(self.flat_p, self.pg)
-        # ICK_SPLIT_ALLREDUCE=1: the step as two graphs around two all-reduces (the early half of the bucket travels
-        # while the late half is computed).  Measured on one GPU the split itself costs ~130 us (a join in the middle
-        # of the backward pass, one more graph launch) and hides ~half of the collective, so it pays off only when
-        # the 46 MB all-reduce takes more than ~0.3 ms; off until that is measured on a multi-GPU node.
-        self.split = os.environ.get("ICK_SPLIT_ALLREDUCE", "0") != "0"
+        # Several ranks: the step runs as two graphs around two all-reduces -- the early half of the bucket (score head,
+        # decoder stack: gradients complete first) travels while the late half (cross K/V projection, context encoders,
+        # embeddings) is computed, and only the late half's all-reduce is exposed.  Measured on one GPU the split itself
+        # costs ~130 us (a join in the middle of the backward pass, one more graph launch); the 45.7 MB all-reduce of cfg2
+        # is 0.3-0.5 ms on xGMI by SURVEY.md 5's link arithmetic, so with ranks > 1 the split is the default.  Same bits
+        # as the single all-reduce (tests/test_deterministic_gpu.py).  ICK_SPLIT_ALLREDUCE=0 / 1 overrides.
+        env = os.environ.get("ICK_SPLIT_ALLREDUCE")
+        self.split = (env != "0") if env not in (None, "") else dp.world_size(self.pg) > 1
 
     # ---- device-only halves -------------------------------------------------------------------
+    def _overlap(self, off_switch):
+        """Second-stream work (context chains beside the image projection, weight gradients beside the data-gradient
+        chain): in captured steps, unless switched off -- and never in deterministic mode, where every buffer must
+        receive its terms in one fixed order."""
+        if self.deterministic:
+            return False
+        return bool((self.use_graph or os.environ.get("ICK_GROUP_SAME_STREAM")) and not os.environ.get(off_switch))
+
     def _enc_kwargs(self, enc_in):
         if enc_in.dim() == 4:
             c1 = self.enc.conv1
@@ -902,7 +923,7 @@ class TrainStep:
 
         scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, gmap=gmap,
                                          seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
-                                         overlap=(self.use_graph or bool(os.environ.get("ICK_GROUP_SAME_STREAM"))) and not os.environ.get("ICK_NO_FWD_OVERLAP"),
+                                         overlap=self._overlap("ICK_NO_FWD_OVERLAP"),
                                          side_tail=tail, **self._enc_kwargs(enc_in))
         decode_len = box["decode_len"]
         ops.stamp("fwd: scores done")
@@ -912,7 +933,7 @@ class TrainStep:
                                       out_sum=self.flat_g[self.n:self.n + 1], out_count=self.flat_g[self.n + 1:])
         ops.stamp("CE done")
         backward_from_tape(dec, tape, dscores, self.grads,
-                           overlap=(self.use_graph or bool(os.environ.get("ICK_GROUP_SAME_STREAM"))) and not os.environ.get("ICK_NO_BWD_OVERLAP"))
+                           overlap=self._overlap("ICK_NO_BWD_OVERLAP"))
         ops.stamp("A: end (after join)")
         return self.flat_g
 
@@ -927,13 +948,13 @@ class TrainStep:
 
         scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, gmap=gmap,
                                          seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
-                                         overlap=(self.use_graph or bool(os.environ.get("ICK_GROUP_SAME_STREAM"))) and not os.environ.get("ICK_NO_FWD_OVERLAP"),
+                                         overlap=self._overlap("ICK_NO_FWD_OVERLAP"),
                                          side_tail=tail, **self._enc_kwargs(enc_in))
         decode_len = box["decode_len"]
         self._loss = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True,
                                    out_sum=self.flat_g[self.n:self.n + 1], out_count=self.flat_g[self.n + 1:])
         self._bp = BackwardPass(dec, tape, self._loss[2], self.grads,
-                                overlap=(self.use_graph or bool(os.environ.get("ICK_GROUP_SAME_STREAM"))) and not os.environ.get("ICK_NO_BWD_OVERLAP"))
+                                overlap=self._overlap("ICK_NO_BWD_OVERLAP"))
         self._bp.early(join=True)
         return self.flat_g
 

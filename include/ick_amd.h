@@ -32,6 +32,12 @@ extern "C" {
 
 /* Library / device probe (no reference counterpart). */
 int ick_version(void);
+/* Deterministic mode: gradient reductions that otherwise use float atomics (scatter-adds of the embedding / entity /
+ * fact / predicate-gate backward, bias and LayerNorm column sums) run in a fixed order -- slower, bit-reproducible.
+ * Default: the environment variable ICK_DETERMINISTIC (1 = on).  Callers must also keep every GEMM unsplit
+ * (split_k = 1) and the step on one stream; training.TrainStep(deterministic=True) does. */
+int ick_set_deterministic(int on);
+int ick_get_deterministic(void);
 int ick_device_info(int* num_cu, int* wave_size, char* arch_name, int arch_name_len);
 
 /* ------------------------------------------------------------------------------------------

@@ -14,13 +14,10 @@ if __name__ == "__main__":
     rank = int(os.environ["RANK"])
     torch.manual_seed(1234 + rank)      # different random initial weights per rank: the broadcast must fix that
     seen = []
-    orig = tr._batch_to_device
-
-    def spy(batch, device, has_facts):
+    def spy(batch):
         seen.append(batch[1].clone())   # the captions identify the samples
-        return orig(batch, device, has_facts)
 
-    tr._batch_to_device = spy
+    tr._batch_hook = spy                # the TRAIN batches the prefetcher hands to the fused step
     steps = []
 
     class Recording(tr.TrainStep):
