@@ -20,11 +20,6 @@ def _default_collate(samples):
     return default_collate(samples)
 
 
-def collated(batch):
-    """collate_fn for loaders over CaptionDataset: __getitems__ has already built the batch."""
-    return batch if isinstance(batch, tuple) else _default_collate(batch)
-
-
 class CaptionDataset(Dataset):
     def __init__(self, data_dir, data_name, split, transform=None, keep_half=False):
         """keep_half: hand float16 feature maps on as float16 (half the bytes through the loader's queues and over
@@ -73,19 +68,17 @@ class CaptionDataset(Dataset):
     def __len__(self):
         return len(self.captions)
 
-    def __getitems__(self, idx):
-        """A whole batch at once (torch's DataLoader calls this with the batch's indices when it exists): one gather out
-        of the memory-mapped feature file and one tensor per field, instead of 64 per-sample tensors that the default
-        collate then stacks (tools/train_rate.py measures the loop with it).
-        Returns the collated batch; pair it with collate_fn=collated (below)."""
+    def fetch_batch(self, idx):
+        """A whole batch at once: the feature maps copied straight out of the memory-mapped file into one block and
+        one tensor per field, instead of 64 per-sample tensors that the default collate then stacks (16 vs 50 ms for
+        64 float16 maps).  Same fields, shapes and dtypes as collating the per-sample tuples.  ds[[i, j, ...]] calls it,
+        so a DataLoader(ds, sampler=BatchSampler(...), batch_size=None) yields these batches."""
         if not self.precomputed or self.transform is not None:
             return _default_collate([self[i] for i in idx])
-        order = np.argsort(np.asarray(idx))                       # ascending file offsets, restored to the batch's order
-        srt = np.asarray(idx)[order]
-        block = np.empty((len(idx),) + self.imgs.shape[1:], dtype=self.imgs.dtype)
-        block[order] = self.imgs[srt]
-        if not (self.keep_half and block.dtype == np.float16):
-            block = block.astype(np.float32, copy=False)
+        out_dtype = np.float16 if (self.keep_half and self.imgs.dtype == np.float16) else np.float32
+        block = np.empty((len(idx),) + self.imgs.shape[1:], dtype=out_dtype)
+        for k, i in enumerate(idx):                               # one copy per sample, straight out of the map
+            block[k] = self.imgs[i]
         item = (torch.from_numpy(block), torch.tensor([self.captions[i] for i in idx], dtype=torch.long),
                 torch.tensor([[self.caplens[i]] for i in idx], dtype=torch.long),
                 torch.tensor([self.capmasks[i] for i in idx], dtype=torch.long),
@@ -97,6 +90,8 @@ class CaptionDataset(Dataset):
         return item
 
     def __getitem__(self, i):
+        if isinstance(i, (list, tuple)):
+            return self.fetch_batch(list(i))
         if self.precomputed:
             if self.keep_half and self.imgs.dtype == np.float16:
                 img = torch.from_numpy(np.array(self.imgs[i]))            # float16 as stored (a copy out of the map)
