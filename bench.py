@@ -38,7 +38,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_TABLE = os.path.join(ROOT, "profiles", "r02_traffic.json")   # PMC bytes per launch, see its "_source"
+TRAFFIC_TABLE = os.path.join(ROOT, "profiles", "r03_traffic.json")   # PMC bytes per launch, see its "_source"
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_GBS = 8000.0
 BEAM = 5

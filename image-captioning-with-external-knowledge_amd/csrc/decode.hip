@@ -187,8 +187,7 @@ struct RowGather {
         const bool wide = d4 > 64;
         const int nrows = s.nparts > 0 ? s.nparts + 2 : 1;
         f32x2 z0l = {0.f, 0.f}, z0h = {0.f, 0.f}, z1l = {0.f, 0.f}, z1h = {0.f, 0.f};
-        for (int q0 = wr * NS; q0 < nrows; q0 += WPR * NS) {               // one sweep unless the source has > 12 rows
-            if (q0 >= WPR * NS) sweep(s, min(r0 + g, (int64_t)R - 1), d, q0, nrows);
+        auto add_sweep = [&](int q0) {
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
                 const float f = q0 + j < nrows ? 1.f : 0.f;                 // scalar
@@ -200,6 +199,14 @@ struct RowGather {
                     z1h = __builtin_elementwise_fma(f32x2{b[j].z, b[j].w}, ff, z1h);
                 }
             }
+        };
+        // The sweep issue() requested is summed in straight-line code: its s_waitcnt then counts only the row loads, not
+        // the weight / K / V streams requested after them (inside a loop the compiler waits for vmcnt(0), i.e. for the
+        // whole stream).  Sources of more than 12 rows take the loop below.
+        if (wr * NS < nrows) add_sweep(wr * NS);
+        for (int q0 = (wr + WPR) * NS; q0 < nrows; q0 += WPR * NS) {
+            sweep(s, min(r0 + g, (int64_t)R - 1), d, q0, nrows);
+            add_sweep(q0);
         }
         float4* dst = psum + (g * WPR + wr) * kD4Max;
         dst[lane] = make_float4(z0l.x, z0l.y, z0h.x, z0h.y);
@@ -453,8 +460,172 @@ struct LayerW {
     float* part;                   // (R, H, d) partial out-projection rows written here
 };
 
+// ---------------------------------------------------------------------------------------------------------
+// Greedy selection folded into the first self-attention block of the NEXT step (ick_decode_ctx.sel_state != NULL):
+// the workgroups of a row group pick the row's token of step `step` = pos - 1 from the vocabulary kernel's per-tile
+// candidates and the pointer scores, apply predict()'s bookkeeping (geo-aware/models.py:410-441: <end>, repeated n-gram
+// clean-up, pointer masks) and embed the token -- one launch per token less (the selection kernel alone was 6.5 us of a
+// ~85 us step).  Every head's workgroup repeats the decision from the SAME inputs: candidates and pointer scores of the
+// previous kernels, and a 12-int window {output[step-1 .. step-5], runner-ups of steps step-1 .. step-3, ended flag} kept
+// in two alternating buffers, so that the one workgroup that records the decision (head 0: output / history / flags /
+// counter / caption buffer / next window) never writes what the others read.
+// ---------------------------------------------------------------------------------------------------------
+struct SelFuse {
+    const float4* cand; int ntiles; const float* ptr;
+    int64_t* output; int32_t* hist; int32_t* finished; int32_t* n_done; int64_t* next_token; int64_t* next_mask;
+    int64_t* cap_buf;
+    const int32_t* st_in; int32_t* st_out;           // (R, 12)
+    const float *word_emb, *ee, *fe, *pe;
+    int rows_per_sample, V, K, F, step, max_len, has_facts, end_token, pad_token;
+    float emb_scale;
+};
+
+__device__ __forceinline__ uint64_t top_key(float v, int idx) {      // larger value first, then smaller index
+    uint32_t u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((uint64_t)u << 32) | (uint32_t)(0x7fffffff - idx);
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t k) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)k, off, 64), hi = __shfl_xor((uint32_t)(k >> 32), off, 64);
+        const uint64_t o = ((uint64_t)hi << 32) | lo;
+        k = o > k ? o : k;
+    }
+    return k;
+}
+
+// xs: LDS [G][kDMax] receives the embedded rows; keys: LDS uint64 [G][kNW][2]; follow with a barrier
+template <int G>
+__device__ __forceinline__ void fused_select(const SelFuse& f, int64_t r0, int R, int d, int pos, float* xs, uint64_t* keys,
+                                             float* xa_out, bool recorder) {
+    constexpr int WPR = kNW / G;                                   // waves per row
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int g = min(wave / WPR, G - 1), wr = wave - g * WPR;
+    const bool mine = wave < G * WPR;
+    const int64_t row = min(r0 + g, (int64_t)R - 1);
+    const int np = f.K + f.F, i = f.step;
+    // this wave's share of the row's candidates: vocabulary tiles, then pointer scores
+    float v1 = -INFINITY, v2 = -INFINITY;
+    int i1 = 0x7fffffff, i2 = 0x7fffffff;
+    for (int t = wr * 64 + lane; mine && t < f.ntiles + np; t += 64 * WPR) {
+        float a1, a2; int j1, j2;
+        if (t < f.ntiles) {
+            const float4 c = f.cand[row * f.ntiles + t];
+            a1 = c.x; j1 = __float_as_int(c.y); a2 = c.z; j2 = __float_as_int(c.w);
+        } else {
+            a1 = f.ptr[row * np + (t - f.ntiles)]; j1 = f.V + (t - f.ntiles); a2 = -INFINITY; j2 = 0x7fffffff;
+        }
+        // merge (a1, j1) >= (a2, j2) into the lane's running pair
+        const bool b1 = top_key(a1, j1) > top_key(v1, i1);
+        const float n2v = b1 ? v1 : a1; const int n2i = b1 ? i1 : j1;       // the loser of the two firsts
+        v1 = b1 ? a1 : v1; i1 = b1 ? j1 : i1;
+        float s2v = b1 ? a2 : v2; int s2i = b1 ? j2 : i2;                    // the winner's own second
+        const bool b2 = top_key(n2v, n2i) > top_key(s2v, s2i);
+        v2 = b2 ? n2v : s2v; i2 = b2 ? n2i : s2i;
+    }
+    const uint64_t kb = wave_max_u64(top_key(v1, i1));
+    const int best_i = 0x7fffffff - (int)(uint32_t)kb;
+    const uint64_t ks = wave_max_u64(i1 == best_i ? top_key(v2, i2) : top_key(v1, i1));
+    if (mine && lane == 0) { keys[(g * kNW + wr) * 2] = kb; keys[(g * kNW + wr) * 2 + 1] = ks; }
+    __syncthreads();
+    if (!mine || wr != 0) return;
+    // the row's first wave: merge the waves' pairs, decide, embed
+    uint64_t B = keys[(g * kNW) * 2], S2 = keys[(g * kNW) * 2 + 1];
+#pragma unroll
+    for (int w = 1; w < WPR; ++w) {
+        const uint64_t b = keys[(g * kNW + w) * 2], s2 = keys[(g * kNW + w) * 2 + 1];
+        if (b > B) { S2 = B > s2 ? B : s2; B = b; } else { S2 = b > S2 ? b : S2; }
+    }
+    const int best = 0x7fffffff - (int)(uint32_t)B;
+    int second = 0x7fffffff - (int)(uint32_t)S2;
+    if (second == 0x7fffffff) second = best;                                    // no runner-up at all
+    const int32_t* st = f.st_in + row * 12;
+    int po[5], ph[3];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) po[q] = st[q];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) ph[q] = st[5 + q];
+    const int fin = st[8];
+    int tok = 0, msk = 0, cur = 0, nfin = fin;
+    int rw1 = po[0], rw2 = po[1], rw3 = po[2];      // output[i-1 .. i-3] after the clean-up
+    int nrw = 0;
+    if (!fin) {
+        if (best == f.end_token) {
+            cur = best; nfin = 1;
+        } else {
+            cur = best;
+            // repeated n-gram clean-up (geo-aware/models.py:421-435)
+            if (i > 0 && cur == po[0]) {
+                cur = second;
+            } else if (i > 2 && cur == po[1] && po[0] == po[2]) {
+                cur = second; rw1 = ph[0]; nrw = 1;
+            } else if (i > 4 && cur == po[2] && po[0] == po[3] && po[1] == po[4]) {
+                cur = second; rw1 = ph[0]; rw2 = ph[1]; rw3 = ph[2]; nrw = 3;
+            }
+            tok = cur;
+            msk = (f.has_facts && cur >= f.V + f.K) ? 2 : (cur >= f.V ? 1 : 0);
+        }
+    }
+    if (recorder && r0 + g < R && lane == 0) {
+        int64_t* o = f.output + row * f.max_len;
+        if (!fin) {
+            o[i] = cur;
+            if (nfin) { f.finished[row] = 1; atomicAdd(f.n_done, 1); }
+            else {
+                f.hist[row * f.max_len + i] = second;
+                if (nrw >= 1) o[i - 1] = rw1;
+                if (nrw >= 3) { o[i - 2] = rw2; o[i - 3] = rw3; }
+            }
+        }
+        f.next_token[row] = tok;
+        f.next_mask[row] = msk;
+        if (f.cap_buf != nullptr && i + 1 < f.max_len) f.cap_buf[row * f.max_len + i + 1] = tok;
+        int32_t* so = f.st_out + row * 12;
+        so[0] = fin ? po[0] : cur; so[1] = rw1; so[2] = rw2; so[3] = rw3; so[4] = po[3];
+        so[5] = (fin || nfin) ? ph[0] : second; so[6] = ph[0]; so[7] = ph[1];
+        so[8] = nfin;
+    }
+    // CaptionEmbedder + sqrt(d) scale + PositionEncoder of the token (geo-aware/models.py:155-181,355-357)
+    const int64_t b = row / f.rows_per_sample;
+    const float* src;
+    if (msk == 1) {
+        int e = tok - f.V;
+        if (e < 0 || e >= f.K) e = f.K - 1;
+        src = f.ee + (b * f.K + e) * d;
+    } else if (msk == 2 && f.fe != nullptr) {
+        int e = tok - f.V - f.K;
+        if (e < 0 || e >= f.F) e = f.F - 1;
+        src = f.fe + (b * f.F + e) * d;
+    } else {
+        src = f.word_emb + (int64_t)(tok >= 0 && tok < f.V ? tok : f.pad_token) * d;
+    }
+    const float* pe = f.pe + (int64_t)pos * d;
+    const int d4 = d >> 2;
+    const bool ok0 = lane < d4, ok1 = 64 + lane < d4;
+    float4 z0 = f4zero(), z1 = f4zero();
+    if (ok0) {
+        const float4 e4 = ld4(src + 4 * lane), p4 = ld4(pe + 4 * lane);
+        z0 = make_float4(fmaf(e4.x, f.emb_scale, p4.x), fmaf(e4.y, f.emb_scale, p4.y), fmaf(e4.z, f.emb_scale, p4.z),
+                         fmaf(e4.w, f.emb_scale, p4.w));
+    }
+    if (ok1) {
+        const float4 e4 = ld4(src + 4 * (64 + lane)), p4 = ld4(pe + 4 * (64 + lane));
+        z1 = make_float4(fmaf(e4.x, f.emb_scale, p4.x), fmaf(e4.y, f.emb_scale, p4.y), fmaf(e4.z, f.emb_scale, p4.z),
+                         fmaf(e4.w, f.emb_scale, p4.w));
+    }
+    float* x = xs + g * kDMax;
+    reinterpret_cast<float4*>(x)[lane] = z0;
+    if (lane < kD4Max - 64) reinterpret_cast<float4*>(x)[64 + lane] = z1;
+    if (recorder && r0 + g < R && xa_out != nullptr) {
+        if (ok0) reinterpret_cast<float4*>(xa_out + row * d)[lane] = z0;
+        if (ok1) reinterpret_cast<float4*>(xa_out + row * d)[64 + lane] = z1;
+    }
+}
+
 struct SelfArgs {
     LayerW w;
+    SelFuse sel;                   // used by the FSEL instantiation (first layer, pos >= 1) only
     float* kc; float* vc;          // (R, H, ML, 32) key / value cache of this layer
     const int32_t* anc;            // optional (R, ML): cache row that holds position p of row r (beam search)
     int R, d, H, dh, ML, pos;
@@ -467,10 +638,11 @@ struct SelfArgs {
 // streamed once for the G rows.  Wave w normalises row w and, later, attends for it.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kOPad = 48;          // attention output row in LDS: head width + the zero tail the out-projection reads
-template <int G>
+template <int G, bool FSEL>
 __global__ __launch_bounds__(kNT) void dec_self_kernel(SelfArgs a) {
     static_assert(G <= kNW, "one wave per row");
     __shared__ __attribute__((aligned(16))) float xs[G][kDMax];
+    __shared__ uint64_t selkeys[FSEL ? G * kNW * 2 : 2];
     __shared__ __attribute__((aligned(16))) float qkv[G][128];     // q | k | v of this head (3 x dh <= 96), zero tail
     __shared__ __attribute__((aligned(16))) float o[G][kOPad];
     __shared__ __attribute__((aligned(16))) float4 part[G * kNT];
@@ -484,17 +656,22 @@ __global__ __launch_bounds__(kNT) void dec_self_kernel(SelfArgs a) {
     const bool have_row = wave < G && r0 + wave < R;                // wave-uniform
     ICK_STAMP(0, 0);
     RowGather<G, kNW> in;
-    in.issue(a.w.src, r0, R, d);
+    if constexpr (!FSEL) in.issue(a.w.src, r0, R, d);
     RowDot<3> qd;
     qd.load(a.w.in_w, a.w.in_b, d,
             [&](int rr) { const int seg = (rr >= dh) + (rr >= 2 * dh); return seg * (d - dh) + h * dh + rr; }, 3 * dh, d4);
     if (done >= a.n_total) return;                                   // every caption has ended (uniform)
     ICK_STAMP(0, 1);
-    in.slice_sums(a.w.src, r0, R, d, part);
     for (int idx = tid; idx < G * 32; idx += kNT) qkv[idx >> 5][96 + (idx & 31)] = 0.f;
     for (int idx = tid; idx < G * kOPad; idx += kNT) (&o[0][0])[idx] = 0.f;
-    __syncthreads();
-    in.finish(a.w.src, r0, R, d, part, &xs[0][0], h == 0);
+    if constexpr (FSEL) {
+        // the token of the previous step is chosen and embedded here: the row source is that embedding
+        fused_select<G>(a.sel, r0, R, d, pos, &xs[0][0], selkeys, a.w.src.out, h == 0);
+    } else {
+        in.slice_sums(a.w.src, r0, R, d, part);
+        __syncthreads();
+        in.finish(a.w.src, r0, R, d, part, &xs[0][0], h == 0);
+    }
     __syncthreads();
     ICK_STAMP(0, 2);
     // the cached keys / values of this wave's row and the out-projection slice are requested before the products run
@@ -1353,12 +1530,21 @@ static GroupPlan plan_groups(const ick_decode_ctx* c) {
     }
     return p;
 }
-static void launch_self(int g, dim3 grid, hipStream_t s, const SelfArgs& a) {
+static void launch_self(int g, bool fsel, dim3 grid, hipStream_t s, const SelfArgs& a) {
+    if (fsel) {
+        switch (g) {
+        case 1: hipLaunchKernelGGL((dec_self_kernel<1, true>), grid, dim3(kNT), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((dec_self_kernel<2, true>), grid, dim3(kNT), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((dec_self_kernel<4, true>), grid, dim3(kNT), 0, s, a); break;
+        default: hipLaunchKernelGGL((dec_self_kernel<8, true>), grid, dim3(kNT), 0, s, a); break;
+        }
+        return;
+    }
     switch (g) {
-    case 1: hipLaunchKernelGGL(dec_self_kernel<1>, grid, dim3(kNT), 0, s, a); break;
-    case 2: hipLaunchKernelGGL(dec_self_kernel<2>, grid, dim3(kNT), 0, s, a); break;
-    case 4: hipLaunchKernelGGL(dec_self_kernel<4>, grid, dim3(kNT), 0, s, a); break;
-    default: hipLaunchKernelGGL(dec_self_kernel<8>, grid, dim3(kNT), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((dec_self_kernel<1, false>), grid, dim3(kNT), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((dec_self_kernel<2, false>), grid, dim3(kNT), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((dec_self_kernel<4, false>), grid, dim3(kNT), 0, s, a); break;
+    default: hipLaunchKernelGGL((dec_self_kernel<8, false>), grid, dim3(kNT), 0, s, a); break;
     }
 }
 static void launch_ffn(int g, dim3 grid, hipStream_t s, const FfnArgs& a) {
@@ -1400,7 +1586,7 @@ extern "C" int ick_decode_beam_supported(int32_t Vx, int32_t beam) {
 }
 
 // which: bit 0 self, 1 cross, 2 ffn, 3 head, 4 vocabulary (all set in the product path; the diagnostic build times subsets)
-static int decode_layers_impl(const ick_decode_ctx* c, int32_t pos, void* stream, unsigned which) {
+static int decode_layers_impl(const ick_decode_ctx* c, int32_t pos, void* stream, unsigned which, int part = 0) {
     ICK_CHECK_ARG(c && c->R > 0 && c->layers > 0 && c->layers <= ICK_MAX_LAYERS && pos >= 0 && pos < c->max_len);
     ICK_CHECK_ARG(ick_decode_supported(c->d, c->H, c->FF, c->S, c->max_len));
     ICK_CHECK_ARG(c->rows_per_sample > 0 && c->R % c->rows_per_sample == 0 && c->R <= 65535);
@@ -1422,7 +1608,25 @@ static int decode_layers_impl(const ick_decode_ctx* c, int32_t pos, void* stream
         sa.kc = w.self_k; sa.vc = w.self_v; sa.anc = c->anc;
         sa.R = R; sa.d = d; sa.H = H; sa.dh = dh; sa.ML = c->max_len; sa.pos = pos; sa.scale = scale;
         sa.n_done = c->n_done; sa.n_total = R;
-        if (which & 1u) launch_self(plan.g_self, dim3(H, ceil_div(R, plan.g_self)), s, sa);
+        const bool fsel = l == 0 && pos >= 1 && c->sel_state != nullptr;
+        if (fsel) {
+            // the token of step pos - 1 is chosen inside this launch (fused_select)
+            ICK_CHECK_ARG(c->rows_per_sample == 1 && c->output && c->hist && c->finished && c->n_done && c->next_token &&
+                          c->next_mask && c->word_emb && c->pe && c->cand && c->ptr && c->ee);
+            SelFuse& f = sa.sel;
+            f.cand = reinterpret_cast<const float4*>(c->cand); f.ntiles = ceil_div(c->V, kVocabTile); f.ptr = c->ptr;
+            f.output = c->output; f.hist = c->hist; f.finished = c->finished; f.n_done = c->n_done;
+            f.next_token = c->next_token; f.next_mask = c->next_mask; f.cap_buf = c->cap_buf;
+            const int i = pos - 1;
+            f.st_in = c->sel_state + (size_t)(i & 1) * R * 12; f.st_out = c->sel_state + (size_t)((i + 1) & 1) * R * 12;
+            f.word_emb = c->word_emb; f.ee = c->ee; f.fe = c->F > 0 ? c->fe : nullptr; f.pe = c->pe;
+            f.rows_per_sample = c->rows_per_sample; f.V = c->V; f.K = c->K; f.F = c->F; f.step = i; f.max_len = c->max_len;
+            f.has_facts = c->F > 0; f.end_token = c->end_token; f.pad_token = c->pad_token; f.emb_scale = c->emb_scale;
+        }
+        const bool first_self = l == 0;
+        if ((which & 1u) && !(part == 2 && first_self))
+            launch_self(plan.g_self, fsel, dim3(H, ceil_div(R, plan.g_self)), s, sa);
+        if (part == 1) { ICK_LAUNCH_RET(); }
         CrossArgs ca;
         ca.w.in_w = w.ca_in_w; ca.w.in_b = w.ca_in_b; ca.w.out_wt = w.ca_out_wt;
         ca.w.src = make_src(c, c->xa, c->p1, H, w.sa_out_b, w.n1_g, w.n1_b, c->xb);
@@ -1457,6 +1661,40 @@ static int decode_layers_impl(const ick_decode_ctx* c, int32_t pos, void* stream
 
 extern "C" int ick_decode_layers(const ick_decode_ctx* c, int32_t pos, void* stream) {
     return decode_layers_impl(c, pos, stream, 31u);
+}
+
+extern "C" int ick_decode_layers_part(const ick_decode_ctx* c, int32_t pos, int32_t part, void* stream) {
+    ICK_CHECK_ARG(part >= 0 && part <= 2);
+    return decode_layers_impl(c, pos, stream, 31u, part);
+}
+
+// every per-call buffer of a greedy decode in one launch (they were eight fills, an embedding and a copy)
+namespace ick { namespace {
+__global__ __launch_bounds__(256) void dec_init_kernel(ick_decode_ctx c, int start_token, int n_done_init) {
+    const int64_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int p = tid; p < c.max_len; p += 256) {
+        c.output[r * c.max_len + p] = c.pad_token;
+        c.hist[r * c.max_len + p] = 0;
+        if (c.cap_buf) c.cap_buf[r * c.max_len + p] = start_token;
+    }
+    if (tid == 0) {
+        c.finished[r] = 0; c.next_token[r] = 0; c.next_mask[r] = 0;
+        if (r == 0) *c.n_done = n_done_init;
+    }
+    if (c.sel_state && tid < 24) c.sel_state[(tid / 12) * (int64_t)c.R * 12 + r * 12 + tid % 12] = 0;
+    // embedding of <start> at position 0 (CaptionEmbedder + sqrt(d) + PositionEncoder)
+    const float* src = c.word_emb + (int64_t)start_token * c.d;
+    for (int col = tid; col < c.d; col += 256) c.x0[r * c.d + col] = fmaf(src[col], c.emb_scale, c.pe[col]);
+}
+} }
+
+extern "C" int ick_decode_init(const ick_decode_ctx* c, int32_t start_token, int32_t n_done_init, void* stream) {
+    ICK_CHECK_ARG(c && c->R > 0 && c->max_len > 0 && c->d > 0 && c->output && c->hist && c->finished && c->n_done &&
+                  c->next_token && c->next_mask && c->word_emb && c->pe && c->x0);
+    ICK_CHECK_ARG(start_token >= 0 && start_token < c->V);
+    hipLaunchKernelGGL(dec_init_kernel, dim3(c->R), dim3(256), 0, (hipStream_t)stream, *c, start_token, n_done_init);
+    ICK_LAUNCH_RET();
 }
 
 #ifdef ICK_DECODE_STAMPS

@@ -231,6 +231,7 @@ class DecoderTransformer(nn.Module):
     variant = "geo"
     use_hip_graphs = True   # inference forward / predict replay a captured hipGraph per input shape
     fused_decode = True     # predict(): fused per-block decode kernels (csrc/decode.hip) when the sizes allow
+    fuse_select = True      # ... with the greedy selection folded into the next step's first launch
 
     def __init__(self, word_map, emb_dim, decoder_dim, encoder_dim, num_heads, num_layers, dropout_dec=0.5,
                  dropout_enc=0.5, dropout_pos=0.1):
@@ -789,7 +790,8 @@ class DecoderTransformer(nn.Module):
             self.__dict__["_dec_pack"] = cache
         return cache[1]
 
-    def _decode_ctx(self, kv, ee, fe, rows_per_sample, max_len, S, anc=None, want_scores=False):
+    def _decode_ctx(self, kv, ee, fe, rows_per_sample, max_len, S, anc=None, want_scores=False, fuse_select=False,
+                    n_done_init=0):
         """lib.DecodeCtx over freshly allocated state buffers for R = B * rows_per_sample rows (+ the tensors, kept
         alive by the caller).  See include/ick_amd.h (ick_decode_ctx)."""
         from . import lib as L
@@ -804,24 +806,27 @@ class DecoderTransformer(nn.Module):
         nch = (FF + 63) // 64
         ntiles = (V + 15) // 16
         f32 = dict(device=dev, dtype=torch.float32)
+        # state buffers are initialised by ops.decode_init (one launch; they were eight fills, an embedding and a copy)
         t = {"x0": torch.empty(R, d, **f32), "xa": torch.empty(R, d, **f32), "xb": torch.empty(R, d, **f32),
              "xc": torch.empty(R, d, **f32), "p1": torch.empty(R, H, d, **f32), "p2": torch.empty(R, H, d, **f32),
              "p3": torch.empty(R, nch, d, **f32), "hfin": torch.empty(R, d, **f32), "hv": torch.empty(R, d, **f32),
              "ptr": torch.empty(R, K + Fn, **f32), "cand": torch.empty(R, ntiles, 4, **f32),
              "self_kv": torch.empty(nl, 2, R, H, max_len, ops.DHP, **f32),
-             "output": torch.full((R, max_len), self.word_map["<pad>"], dtype=torch.long, device=dev),
-             "hist": torch.zeros(R, max_len, dtype=torch.int32, device=dev),
-             "finished": torch.zeros(R, dtype=torch.int32, device=dev),
-             "n_done": torch.zeros(1, dtype=torch.int32, device=dev),
-             "next_token": torch.zeros(R, dtype=torch.long, device=dev),
-             "next_mask": torch.zeros(R, dtype=torch.long, device=dev),
+             "output": torch.empty((R, max_len), dtype=torch.long, device=dev),
+             "hist": torch.empty(R, max_len, dtype=torch.int32, device=dev),
+             "finished": torch.empty(R, dtype=torch.int32, device=dev),
+             "n_done": torch.empty(1, dtype=torch.int32, device=dev),
+             "next_token": torch.empty(R, dtype=torch.long, device=dev),
+             "next_mask": torch.empty(R, dtype=torch.long, device=dev),
              "pack": self._decode_pack(), "kv": kv, "ee": ee, "fe": fe, "anc": anc}
+        if fuse_select:
+            t["sel_state"] = torch.empty(2, R, 12, dtype=torch.int32, device=dev)
         if want_scores:
             t["scores"] = torch.empty(R, V, **f32)
         if self.has_facts:
             t["gate"] = torch.empty(R, 1, d, **f32)
             t["eib"] = torch.empty(R, 1, Fn, **f32)
-            t["cap_buf"] = torch.full((R, max_len), self.word_map["<start>"], dtype=torch.long, device=dev)
+            t["cap_buf"] = torch.empty((R, max_len), dtype=torch.long, device=dev)
         c = L.DecodeCtx()
         c.R, c.rows_per_sample, c.d, c.H, c.FF, c.layers, c.S, c.max_len = R, rows_per_sample, d, H, FF, nl, S, max_len
         c.V, c.K, c.F = V, K, Fn
@@ -856,6 +861,9 @@ class DecoderTransformer(nn.Module):
             setattr(c, name, t[name].data_ptr())
         if want_scores:
             c.scores, c.scores_ld = t["scores"].data_ptr(), V
+        if fuse_select:
+            c.sel_state = t["sel_state"].data_ptr()
+        ops.decode_init(c, self.word_map["<start>"], n_done_init)
         return c, t
 
     def _predict_fused(self, enc_tok, entities, facts, max_pred_len):
@@ -865,20 +873,27 @@ class DecoderTransformer(nn.Module):
         ee, fe, kv, _, side = self._encode_context(enc_tok, entities, facts, None)
         side.join()
         S = kv.shape[3]
-        c, t = self._decode_ctx(kv, ee, fe, 1, max_pred_len, S)
-        dev = enc_tok.device
-        tok = torch.full((B, 1), self.word_map["<start>"], dtype=torch.long, device=dev)
-        msk = torch.zeros(B, 1, dtype=torch.long, device=dev)
-        pe = self.pos_encoder.pe.view(-1, d)
-        x0 = ops.caption_embed(tok, msk, self.word_embedding.weight.detach(), ee, fe, pe, V, self.word_map["<pad>"],
-                               math.sqrt(d), pos0=0)
-        t["x0"].copy_(x0.view(B, d))
+        # the token of step i - 1 is chosen inside the first launch of step i (csrc/decode.hip: fused_select); only the
+        # last step needs the selection kernel of its own: 11 launches per token (12 with facts)
+        fuse = self.fuse_select
+        c, t = self._decode_ctx(kv, ee, fe, 1, max_pred_len, S, fuse_select=fuse)
+
+        def indicators():
+            ops.context_indicators(t["cap_buf"], facts, K, V, self._pred_wt(), self.fc_predicate.bias.detach(),
+                                   mode=1, eib=t["eib"], gate=t["gate"])
+
         for i in range(max_pred_len):
-            if self.has_facts:
-                ops.context_indicators(t["cap_buf"], facts, K, V, self._pred_wt(), self.fc_predicate.bias.detach(),
-                                       mode=1, eib=t["eib"], gate=t["gate"])
-            ops.decode_layers(c, i)
-            ops.decode_select_greedy(c, i)
+            if fuse and i > 0:
+                ops.decode_layers_part(c, i, 1)           # selection of step i - 1 + first self-attention block
+                if self.has_facts:
+                    indicators()
+                ops.decode_layers_part(c, i, 2)
+            else:
+                if self.has_facts:
+                    indicators()
+                ops.decode_layers(c, i)
+            if not fuse or i == max_pred_len - 1:
+                ops.decode_select_greedy(c, i)
         return t["output"]
 
     def _predict_beam_device(self, enc_tok, entities, facts, max_pred_len, beam):
@@ -894,22 +909,17 @@ class DecoderTransformer(nn.Module):
         S = kv.shape[3]
         R = B * beam
         anc = [torch.zeros(R, max_pred_len, dtype=torch.int32, device=dev) for _ in range(2)]
-        c, t = self._decode_ctx(kv, ee, fe, beam, max_pred_len, S, anc=anc[0], want_scores=True)
+        c, t = self._decode_ctx(kv, ee, fe, beam, max_pred_len, S, anc=anc[0], want_scores=True,
+                                n_done_init=B * (beam - 1))             # the unused slots count as ended
         seq = [torch.full((R, max_pred_len), self.word_map["<pad>"], dtype=torch.long, device=dev) for _ in range(2)]
         cum = torch.full((B, beam), float("-inf"), device=dev)
         cum[:, 0] = 0.0                                   # one live hypothesis per caption at the start
         fin = torch.zeros(R, dtype=torch.int32, device=dev)
-        t["n_done"].fill_(B * (beam - 1))                 # the unused slots count as ended
         facts_r = cap = None
         if self.has_facts:
             facts_r = facts.repeat_interleave(beam, dim=0).contiguous()
             cap = [torch.full((R, max_pred_len), self.word_map["<start>"], dtype=torch.long, device=dev)
                    for _ in range(2)]
-        tok = torch.full((R, 1), self.word_map["<start>"], dtype=torch.long, device=dev)
-        x0 = ops.caption_embed(tok, torch.zeros_like(tok), self.word_embedding.weight.detach(),
-                               ee.repeat_interleave(beam, dim=0), None if fe is None else fe.repeat_interleave(beam, dim=0),
-                               self.pos_encoder.pe.view(-1, d), V, self.word_map["<pad>"], math.sqrt(d), pos0=0)
-        t["x0"].copy_(x0.view(R, d))
         bs = L.BeamState()
         bs.cum, bs.fin, bs.start_token = cum.data_ptr(), fin.data_ptr(), self.word_map["<start>"]
         Vx = V + K + (fe.shape[1] if fe is not None else 0)

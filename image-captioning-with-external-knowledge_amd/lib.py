@@ -119,7 +119,7 @@ class DecodeCtx(C.Structure):
                  ("layer", DecodeLayer * MAX_LAYERS)] +
                 [(n, vp) for n in ("anc", "wv", "bv", "we", "be", "wf", "bf", "ee", "fe", "gate", "eib", "word_emb", "pe",
                                    "x0", "xa", "xb", "xc", "p1", "p2", "p3", "hfin", "hv", "ptr", "cand", "scores",
-                                   "output", "hist", "finished", "n_done", "next_token", "next_mask", "cap_buf")])
+                                   "output", "hist", "finished", "n_done", "next_token", "next_mask", "cap_buf", "sel_state")])
 
 
 class BeamState(C.Structure):
@@ -157,6 +157,8 @@ SIGNATURES = {
     "ick_packed_ce": [vp, i64, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "ick_decode_supported": [i32, i32, i32, i32, i32],
     "ick_decode_layers": [C.POINTER(DecodeCtx), i32, vp],
+    "ick_decode_layers_part": [C.POINTER(DecodeCtx), i32, i32, vp],
+    "ick_decode_init": [C.POINTER(DecodeCtx), i32, i32, vp],
     "ick_decode_select_greedy": [C.POINTER(DecodeCtx), i32, vp],
     "ick_decode_select_beam": [C.POINTER(DecodeCtx), C.POINTER(BeamState), i32, vp],
     "ick_decode_beam_supported": [i32, i32],

@@ -518,6 +518,16 @@ def decode_layers(ctx, pos):
     L.check(L.load().ick_decode_layers(C.byref(ctx), pos, _stream()), "ick_decode_layers")
 
 
+def decode_layers_part(ctx, pos, part):
+    """part 1: the first self-attention block (with ctx.sel_state: the previous step's token selection inside it);
+    part 2: the rest of the step."""
+    L.check(L.load().ick_decode_layers_part(C.byref(ctx), pos, part, _stream()), "ick_decode_layers_part")
+
+
+def decode_init(ctx, start_token, n_done_init=0):
+    L.check(L.load().ick_decode_init(C.byref(ctx), start_token, n_done_init, _stream()), "ick_decode_init")
+
+
 def decode_select_greedy(ctx, pos):
     L.check(L.load().ick_decode_select_greedy(C.byref(ctx), pos, _stream()), "ick_decode_select_greedy")
 

@@ -332,6 +332,9 @@ typedef struct {
     int32_t *hist, *finished, *n_done;/* (R, max_len) runner-ups; (R) ended flags; (1) number of ended rows */
     int64_t *next_token, *next_mask;  /* (R) */
     int64_t *cap_buf;                 /* optional (R, max_len) caption buffer read by ick_context_indicators */
+    int32_t *sel_state;               /* optional (2, R, 12) workspace: with it (greedy, rows_per_sample == 1) ick_decode_layers
+                                       * of position pos >= 1 chooses the token of step pos - 1 inside its first launch, and
+                                       * ick_decode_select_greedy is only called for the last step */
 } ick_decode_ctx;
 
 /* 1 when the fused path handles these sizes (d % 4 == 0, 64 <= d <= 320, head width <= 32, S <= 1024,
@@ -339,6 +342,13 @@ typedef struct {
 int ick_decode_supported(int32_t d, int32_t H, int32_t FF, int32_t S, int32_t max_len);
 /* Decoder stack + score head for position `pos`: reads x0, leaves ptr / cand (/ scores / hfin). */
 int ick_decode_layers(const ick_decode_ctx* ctx, int32_t pos, void* stream);
+/* The same in two parts (part 1: the first self-attention block -- with sel_state the selection of the previous step --,
+ * part 2: everything behind it; part 0 = ick_decode_layers): the knowledge variants run ick_context_indicators on the
+ * caption buffer between the two. */
+int ick_decode_layers_part(const ick_decode_ctx* ctx, int32_t pos, int32_t part, void* stream);
+/* One launch that initialises every per-call buffer of a decode: output = <pad>, history / flags / windows = 0,
+ * caption buffer = <start>, *n_done = n_done_init, x0 = embedding of <start> at position 0. */
+int ick_decode_init(const ick_decode_ctx* ctx, int32_t start_token, int32_t n_done_init, void* stream);
 /* Greedy selection + predict()'s bookkeeping + embedding of the next input token into x0 (models.py:410-442). */
 int ick_decode_select_greedy(const ick_decode_ctx* ctx, int32_t pos, void* stream);
 

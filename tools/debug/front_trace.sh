@@ -3,7 +3,7 @@
 # while conv1 / the image K/V projection run?
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_front
-rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_front -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no-profile --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_front.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_front -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no-profile --no-cpu-baseline --no-modes --min-seconds 0 > $GRAFT_REPO_ROOT/gpurun_out/prof_front.log 2>&1
 tail -1 $GRAFT_REPO_ROOT/gpurun_out/prof_front.log | cut -c1-160
 python3 $GRAFT_REPO_ROOT/tools/timeline.py $GRAFT_REPO_ROOT/gpurun_out/prof_front > $GRAFT_REPO_ROOT/gpurun_out/front_timeline.txt
 head -80 $GRAFT_REPO_ROOT/gpurun_out/front_timeline.txt
