@@ -201,6 +201,8 @@ class Encoder(nn.Module):
         if feats.dim() != 4 or feats.shape[1] != self.encoder_dim:
             raise IckError("Encoder.forward expects images (B, 3, H, W) or the (B, %d, H, W) feature map"
                            % self.encoder_dim)
+        if feats.dtype != torch.float32:          # a float16 feature file: the kernels read float32
+            feats = feats.float()
         feats = feats.contiguous()
         B, Cc, Hh, Ww = feats.shape
         P = Hh * Ww

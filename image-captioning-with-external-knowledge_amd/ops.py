@@ -53,6 +53,9 @@ def gemm_args(A, B, Cout, M, N, K, a_rs, a_ks, b_rs, b_ks, c_rs, bias=None, a_gr
     """ick_gemm_args for C[m,n] = act(alpha * sum_k A(m,k) B(n,k) + bias[n]) with explicit element strides; A/B/Cout
     are tensors (only their data pointers are used -- the caller guarantees the strides stay in bounds).
     colsum_a (k-major A only): colsum_a[m] += sum_k A(m,k)."""
+    for t in (A, B, Cout):
+        if t.dtype != torch.float32:
+            raise L.IckError("ick_gemm operands must be float32, got %s" % t.dtype)
     a = L.GemmArgs()
     a.A, a.B, a.C, a.bias = _p(A), _p(B), _p(Cout), _p(bias)
     a.M, a.N, a.K = M, N, K

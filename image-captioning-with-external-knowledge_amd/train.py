@@ -61,7 +61,10 @@ def _batch_to_device(batch, device, has_facts):
     imgs, caps, caplens, capmasks, ent = batch[0], batch[1], batch[2], batch[3], batch[4]
     facts = batch[6].to(device) if has_facts else None
     # entity features stay on the host exactly as in geo-aware/train.py:263-266; the decoder moves them
-    return imgs.to(device), caps.to(device), caplens.to(device), capmasks.to(device), ent, facts
+    imgs = imgs.to(device)
+    if imgs.dtype != torch.float32:                     # a float16 feature file: widened on the device
+        imgs = imgs.float()
+    return imgs, caps.to(device), caplens.to(device), capmasks.to(device), ent, facts
 
 
 class ThreadedBatches:
@@ -276,11 +279,12 @@ class ShardSampler(torch.utils.data.Sampler):
         return len(self.idx)
 
 
-def make_loaders(cfg, rank, world):
+def make_loaders(cfg, rank, world, fused=None):
     """TRAIN: one permutation per epoch shared by all ranks (seed + epoch), dealt out in disjoint equal shards --
     DistributedSampler pads by wrapping around so that every rank runs the same number of steps (each step holds a
     collective).  The global batch is cfg.batch_size * world samples.  VAL: disjoint unpadded shards."""
-    data = {s: CaptionDataset(cfg.data_dir, cfg.data_name, s, keep_half=cfg.half_features and cfg.fused and cfg.prefetch
+    fused = cfg.fused if fused is None else fused       # main(): fine_tune_encoder turns the fused step off
+    data = {s: CaptionDataset(cfg.data_dir, cfg.data_name, s, keep_half=cfg.half_features and fused and cfg.prefetch
                               and s == "TRAIN") for s in ("TRAIN", "VAL")}
     samplers = {"TRAIN": None, "VAL": None}
     if world > 1:
@@ -370,7 +374,7 @@ def main(cfg=None):
     elif decoder_optimizer is None:
         decoder_optimizer = torch.optim.Adam([p for p in decoder.parameters() if p.requires_grad], lr=cfg.decoder_lr)
     criterion = nn.CrossEntropyLoss(ignore_index=word_map["<pad>"]).to(device)
-    loaders, samplers, shuffle_gen = make_loaders(cfg, rank, world)
+    loaders, samplers, shuffle_gen = make_loaders(cfg, rank, world, fused)
     history = []
     for epoch in range(start_epoch, cfg.epochs):
         if epochs_since_improvement == cfg.max_epochs_since_improvement:
