@@ -317,6 +317,11 @@ def pass_fraction(cfgname, mode, ms_per_step, L):
     return None
 
 
+def _gemm_mode():
+    from ick_amd import ops
+    return ops.gemm_split_mode()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -363,6 +368,12 @@ def main():
                                 "beam": "beam_decode (Encoder.conv1 + predict_beam, beam %d, KV-cached)" % BEAM}[args.mode],
                        "global_batch": world * B,
                        "graph": res["graph"],      # False = hipGraph capture failed and the steps were launched eagerly
+                       # how the large GEMM tiles form their fp32 products (csrc/gemm.hip; ICK_GEMM_SPLIT)
+                       "gemm_products": {0: "exact fp32 MFMA (v_mfma_f32_16x16x4_f32)",
+                                         1: "split: 6 bf16 MFMA partial products of the exact 3-way bf16 split, fp32 "
+                                            "accumulate (forward layouts)",
+                                         2: "split: 6 bf16 MFMA partial products of the exact 3-way bf16 split, fp32 "
+                                            "accumulate (all large tiles)"}[_gemm_mode()],
                        "collective_backend": backend if args.mode == "train" else "none",
                        "parallelism": ("dp%d (one flat-bucket all-reduce per step)" if args.mode == "train"
                                        else "dp%d (independent shards)") % world},
@@ -407,14 +418,21 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         torch.cuda.synchronize()
-        for name, mode, cname, steps in (("forward_cfg2", "forward", "cfg2", 50), ("greedy_cfg5", "greedy", "cfg5", 20),
-                                         ("beam5_cfg5", "beam", "cfg5", 10), ("train_cfg4", "train", "cfg4", 20)):
-            if (mode, cname) == (args.mode, cfgname):
+        # the *_split legs: the same workloads with the opt-in split-bf16 products of the large GEMM tiles
+        # (ICK_GEMM_SPLIT=1; fp32-accurate, tests/test_gemm_split_gpu.py) -- the headline stays on the exact fp32 MFMA
+        for name, mode, cname, steps, split in (("forward_cfg2", "forward", "cfg2", 50, 0),
+                                                ("greedy_cfg5", "greedy", "cfg5", 20, 0),
+                                                ("beam5_cfg5", "beam", "cfg5", 10, 0),
+                                                ("train_cfg4", "train", "cfg4", 20, 0),
+                                                ("train_cfg2_split_gemm", "train", "cfg2", 50, 1),
+                                                ("forward_cfg2_split_gemm", "forward", "cfg2", 50, 1)):
+            if (mode, cname) == (args.mode, cfgname) and not split:
                 continue
             cmd = [sys.executable, os.path.abspath(__file__), "--mode", mode, "--config", cname, "--steps", str(steps),
                    "--warmup", "3", "--min-seconds", "0.5", "--no-modes", "--no-cpu-baseline", "--profile-steps",
                    "0" if args.no_profile else "2"] + (["--no-profile"] if args.no_profile else [])
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+            env["ICK_GEMM_SPLIT"] = str(split)
             r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not lines:
@@ -422,7 +440,8 @@ def main():
                 continue
             c = json.loads(lines[-1])
             entry = {"workload": c["config"]["workload"], "mode": mode, "steps": steps, "repeats": c["repeats"],
-                     "ms_per_step": c["ms_per_step"], "value": c["value"], "unit": c["unit"], "graph": c["config"]["graph"]}
+                     "ms_per_step": c["ms_per_step"], "value": c["value"], "unit": c["unit"], "graph": c["config"]["graph"],
+                     "gemm_products": c["config"].get("gemm_products")}
             rf = c.get("roofline", {})
             if "pass_frac_executed" in rf:
                 entry["pass_frac"] = rf["pass_frac_executed"]

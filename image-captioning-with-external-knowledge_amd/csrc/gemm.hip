@@ -63,13 +63,49 @@ __device__ __forceinline__ int64_t col_offset(const ick_gemm_args& p, int col) {
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 constexpr uint32_t kOobOffset = 0x80000000u;   // >= any extent the vector path accepts (< 2 GiB)
 
-template <int R, bool KM, bool VEC, int BKT, int NT = 256>
+// ---- split operands (SPL): fp32 products on the bf16 matrix pipe --------------------------------------------------
+// gfx950 has no reduced-precision fp32 MFMA, and the exact one runs at 1/16 of the bf16 rate.  Every fp32 value is the
+// EXACT sum of three bf16 numbers (x = hi + mid + lo: 3 x 8 significand bits, round-to-nearest at each level, the
+// residuals are exact fp32 subtractions), so a product a*b is the sum of nine bf16 x bf16 products, each of which the
+// matrix pipe forms exactly and accumulates in fp32.  The three smallest (mid*lo, lo*mid, lo*lo: <= 2^-24 of a*b
+// together) are dropped: six v_mfma_f32_16x16x32_bf16 per 16x16x32 block instead of eight v_mfma_f32_16x16x4_f32 at
+// a sixteenth of the rate -- 2.7 x the matrix throughput at an error below one fp32 rounding of the product
+// (measured against fp64 beside the exact path: tests/test_gemm_split_gpu.py).  The split happens once per staged
+// element, between the global load and the LDS store; LDS holds three bf16 planes per operand tile:
+//   k-contiguous operand: plane[row][32 k] in 64-byte rows, 16-byte chunk c of row r at chunk c ^ ((-(r >> 2)) & 3):
+//     the ds_read_b128 of the MFMA operand (lane (i, q) takes k = 8q..8q+7 of row i) is conflict-free for the four
+//     16-lane groups the LDS serves it in, and so are the ds_write_b64 of the stager;
+//   k-major operand: plane[k][rows] with (2 rows + 32)-byte k lines, stored as it arrives (ds_write_b64 of 4 rows) and
+//     read with ds_read_b64_tr_b16, the transposing read: two of them deliver the same 8-k operand.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+// (a, b) -> packed (hi, mid, lo) pairs, a in the low half
+__device__ __forceinline__ void split3(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = pack_bf16(a, b);
+    const float ra = a - __builtin_bit_cast(float, hi << 16), rb = b - __builtin_bit_cast(float, hi & 0xffff0000u);
+    mid = pack_bf16(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, mid << 16), sb = rb - __builtin_bit_cast(float, mid & 0xffff0000u);
+    lo = pack_bf16(sa, sb);
+}
+__device__ __forceinline__ int kc_swz(int row) { return (-(row >> 2)) & 3; }
+
+template <int R, bool KM, bool VEC, int BKT, int NT = 256, bool SPL = false>
 struct Stager {
     static constexpr int NP = R * BKT / (4 * NT);    // float4 per thread (NT threads)
     static_assert(NP >= 1, "tile too small for the workgroup");
+    static_assert(!SPL || (VEC && BKT == 32), "split operands: vector staging, 32-k slices");
     static constexpr int CH = KM ? R / 4 : BKT / 4;  // float4 chunks along the contiguous dim
     static constexpr int LD = KM ? R + 4 : BKT + 4;
-    static constexpr int FLOATS = KM ? BKT * LD : R * LD;
+    static constexpr int KLINE = 2 * R + 32;         // SPL, k-major: bytes per k line of a plane
+    static constexpr int PLANE = KM ? BKT * KLINE : R * 64;   // SPL: bytes per bf16 plane
+    static constexpr int FLOATS = SPL ? 3 * PLANE / 4 : (KM ? BKT * LD : R * LD);
     static constexpr int KP = NT / CH;               // k-major: k lines covered per pass
     static constexpr int RP = NT / CH;               // k-contiguous: rows covered per pass
     const float* base;
@@ -80,6 +116,8 @@ struct Stager {
     int c, r0;
     uint32_t ok;               // !VEC: validity bits of the rows behind off[]
     float4 v[2][NP];           // two register sets: the loads of slice i+2 fly while slice i+1 waits to be stored
+    float4 cs;                 // SPL, k-major: this thread's share of the column sums (rows 4c..4c+3 over its k lines)
+    bool want_cs;
 
     __device__ __forceinline__ void init(const float* p, const RowMap& m, int64_t kstride, int tile_row0, int rows,
                                          int64_t extent) {
@@ -88,6 +126,8 @@ struct Stager {
         c = t % CH;
         r0 = t / CH;
         ok = 0;
+        cs = float4{0.f, 0.f, 0.f, 0.f};
+        want_cs = false;
         if constexpr (VEC) {
             rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), (short)0, (int)(extent * 4), 0x00020000);
             if constexpr (KM) {
@@ -150,7 +190,7 @@ struct Stager {
 
     // Write the slice to LDS; zero what lies beyond kend (VEC: rows outside the matrix are already zero).
     template <int SET>
-    __device__ __forceinline__ void store(float* lds, int k0, int kend) const {
+    __device__ __forceinline__ void store(float* lds, int k0, int kend) {
         const bool tail = k0 + BKT > kend;   // uniform: only the last slice of the K range needs masking
         if constexpr (KM) {
 #pragma unroll
@@ -162,7 +202,18 @@ struct Stager {
                     x.x = (kv && (m & 1u)) ? x.x : 0.f; x.y = (kv && (m & 2u)) ? x.y : 0.f;
                     x.z = (kv && (m & 4u)) ? x.z : 0.f; x.w = (kv && (m & 8u)) ? x.w : 0.f;
                 }
-                *reinterpret_cast<float4*>(lds + (r0 + KP * j) * LD + 4 * c) = x;
+                if constexpr (SPL) {
+                    if (want_cs) { cs.x += x.x; cs.y += x.y; cs.z += x.z; cs.w += x.w; }
+                    uint32_t h0, m0, l0, h1, m1, l1;
+                    split3(x.x, x.y, h0, m0, l0);
+                    split3(x.z, x.w, h1, m1, l1);
+                    char* at = reinterpret_cast<char*>(lds) + (r0 + KP * j) * KLINE + 8 * c;
+                    *reinterpret_cast<uint2*>(at) = uint2{h0, h1};
+                    *reinterpret_cast<uint2*>(at + PLANE) = uint2{m0, m1};
+                    *reinterpret_cast<uint2*>(at + 2 * PLANE) = uint2{l0, l1};
+                } else {
+                    *reinterpret_cast<float4*>(lds + (r0 + KP * j) * LD + 4 * c) = x;
+                }
             }
         } else {
             const int k = k0 + 4 * c;
@@ -174,7 +225,18 @@ struct Stager {
                     x.x = (rv && k + 0 < kend) ? x.x : 0.f; x.y = (rv && k + 1 < kend) ? x.y : 0.f;
                     x.z = (rv && k + 2 < kend) ? x.z : 0.f; x.w = (rv && k + 3 < kend) ? x.w : 0.f;
                 }
-                *reinterpret_cast<float4*>(lds + (r0 + RP * j) * LD + 4 * c) = x;
+                if constexpr (SPL) {
+                    uint32_t h0, m0, l0, h1, m1, l1;
+                    split3(x.x, x.y, h0, m0, l0);
+                    split3(x.z, x.w, h1, m1, l1);
+                    const int row = r0 + RP * j;
+                    char* at = reinterpret_cast<char*>(lds) + row * 64 + 16 * ((c >> 1) ^ kc_swz(row)) + 8 * (c & 1);
+                    *reinterpret_cast<uint2*>(at) = uint2{h0, h1};
+                    *reinterpret_cast<uint2*>(at + PLANE) = uint2{m0, m1};
+                    *reinterpret_cast<uint2*>(at + 2 * PLANE) = uint2{l0, l1};
+                } else {
+                    *reinterpret_cast<float4*>(lds + (r0 + RP * j) * LD + 4 * c) = x;
+                }
             }
         }
     }
@@ -194,6 +256,29 @@ __device__ __forceinline__ void read_frag(const float* lds, int row0, int t, int
     }
 }
 
+// SPL: the three bf16 planes of one 16-row x 32-k MFMA operand (see the layout notes above).
+template <int R, bool KM>
+__device__ __forceinline__ void read_frag_spl(const float* lds, int row0, int i, int q, bf16x8_t (&f)[3]) {
+    const char* base = reinterpret_cast<const char*>(lds);
+    if constexpr (KM) {
+        constexpr int KLINE = 2 * R + 32, PLANE = 32 * KLINE;
+        const char* at = base + (8 * q + (i >> 2)) * KLINE + (row0 + 4 * (i & 3)) * 2;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const s16x4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(at + p * PLANE));
+            const s16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(at + p * PLANE + 4 * KLINE));
+            f[p] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    } else {
+        constexpr int PLANE = R * 64;
+        const int row = row0 + i;
+        const char* at = base + row * 64 + 16 * (q ^ kc_swz(row));
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            f[p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(at + p * PLANE));
+    }
+}
+
 // Split-K problems whose K split count is a multiple of 8 (the weight gradients: small outputs, long reductions):
 // workgroups are dispatched round robin over the 8 XCDs in linear order, so XCD x is given the whole tile grid of the K
 // splits x, x + 8, ...: every XCD then streams only its own K range of both operands and the re-reads by the other
@@ -210,13 +295,13 @@ __device__ __forceinline__ bool split_major(int& bid, int& zid, int nt, int nspl
 }
 
 // One output tile: workgroup `bid` of the tiles_m x tiles_n grid of problem p, K slice `zid`.
-template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT>
+template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT, bool SPL = false>
 __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, int tiles_n, int kchunk, int bid,
                                           int zid, float* smem, bool xcd_remap = true) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     constexpr int BK = BKT;
-    using SA = Stager<BM, AKM, VEC, BKT, WM * WN * 64>;
-    using SB = Stager<BN, BKM, VEC, BKT, WM * WN * 64>;
+    using SA = Stager<BM, AKM, VEC, BKT, WM * WN * 64, SPL>;
+    using SB = Stager<BN, BKM, VEC, BKT, WM * WN * 64, SPL>;
     constexpr int STAGE = SA::FLOATS + SB::FLOATS;
 
     // XCD-aware tile order (blocks b, b+8, ... share an XCD).
@@ -252,6 +337,7 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
     const int nk = (kend - kbeg + BK - 1) / BK;
     const bool colsum = AKM && p.colsum_a != nullptr && tn == 0;   // uniform
     float csum = 0.f;
+    if constexpr (SPL && AKM) sa.want_cs = colsum;    // split planes in LDS: the column sums are taken from the registers
     // Software pipeline, two slices deep: slice i is in LDS buffer i&1, slice i+1 is in flight (or landed)
     // in register set (i+1)&1 and is written to the other LDS buffer after the MFMAs of slice i, slice i+2
     // is requested into register set i&1 before them -- every global load has two MFMA phases to land.
@@ -269,7 +355,30 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
         const float* Bs = As + SA::FLOATS;
         const int k0 = kbeg + it * BK;
         if (it + 2 < nk) { sa.template load<CUR>(k0 + 2 * BK, kend); if (!only) sb.template load<CUR>(k0 + 2 * BK, kend); }
-        const int nchunk = only ? 0 : min(BK / 16, (kend - k0 + 15) >> 4);
+        if constexpr (SPL) {
+            if (!only) {
+                // one 16x16x32 block per tile and slice, six bf16 products (smallest first)
+                bf16x8_t af[TM][3], bf[TN][3];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) read_frag_spl<BM, AKM>(As, (wm * TM + a) * 16, fi, fq, af[a]);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) read_frag_spl<BN, BKM>(Bs, (wn * TN + b) * 16, fi, fq, bf[b]);
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        f32x4 c = acc[a][b];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[b][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][2], bf[b][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][1], bf[b][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[b][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][1], bf[b][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[b][0], c, 0, 0, 0);
+                        acc[a][b] = c;
+                    }
+            }
+        }
+        const int nchunk = (only || SPL) ? 0 : min(BK / 16, (kend - k0 + 15) >> 4);
         for (int t = 0; t < nchunk; ++t) {
             float af[TM][4], bf[TN][4];
 #pragma unroll
@@ -284,7 +393,7 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
                     for (int b = 0; b < TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][u], bf[b][u], acc[a][b], 0, 0, 0);
         }
-        if constexpr (AKM) {
+        if constexpr (AKM && !SPL) {
             // bias-gradient fusion: column sums of the k-major A operand (dY of a weight-gradient GEMM), taken
             // from the tile already in LDS by the workgroups of the first tile column
             if (colsum && threadIdx.x < BM) {
@@ -304,6 +413,16 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
         if (it + 1 < nk) phase(it + 1, std::integral_constant<int, 1>{});
     }
 
+    if constexpr (SPL && AKM) {
+        if (colsum) {      // uniform.  The threads' shares ([k-line group r0][4 rows]) meet in LDS (free after the last barrier)
+            *reinterpret_cast<float4*>(smem + sa.r0 * BM + 4 * sa.c) = sa.cs;
+            __syncthreads();
+            if (threadIdx.x < BM) {
+#pragma unroll 4
+                for (int r = 0; r < SA::KP; ++r) csum += smem[r * BM + threadIdx.x];
+            }
+        }
+    }
     if (colsum && threadIdx.x < BM && m0 + (int)threadIdx.x < p.M) atomicAdd(p.colsum_a + m0 + threadIdx.x, csum);
     if (only) return;
 
@@ -366,13 +485,13 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT>
+template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT, bool SPL>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(ick_gemm_args p, int tiles_m, int tiles_n, int kchunk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if constexpr (TM == 1) chain_priority();     // 32 x 32 tiles: the chain GEMMs (single launches, not the grouped weight gradients)
     int bid = blockIdx.x, zid = blockIdx.z;
     const bool by_split = split_major(bid, zid, gridDim.x, gridDim.z);
-    gemm_tile<WM, WN, TM, TN, AKM, BKM, VEC, BKT>(p, tiles_m, tiles_n, kchunk, bid, zid, smem, !by_split);
+    gemm_tile<WM, WN, TM, TN, AKM, BKM, VEC, BKT, SPL>(p, tiles_m, tiles_n, kchunk, bid, zid, smem, !by_split);
 }
 
 // Several independent problems of the same kernel configuration in one launch (the weight-gradient GEMMs of a
@@ -386,7 +505,7 @@ struct GroupArgs {
     ick_gemm_args g[kGroupMax];
 };
 
-template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT>
+template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT, bool SPL>
 __global__ __launch_bounds__(256) void gemm_group_kernel(GroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int gi = 0;
@@ -396,8 +515,8 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GroupArgs ga) {
     if (local >= nt * ga.split[gi]) return;      // padding
     int zid = local / nt, bid = local - zid * nt;
     const bool by_split = split_major(bid, zid, nt, ga.split[gi]);
-    gemm_tile<WM, WN, TM, TN, AKM, BKM, VEC, BKT>(ga.g[gi], ga.tiles_m[gi], ga.tiles_n[gi], ga.kchunk[gi], bid, zid, smem,
-                                                  !by_split);
+    gemm_tile<WM, WN, TM, TN, AKM, BKM, VEC, BKT, SPL>(ga.g[gi], ga.tiles_m[gi], ga.tiles_n[gi], ga.kchunk[gi], bid, zid,
+                                                       smem, !by_split);
 }
 
 // Host-side plan of one problem: validated arguments + kernel configuration.
@@ -406,6 +525,8 @@ struct Plan {
     bool akm, bkm, vec;
     bool big;                    // 64 x 64 tiles (else 32 x 32)
     bool wide;                   // 128 x 64 tiles, 8 waves (single launches only)
+    bool spl;                    // split-bf16 products (64 x 64 and 128 x 64 tiles of the vector path)
+    bool xl;                     // 128 x 128 tiles, 8 waves, split products only (single launches only; implies wide)
     int tiles_m, tiles_n, kchunk, split;
 };
 
@@ -421,35 +542,45 @@ inline size_t lds_floor(int which) {
     return (size_t)v[which];
 }
 
-template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC>
-int launch_tile(const Plan& pl, hipStream_t s) {
+template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, bool SPL>
+int launch_tile_s(const Plan& pl, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = WM * WN * 64;
-    constexpr int STAGE = Stager<BM, AKM, VEC, 32, NT>::FLOATS + Stager<BN, BKM, VEC, 32, NT>::FLOATS;
+    constexpr int STAGE = Stager<BM, AKM, VEC, 32, NT, SPL>::FLOATS + Stager<BN, BKM, VEC, 32, NT, SPL>::FLOATS;
     constexpr size_t smem = 2 * STAGE * sizeof(float);
-    static_assert(smem <= 64 * 1024, "tile needs the large-LDS attribute");
+    static_assert(smem <= 160 * 1024, "tile exceeds the LDS of a CU");
     const size_t lds = (TM > 1) ? std::max(smem, lds_floor(0)) : smem;
     if (lds > 64 * 1024) {
         static bool attr = false;
         if (!attr) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<WM, WN, TM, TN, AKM, BKM, VEC, 32>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute(
+                reinterpret_cast<const void*>(gemm_kernel<WM, WN, TM, TN, AKM, BKM, VEC, 32, SPL>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
             attr = true;
         }
     }
-    hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, AKM, BKM, VEC, 32>), dim3(pl.tiles_m * pl.tiles_n, 1, pl.split),
+    hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, AKM, BKM, VEC, 32, SPL>), dim3(pl.tiles_m * pl.tiles_n, 1, pl.split),
                        dim3(NT), lds, s, pl.a, pl.tiles_m, pl.tiles_n, pl.kchunk);
     ICK_LAUNCH_RET();
+}
+template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC>
+int launch_tile(const Plan& pl, hipStream_t s) {
+    if constexpr (VEC && TM > 1) {
+        if (pl.spl) return launch_tile_s<WM, WN, TM, TN, AKM, BKM, VEC, true>(pl, s);
+    }
+    return launch_tile_s<WM, WN, TM, TN, AKM, BKM, VEC, false>(pl, s);
 }
 template <int TM, int TN, bool AKM, bool BKM, bool VEC>
 int launch_one(const Plan& pl, hipStream_t s) { return launch_tile<2, 2, TM, TN, AKM, BKM, VEC>(pl, s); }
 template <int TM, int TN, bool AKM, bool BKM, bool VEC>
 int launch_wide(const Plan& pl, hipStream_t s) { return launch_tile<4, 2, TM, TN, AKM, BKM, VEC>(pl, s); }   // 8 waves
+template <int TM, int TN, bool AKM, bool BKM, bool VEC>
+int launch_xl(const Plan& pl, hipStream_t s) { return launch_tile_s<4, 2, TM, TN, AKM, BKM, VEC, true>(pl, s); }
 
-template <int TM, int TN, bool AKM, bool BKM>
-int launch_group(const Plan* const* pls, int n, hipStream_t s) {
+template <int TM, int TN, bool AKM, bool BKM, bool SPL>
+int launch_group_s(const Plan* const* pls, int n, hipStream_t s) {
     constexpr int BM = 2 * TM * 16, BN = 2 * TN * 16;
-    constexpr int STAGE = Stager<BM, AKM, true, 32>::FLOATS + Stager<BN, BKM, true, 32>::FLOATS;
+    constexpr int STAGE = Stager<BM, AKM, true, 32, 256, SPL>::FLOATS + Stager<BN, BKM, true, 32, 256, SPL>::FLOATS;
     constexpr size_t smem = 2 * STAGE * sizeof(float);
     GroupArgs ga;
     ga.count = n;
@@ -465,8 +596,28 @@ int launch_group(const Plan* const* pls, int n, hipStream_t s) {
         ga.wg_end[i] = total; ga.tiles_m[i] = ga.tiles_n[i] = 1; ga.kchunk[i] = 32; ga.split[i] = 0; ga.g[i] = pls[0]->a;
     }
     const size_t lds = (TM > 1) ? std::max(smem, lds_floor(1)) : smem;
-    hipLaunchKernelGGL((gemm_group_kernel<2, 2, TM, TN, AKM, BKM, true, 32>), dim3(total), dim3(256), lds, s, ga);
+    hipLaunchKernelGGL((gemm_group_kernel<2, 2, TM, TN, AKM, BKM, true, 32, SPL>), dim3(total), dim3(256), lds, s, ga);
     ICK_LAUNCH_RET();
+}
+template <int TM, int TN, bool AKM, bool BKM>
+int launch_group(const Plan* const* pls, int n, hipStream_t s) {
+    if constexpr (TM > 1) {
+        if (pls[0]->spl) return launch_group_s<TM, TN, AKM, BKM, true>(pls, n, s);
+    }
+    return launch_group_s<TM, TN, AKM, BKM, false>(pls, n, s);
+}
+
+// Split-bf16 products for the 64 x 64 / 128 x 64 / 128 x 128 tiles.  Opt-in: ICK_GEMM_SPLIT=1 (or ick_set_gemm_split(1))
+// takes them where they are faster than the exact fp32 MFMA (B operand k-contiguous: the forward GEMMs and the feature
+// projection); 2 takes them for every large-tile problem (the k-major forms gain nothing yet: tools/gemm_split_bench.py).
+// Default 0: every product on v_mfma_f32_16x16x4_f32.
+int g_gemm_split = -1;
+inline int gemm_split_mode() {
+    if (g_gemm_split < 0) {
+        const char* e = getenv("ICK_GEMM_SPLIT");
+        g_gemm_split = e ? std::min(2, std::max(0, atoi(e))) : 0;
+    }
+    return g_gemm_split;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -551,8 +702,20 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
         pl.wide = pl.vec && pl.big && a.M >= 128 &&
                   (forced == 8 || (forced < 0 && akm && !bkm && a.N <= 320 && a.M >= 4096 && a.K >= 1024 && split_req == 1));
     }
+    pl.spl = pl.vec && pl.big && (gemm_split_mode() == 2 || (gemm_split_mode() == 1 && !bkm));
+    pl.xl = false;
+    if (pl.spl && split_req == 1) {
+        // 128 x 128 tiles: twice the products per staged (and split) element.  One workgroup per CU (98 KB of LDS), so
+        // the problem must bring several rounds of tiles and waste little of its last tile column
+        static int forced = -2;
+        if (forced == -2) { const char* e = getenv("ICK_GEMM_XL"); forced = e ? atoi(e) : -1; }
+        const int64_t t128 = (int64_t)ceil_div(a.M, 128) * ceil_div(a.N, 128);
+        const bool fits = a.M >= 128 && a.N >= 128 && t128 >= 512 && ceil_div(a.N, 128) * 128 <= a.N + a.N / 8;
+        pl.xl = forced < 0 ? fits : (forced > 0 && a.M >= 128 && a.N >= 128);
+        if (pl.xl) pl.wide = true;
+    }
     const int BMN = pl.big ? 64 : 32;
-    pl.tiles_m = ceil_div(a.M, pl.wide ? 128 : BMN); pl.tiles_n = ceil_div(a.N, BMN);
+    pl.tiles_m = ceil_div(a.M, pl.wide ? 128 : BMN); pl.tiles_n = ceil_div(a.N, pl.xl ? 128 : BMN);
     pl.kchunk = ceil_div(ceil_div(a.K, split_req), 32) * 32;
     pl.split = ceil_div(a.K, pl.kchunk);
     return ICK_OK;
@@ -570,6 +733,7 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
 
 int launch_plan(const Plan& pl, hipStream_t s) {
     if (!pl.vec) ICK_BY_LAYOUT(launch_one, 2, 2, ICK_COMMA_FALSE, pl, s);
+    if (pl.xl) ICK_BY_LAYOUT(launch_xl, 2, 4, ICK_COMMA_TRUE, pl, s);
     if (pl.wide) ICK_BY_LAYOUT(launch_wide, 2, 2, ICK_COMMA_TRUE, pl, s);
     if (pl.big) ICK_BY_LAYOUT(launch_one, 2, 2, ICK_COMMA_TRUE, pl, s);
     ICK_BY_LAYOUT(launch_one, 1, 1, ICK_COMMA_TRUE, pl, s);
@@ -597,11 +761,20 @@ extern "C" int ick_gemm_plan(const ick_gemm_args* in, ick_gemm_plan_info* out) {
     Plan pl;
     if (int rc = make_plan(in, pl)) return rc;
     const int bmn = pl.big ? 64 : 32;
-    out->tile_m = pl.wide ? 128 : bmn; out->tile_n = bmn; out->waves = pl.wide ? 8 : 4;
+    out->tile_m = pl.wide ? 128 : bmn; out->tile_n = pl.xl ? 128 : bmn; out->waves = pl.wide ? 8 : 4;
     out->tiles_m = pl.tiles_m; out->tiles_n = pl.tiles_n; out->split_k = pl.split;
     out->a_kmajor = pl.akm; out->b_kmajor = pl.bkm; out->vec = pl.vec;
+    out->split_bf16 = pl.spl;
     return ICK_OK;
 }
+
+extern "C" int ick_set_gemm_split(int mode) {
+    if (mode < 0 || mode > 2) return ICK_EINVAL;
+    ick::g_gemm_split = mode;
+    return ICK_OK;
+}
+
+extern "C" int ick_get_gemm_split(void) { return ick::gemm_split_mode(); }
 
 extern "C" int ick_gemm_grouped(const ick_gemm_args* problems, int32_t count, void* stream) {
     using namespace ick;
@@ -636,7 +809,7 @@ extern "C" int ick_gemm_grouped(const ick_gemm_args* problems, int32_t count, vo
         int n = 0;
         for (int j = i; j < count && n < kGroupMax; ++j) {
             if (done[j] || !plans[j].vec || plans[j].wide || plans[j].akm != plans[i].akm || plans[j].bkm != plans[i].bkm ||
-                plans[j].big != plans[i].big) continue;
+                plans[j].big != plans[i].big || plans[j].spl != plans[i].spl) continue;
             grp[n++] = &plans[j];
             done[j] = true;
         }

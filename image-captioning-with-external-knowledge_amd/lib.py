@@ -77,7 +77,7 @@ class PackItem(C.Structure):
 
 class GemmPlanInfo(C.Structure):
     _fields_ = [(n, i32) for n in ("tile_m", "tile_n", "waves", "tiles_m", "tiles_n", "split_k", "a_kmajor", "b_kmajor",
-                                   "vec")]
+                                   "vec", "split_bf16")]
 
 
 class AttnArgs(C.Structure):
@@ -135,6 +135,8 @@ SIGNATURES = {
     "ick_device_info": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int],
     "ick_gemm": [C.POINTER(GemmArgs), vp],
     "ick_gemm_plan": [C.POINTER(GemmArgs), C.POINTER(GemmPlanInfo)],
+    "ick_set_gemm_split": [i32],
+    "ick_get_gemm_split": [],
     "ick_rowchain_supported": [i32, i32, i32],
     "ick_rowchain_fwd": [C.POINTER(RowChainArgs), vp],
     "ick_rowchain_bwd_supported": [i32, i32, i32],

@@ -93,6 +93,18 @@ def set_deterministic(on=True):
     L.check(L.load().ick_set_deterministic(1 if on else 0), "ick_set_deterministic")
 
 
+def set_gemm_split(mode):
+    """Split-bf16 products on the large GEMM tiles (ick_set_gemm_split; default 0 = off, ICK_GEMM_SPLIT in the
+    environment): six bf16 x bf16 partial products of the exact three-way bf16 split of both fp32 operands, accumulated
+    in fp32, instead of the 16 x slower exact fp32 MFMA.  1 = where it is faster (B operand k-contiguous), 2 = every
+    large-tile problem."""
+    L.check(L.load().ick_set_gemm_split(int(mode)), "ick_set_gemm_split")
+
+
+def gemm_split_mode():
+    return int(L.load().ick_get_gemm_split())
+
+
 def is_deterministic():
     return bool(L.load().ick_get_deterministic())
 

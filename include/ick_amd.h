@@ -93,8 +93,16 @@ int ick_gemm(const ick_gemm_args* args, void* stream);
  * the instantiation a benchmark quotes is the one they compared with the oracle. */
 typedef struct {
     int32_t tile_m, tile_n, waves, tiles_m, tiles_n, split_k, a_kmajor, b_kmajor, vec;
+    int32_t split_bf16;   /* 1: products formed as six bf16 x bf16 partial products of the exact three-way bf16 split of
+                           * both fp32 operands, accumulated in fp32 (64x64 / 128x64 tiles); 0: v_mfma_f32_16x16x4_f32 */
 } ick_gemm_plan_info;
 int ick_gemm_plan(const ick_gemm_args* args, ick_gemm_plan_info* out);
+/* Process-wide mode of the split-bf16 product path of the large GEMM tiles.  0 (default; environment ICK_GEMM_SPLIT
+ * unset): every product on the exact fp32 MFMA.  1: split products where they are faster (B operand k-contiguous: forward
+ * GEMMs, Encoder.conv1).  2: for every large-tile problem.  The split is exact (x = hi + mid + lo in bf16), six of the
+ * nine partial products are formed; error against fp64 no larger than the exact path's (tests/test_gemm_split_gpu.py). */
+int ick_set_gemm_split(int mode);
+int ick_get_gemm_split(void);
 /* `count` (<= 64) independent problems; those that select the same kernel configuration share one launch (up to 8
  * per launch).  Used for the weight-gradient GEMMs of a layer (geo-aware/train.py:284 `loss.backward()`), each of
  * which alone is a latency-bound launch of a few hundred workgroups. */
