@@ -24,6 +24,22 @@
 
 #include "common.h"
 
+// Diagnostic build (-DICK_GEMM_STAMPS, tools/debug/gemm_stamps.py): every workgroup of a single-problem launch records
+// where it ran (HW_ID) and the realtime clock (100 MHz) at its start, after its first LDS stage, after its K loop and
+// at its end.  Compiled out of the product library.
+#ifdef ICK_GEMM_STAMPS
+__device__ unsigned long long ick_gemm_stamps[16384][8];
+#define ICK_GSTAMP(i)                                                                                          \
+    do {                                                                                                       \
+        if (threadIdx.x == 0 && stamp_id < 16384) ick_gemm_stamps[stamp_id][i] = __builtin_readcyclecounter(); \
+    } while (0)
+extern "C" int ick_debug_read_gemm_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ick_gemm_stamps), sizeof(unsigned long long) * 8 * n);
+}
+#else
+#define ICK_GSTAMP(i)
+#endif
+
 namespace ick {
 namespace {
 
@@ -41,6 +57,29 @@ struct RowMap {  // offset of logical row r:  goff(r / grp) + (r % grp) * rs
         return gg * gs + (int64_t)i * rs;
     }
 };
+
+// Offsets of N valid rows at once: the group-map lookups of all rows are issued together (one memory round trip
+// instead of one per row: a conditional load is followed by its own s_waitcnt).
+template <int N>
+__device__ __forceinline__ void map_rows(const RowMap& m, const int (&rows)[N], int64_t (&off)[N]) {
+    if (m.grp <= 0) {            // uniform
+#pragma unroll
+        for (int i = 0; i < N; ++i) off[i] = (int64_t)rows[i] * m.rs;
+        return;
+    }
+    int g[N], in[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { g[i] = rows[i] / m.grp; in[i] = rows[i] - g[i] * m.grp; }
+    if (m.gmap != nullptr) {     // uniform
+        int gg[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) gg[i] = m.gmap[g[i]];
+#pragma unroll
+        for (int i = 0; i < N; ++i) g[i] = gg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) off[i] = (int64_t)g[i] * m.gs + (int64_t)in[i] * m.rs;
+}
 
 // Column offset inside an output row: the column itself, or the head-split scatter
 // [segment][head][position][dhp] (see include/ick_amd.h).
@@ -132,16 +171,22 @@ struct Stager {
             rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), (short)0, (int)(extent * 4), 0x00020000);
             if constexpr (KM) {
                 const int gr = tile_row0 + 4 * c;
-                const uint32_t ro = gr < rows ? (uint32_t)(m(gr) * 4) : kOobOffset;
+                const int one[1] = {min(gr, rows - 1)};
+                int64_t mo[1];
+                map_rows<1>(m, one, mo);
+                const uint32_t ro = (uint32_t)(mo[0] * 4);
 #pragma unroll
                 for (int j = 0; j < NP; ++j)
                     voff[j] = gr < rows ? ro + (uint32_t)((int64_t)(r0 + KP * j) * ks * 4) : kOobOffset;
             } else {
+                int grs[NP];
+                int64_t mo[NP];
 #pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    const int gr = tile_row0 + r0 + RP * j;
-                    voff[j] = gr < rows ? (uint32_t)((m(gr) + 4 * c) * 4) : kOobOffset;
-                }
+                for (int j = 0; j < NP; ++j) grs[j] = min(tile_row0 + r0 + RP * j, rows - 1);
+                map_rows<NP>(m, grs, mo);
+#pragma unroll
+                for (int j = 0; j < NP; ++j)
+                    voff[j] = tile_row0 + r0 + RP * j < rows ? (uint32_t)((mo[j] + 4 * c) * 4) : kOobOffset;
             }
         } else if constexpr (KM) {
 #pragma unroll
@@ -303,6 +348,17 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
     using SA = Stager<BM, AKM, VEC, BKT, WM * WN * 64, SPL>;
     using SB = Stager<BN, BKM, VEC, BKT, WM * WN * 64, SPL>;
     constexpr int STAGE = SA::FLOATS + SB::FLOATS;
+#ifdef ICK_GEMM_STAMPS
+    const int stamp_id = bid + zid * tiles_m * tiles_n;
+    if (threadIdx.x == 0 && stamp_id < 16384) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        ick_gemm_stamps[stamp_id][7] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
+    ICK_GSTAMP(0);
 
     // XCD-aware tile order (blocks b, b+8, ... share an XCD).
     const int nwg = tiles_m * tiles_n;
@@ -349,6 +405,7 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
         if (!only) sb.template store<0>(smem + SA::FLOATS, kbeg, kend);
     }
     __syncthreads();
+    ICK_GSTAMP(1);
     auto phase = [&](int it, auto cur) {
         constexpr int CUR = decltype(cur)::value, NXT = 1 - CUR;
         const float* As = smem + CUR * STAGE;
@@ -413,6 +470,7 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
         if (it + 1 < nk) phase(it + 1, std::integral_constant<int, 1>{});
     }
 
+    ICK_GSTAMP(2);
     if constexpr (SPL && AKM) {
         if (colsum) {      // uniform.  The threads' shares ([k-line group r0][4 rows]) meet in LDS (free after the last barrier)
             *reinterpret_cast<float4*>(smem + sa.r0 * BM + 4 * sa.c) = sa.cs;
@@ -445,52 +503,98 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
     int64_t coff[TM][4];
     int rowid[TM][4];
     const Dropout drop = make_dropout(p.drop_p, p.drop_epoch ? p.drop_seed + *p.drop_epoch : p.drop_seed, p.drop_site);
+    {
+        int rws[TM * 4];
+        int64_t mo[TM * 4];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                rowid[a][r] = m0 + (wm * TM + a) * 16 + fq * 4 + r;
+                rws[a * 4 + r] = min(rowid[a][r], p.M - 1);
+            }
+        map_rows<TM * 4>(cmap, rws, mo);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) coff[a][r] = rowid[a][r] < p.M ? mo[a * 4 + r] + row_bias : -1;
+    }
+    ICK_GSTAMP(4);
+    // Values first, memory second: vmcnt counts loads and stores in one queue, so a load between two stores (the gate,
+    // the old value of an accumulating epilogue) makes every row wait for the previous row's stores to be acknowledged
+    // (measured on the cross K/V projection: 4.1 of a workgroup's 22 us).  Every load of the epilogue is issued before
+    // its first store.
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + (wm * TM + a) * 16 + fq * 4 + r;
-            rowid[a][r] = row;
-            coff[a][r] = row < p.M ? cmap(row) + row_bias : -1;
-        }
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                float v = acc[a][b][r] * alpha + bv[b];
+                if (relu) v = fmaxf(v, 0.f);
+                if (drop.on()) v *= drop.mask((uint32_t)rowid[a][r] * (uint32_t)p.N + (uint32_t)cols[b]);
+                acc[a][b][r] = v;
+            }
+    if (p.gate != nullptr) {      // uniform
+        float g[TM][4][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    // unconditional loads (element 0 stands in for what lies outside the matrix; never stored)
+                    g[a][r][b] = p.gate[(coff[a][r] >= 0 && cols[b] < p.N) ? (int64_t)rowid[a][r] * p.gate_rs + cols[b] : 0];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b][r] = g[a][r][b] > 0.f ? acc[a][b][r] * p.gate_scale : 0.f;
+    }
+    if (mode == 1) {              // uniform
+        float old[TM][4][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    old[a][r][b] = p.C[(coff[a][r] >= 0 && cols[b] < p.N) ? coff[a][r] + co[b] : 0];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b][r] += old[a][r][b];
+    }
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (coff[a][r] < 0) continue;
             float* crow = p.C + coff[a][r];
-            float v[TN];
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                v[b] = acc[a][b][r] * alpha + bv[b];
-                if (relu) v[b] = fmaxf(v[b], 0.f);
-                if (drop.on()) v[b] *= drop.mask((uint32_t)rowid[a][r] * (uint32_t)p.N + (uint32_t)cols[b]);
-                if (p.gate != nullptr && cols[b] < p.N)
-                    v[b] = p.gate[(int64_t)rowid[a][r] * p.gate_rs + cols[b]] > 0.f ? v[b] * p.gate_scale : 0.f;
-            }
-            if (mode == 0) {
+            if (mode != 2) {
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    if (cols[b] < p.N) crow[co[b]] = v[b];
-            } else if (mode == 1) {
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    if (cols[b] < p.N) crow[co[b]] += v[b];
+                    if (cols[b] < p.N) crow[co[b]] = acc[a][b][r];
             } else {
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    if (cols[b] < p.N) atomicAdd(crow + co[b], v[b]);
+                    if (cols[b] < p.N) atomicAdd(crow + co[b], acc[a][b][r]);
             }
         }
     }
+    ICK_GSTAMP(3);
 }
 
 template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT, bool SPL>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(ick_gemm_args p, int tiles_m, int tiles_n, int kchunk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if constexpr (TM == 1) chain_priority();     // 32 x 32 tiles: the chain GEMMs (single launches, not the grouped weight gradients)
+    const int nt = tiles_m * tiles_n;
     int bid = blockIdx.x, zid = blockIdx.z;
-    const bool by_split = split_major(bid, zid, gridDim.x, gridDim.z);
+    const bool by_split = split_major(bid, zid, nt, gridDim.z);
     gemm_tile<WM, WN, TM, TN, AKM, BKM, VEC, BKT, SPL>(p, tiles_m, tiles_n, kchunk, bid, zid, smem, !by_split);
 }
 
@@ -559,7 +663,8 @@ int launch_tile_s(const Plan& pl, hipStream_t s) {
             attr = true;
         }
     }
-    hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, AKM, BKM, VEC, 32, SPL>), dim3(pl.tiles_m * pl.tiles_n, 1, pl.split),
+    const int gx = pl.tiles_m * pl.tiles_n;
+    hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, AKM, BKM, VEC, 32, SPL>), dim3(gx, 1, pl.split),
                        dim3(NT), lds, s, pl.a, pl.tiles_m, pl.tiles_n, pl.kchunk);
     ICK_LAUNCH_RET();
 }
