@@ -23,6 +23,21 @@
 
 #include "attention_mfma.h"
 
+// Diagnostic build (-DICK_ATTN_STAMPS, tools/debug/attn_stamps.py): workgroup (0, 0) of the last launch of each kernel
+// variant records the shader clock at its phase boundaries.  Compiled out of the product library.
+#ifdef ICK_ATTN_STAMPS
+__device__ unsigned long long ick_attn_stamps[4][16];
+#define ICK_ASTAMP(kern, i)                                                                   \
+    do {                                                                                      \
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) ick_attn_stamps[kern][i] = __builtin_readcyclecounter(); \
+    } while (0)
+extern "C" int ick_debug_read_attn_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ick_attn_stamps), sizeof(ick_attn_stamps));
+}
+#else
+#define ICK_ASTAMP(kern, i)
+#endif
+
 namespace ick {
 namespace {
 
@@ -48,16 +63,19 @@ __device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& b, f32x4 c
 // loads of the thread are issued before the first LDS write (IT = 256-thread passes, compile time), so the
 // passes share one memory round trip instead of paying one each.
 template <int IT>
-__device__ __forceinline__ void stage_transposed(const float* __restrict__ src, float* __restrict__ dst, int rows,
-                                                 int rows_pad, int SP, int dh) {
-    float4 x[IT];
+__device__ __forceinline__ void stage_transposed_load(const float* __restrict__ src, int rows, float4 (&x)[IT]) {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int f = threadIdx.x + 256 * it;
         const int s = f >> 3, c = f & 7;
-        x[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s < rows) x[it] = *reinterpret_cast<const float4*>(src + (int64_t)s * DHP + 4 * c);
+        // unconditional (rows beyond the matrix re-read row 0 and are zeroed at store time): a predicated load
+        // would be followed by its own wait
+        x[it] = *reinterpret_cast<const float4*>(src + (int64_t)(s < rows ? s : 0) * DHP + 4 * c);
     }
+}
+template <int IT>
+__device__ __forceinline__ void stage_transposed_store(const float4 (&x)[IT], float* __restrict__ dst, int rows,
+                                                       int rows_pad, int SP, int dh) {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int f = threadIdx.x + 256 * it;
@@ -77,12 +95,15 @@ template <int NQT, int MAXT>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ick_attn_args p, int SP) {
     chain_priority();
     constexpr int NQ = NQT * 16;
+    [[maybe_unused]] constexpr int SK = MAXT > 1 ? 1 : 0;      // stamp slot: cross (MAXT > 1) / self
+    ICK_ASTAMP(SK, 0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Vt = smem;                    // max(DHP * SP, 4 waves * NQT * 2 tiles * 256)   V^T: [col][key]
     float* Ored = smem;                  // the partial output tiles reuse V^T's space once every wave is done with it
     float* Qs = Vt + max(DHP * SP, 4 * NQT * 2 * 256);   // NQ * QLD      Q rows (zero padded)
     float* red = Qs + NQ * QLD;          // 4 * NQ       per-wave row statistics
     float* stat = red + 4 * NQ;          // 2 * NQ       final max / 1/sum
+    float* rsum = stat + 2 * NQ;         // 4 * NQ       per-wave row sums (red still holds the maxima other waves read)
 
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -96,28 +117,43 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ick_attn_args p, int
     const float* kb = p.K + (int64_t)b * p.k_bs + (int64_t)h * p.k_hs;
     const float* vb = p.V + (int64_t)b * p.v_bs + (int64_t)h * p.v_hs;
 
-    // this wave's K fragments straight from global memory (requested first: they land during the staging)
+    // Every global load of the kernel is requested up front, in the order it is needed: Q (staged first, behind its
+    // own barrier), this wave's K fragments (S^T), V (transposed into LDS only after S^T, whose matrix work hides its
+    // latency).  One memory round trip on the critical path instead of two.
+    constexpr int QIT = (NQ * 8 + 255) / 256;
+    float4 qx[QIT];
+#pragma unroll
+    for (int it = 0; it < QIT; ++it) {
+        const int f = tid + 256 * it;
+        const int t = f >> 3, c = f & 7;
+        qx[it] = *reinterpret_cast<const float4*>(qb + (int64_t)(t < T ? t : 0) * DHP + 4 * c);
+    }
     float4 kf[MAXT][2];
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
         const int key = 16 * (wave + 4 * i) + li;
-        const bool ok = key < slen;
-        const float* kr = kb + (int64_t)(ok ? key : 0) * DHP + 4 * lq;
+        const float* kr = kb + (int64_t)(key < slen ? key : 0) * DHP + 4 * lq;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            float4 x = *reinterpret_cast<const float4*>(kr + 16 * t);
-            x = mask_cols(x, 16 * t + 4 * lq, ok ? dh : 0);
-            kf[i][t] = x;
-        }
+        for (int t = 0; t < 2; ++t) kf[i][t] = *reinterpret_cast<const float4*>(kr + 16 * t);
     }
-    for (int f = tid; f < NQ * 8; f += 256) {
+    float4 vx[2 * MAXT];
+    stage_transposed_load<2 * MAXT>(vb, slen, vx);
+#pragma unroll
+    for (int it = 0; it < QIT; ++it) {
+        const int f = tid + 256 * it;
         const int t = f >> 3, c = f & 7;
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < T) x = mask_cols(*reinterpret_cast<const float4*>(qb + (int64_t)t * DHP + 4 * c), 4 * c, dh);
-        *reinterpret_cast<float4*>(Qs + t * QLD + 4 * c) = x;
+        if (f < NQ * 8) *reinterpret_cast<float4*>(Qs + t * QLD + 4 * c) = mask_cols(qx[it], 4 * c, t < T ? dh : 0);
     }
-    stage_transposed<2 * MAXT>(vb, Vt, slen, nkt * 16, SP, dh);
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        const bool ok = 16 * (wave + 4 * i) + li < slen;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) kf[i][t] = mask_cols(kf[i][t], 16 * t + 4 * lq, ok ? dh : 0);
+    }
+    ICK_ASTAMP(SK, 1);
     __syncthreads();
+    ICK_ASTAMP(SK, 2);
+    ICK_ASTAMP(SK, 3);
 
     // S^T tiles: lane <-> query (16 qt + li), registers <-> keys 16 kt + 4 lq + r
     f32x4 sc[MAXT][NQT];
@@ -149,16 +185,18 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ick_attn_args p, int
         mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 32, 64));
         if (lq == 0) red[wave * NQ + query] = mx[qt];
     }
-    __syncthreads();
+    ICK_ASTAMP(SK, 4);
+    stage_transposed_store<2 * MAXT>(vx, Vt, slen, nkt * 16, SP, dh);
+    __syncthreads();                     // the waves' row maxima and V^T are in LDS
     if (tid < NQ) stat[tid] = fmaxf(fmaxf(red[tid], red[NQ + tid]), fmaxf(red[2 * NQ + tid], red[3 * NQ + tid]));
-    __syncthreads();
+    ICK_ASTAMP(SK, 5);
 
     // P = exp(s - max) (the normaliser keeps every key; attention dropout only thins the numerator)
     float sum[NQT];
 #pragma unroll
     for (int qt = 0; qt < NQT; ++qt) {
         const int query = 16 * qt + li;
-        const float m = stat[query];
+        const float m = fmaxf(fmaxf(red[query], red[NQ + query]), fmaxf(red[2 * NQ + query], red[3 * NQ + query]));
         const uint32_t rowbase = (uint32_t)((b * p.H + h) * T + query) * (uint32_t)S;
         float s = 0.f;
 #pragma unroll
@@ -192,16 +230,18 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ick_attn_args p, int
             }
             oacc[qt][jt] = acc;
         }
-        if (lq == 0) red[wave * NQ + 16 * qt + li] = sum[qt];
+        if (lq == 0) rsum[wave * NQ + 16 * qt + li] = sum[qt];
     }
+    ICK_ASTAMP(SK, 6);
     __syncthreads();     // every wave is done reading V^T: its space now takes the partial tiles
+    ICK_ASTAMP(SK, 7);
 #pragma unroll
     for (int qt = 0; qt < NQT; ++qt)
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
             *reinterpret_cast<f32x4*>(Ored + ((wave * NQT + qt) * 2 + jt) * 256 + lane * 4) = oacc[qt][jt];
     if (tid < NQ) {
-        const float s = (red[tid] + red[NQ + tid]) + (red[2 * NQ + tid] + red[3 * NQ + tid]);
+        const float s = (rsum[tid] + rsum[NQ + tid]) + (rsum[2 * NQ + tid] + rsum[3 * NQ + tid]);
         stat[NQ + tid] = s > 0.f ? 1.f / s : 0.f;
         if (p.lse && tid < T) p.lse[((int64_t)b * p.H + h) * T + tid] = stat[tid] + __logf(s);
     }
@@ -222,6 +262,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ick_attn_args p, int
                 if (j0 + r < dh) orow[j0 + r] = o[r] * inv;
         }
     }
+    ICK_ASTAMP(SK, 8);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -230,6 +271,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ick_attn_args p, int
 template <int NQT, int MAXT>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p, int SP, bool st2) {
     chain_priority_bwd();
+    [[maybe_unused]] constexpr int SK = MAXT > 1 ? 3 : 2;
+    ICK_ASTAMP(SK, 0);
     constexpr int NQ = NQT * 16;
     constexpr int TLD = NQ + 4;          // row stride of the transposed Q / dO tiles ([col][query])
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -257,45 +300,59 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p,
     const float* ob = p.O + (int64_t)b * p.o_bs + h * dh;
     const float* gb = p.dO + (int64_t)b * p.o_bs + h * dh;
 
-    // this wave's K / V fragments straight from global memory, requested before the staging so that they land
-    // while it runs (key tile 16 (wave + 4 i), lane <-> key li, columns 16 t + 4 lq .. +3)
+    // Every global load is requested up front in the order of its use: what the staging needs first (Q, lse, dO, O:
+    // small), then this wave's K / V fragments tile by tile -- the staging and the first key tiles run while the
+    // later fragments are still on their way (vmcnt counts in order).
+    constexpr int QIT = (NQ * 8 + 255) / 256;
+    float4 qx[QIT];
+#pragma unroll
+    for (int it = 0; it < QIT; ++it) {
+        const int f = tid + 256 * it;
+        const int t = f >> 3, c = f & 7;
+        qx[it] = *reinterpret_cast<const float4*>(qb + (int64_t)(t < T ? t : 0) * DHP + 4 * c);
+    }
+    const float lse_v = p.lse[((int64_t)b * p.H + h) * T + (tid < T ? tid : 0)];
+    float gv[NQT * 2], ov[NQT * 2];
+#pragma unroll
+    for (int it = 0; it < NQT * 2; ++it) {
+        const int f = tid + 256 * it;
+        const int t = f >> 5, j = f & 31;
+        const bool ok = t < T && j < dh;
+        const int64_t at = ok ? (int64_t)t * p.o_ts + j : 0;      // unconditional loads (masked below)
+        gv[it] = gb[at];
+        ov[it] = ob[at];
+    }
+    // key tile 16 (wave + 4 i), lane <-> key li, columns 16 t + 4 lq .. +3
     float4 kf[MAXT][2], vf[MAXT][2];
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
         const int key = 16 * (wave + 4 * i) + li;
-        const bool kok = key < S;
-        const float* kr = kb + (int64_t)(kok ? key : 0) * DHP + 4 * lq;
-        const float* vr = vb + (int64_t)(kok ? key : 0) * DHP + 4 * lq;
+        const int64_t ro = (int64_t)(key < S ? key : 0) * DHP + 4 * lq;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            kf[i][t] = mask_cols(*reinterpret_cast<const float4*>(kr + 16 * t), 16 * t + 4 * lq, kok ? dh : 0);
-            vf[i][t] = mask_cols(*reinterpret_cast<const float4*>(vr + 16 * t), 16 * t + 4 * lq, kok ? dh : 0);
+            kf[i][t] = *reinterpret_cast<const float4*>(kb + ro + 16 * t);
+            vf[i][t] = *reinterpret_cast<const float4*>(vb + ro + 16 * t);
         }
     }
-    // ---- staging: Q (row-major and transposed), dO (both), K^T, lse, D
-    for (int f = tid; f < NQ * 8; f += 256) {
-        const int t = f >> 3, c = f & 7;
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < T) x = mask_cols(*reinterpret_cast<const float4*>(qb + (int64_t)t * DHP + 4 * c), 4 * c, dh);
-        *reinterpret_cast<float4*>(Qs + t * QLD + 4 * c) = x;
-        Qt[(4 * c + 0) * TLD + t] = x.x; Qt[(4 * c + 1) * TLD + t] = x.y;
-        Qt[(4 * c + 2) * TLD + t] = x.z; Qt[(4 * c + 3) * TLD + t] = x.w;
-    }
-    const float lse_v = tid < T ? p.lse[((int64_t)b * p.H + h) * T + tid] : 0.f;
-    float gv[NQT * 2], ov[NQT * 2];
+    ICK_ASTAMP(SK, 1);
+    // ---- staging: Q (row-major and transposed), dO (both), lse, D
 #pragma unroll
-    for (int it = 0; it < NQT * 2; ++it) {   // all loads first: one memory round trip
+    for (int it = 0; it < QIT; ++it) {
         const int f = tid + 256 * it;
-        const int t = f >> 5, j = f & 31;
-        const bool ok = t < T && j < dh;
-        gv[it] = ok ? gb[(int64_t)t * p.o_ts + j] : 0.f;
-        ov[it] = ok ? ob[(int64_t)t * p.o_ts + j] : 0.f;
+        const int t = f >> 3, c = f & 7;
+        if (f < NQ * 8) {
+            const float4 x = mask_cols(qx[it], 4 * c, t < T ? dh : 0);
+            *reinterpret_cast<float4*>(Qs + t * QLD + 4 * c) = x;
+            Qt[(4 * c + 0) * TLD + t] = x.x; Qt[(4 * c + 1) * TLD + t] = x.y;
+            Qt[(4 * c + 2) * TLD + t] = x.z; Qt[(4 * c + 3) * TLD + t] = x.w;
+        }
     }
 #pragma unroll
     for (int it = 0; it < NQT * 2; ++it) {
         const int f = tid + 256 * it;
         const int t = f >> 5, j = f & 31;
-        const float g = gv[it], o = ov[it];
+        const bool ok = t < T && j < dh;
+        const float g = ok ? gv[it] : 0.f, o = ok ? ov[it] : 0.f;
         Gs[t * QLD + j] = g;
         Gt[j * TLD + t] = g;
         // D[t] = sum_j dO[t][j] O[t][j]: the 32 lanes of a row are one half wave
@@ -304,8 +361,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p,
         d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 16, 64);
         if (j == 0) Dl[t] = d;
     }
-    if (tid < NQ) Ls[tid] = lse_v;
+    if (tid < NQ) Ls[tid] = tid < T ? lse_v : 0.f;
+    ICK_ASTAMP(SK, 2);
     __syncthreads();
+    ICK_ASTAMP(SK, 3);
 
     // ---- per key tile: S, dP (lane <-> key 16 kt + li, registers <-> queries 16 qt + 4 lq + r), dV^T, dK^T
 #pragma unroll
@@ -314,6 +373,11 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p,
         if (kt >= nkt) continue;         // wave-uniform
         const int key = 16 * kt + li;
         const bool kok = key < S;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            kf[i][t] = mask_cols(kf[i][t], 16 * t + 4 * lq, kok ? dh : 0);
+            vf[i][t] = mask_cols(vf[i][t], 16 * t + 4 * lq, kok ? dh : 0);
+        }
         f32x4 dvt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         f32x4 dkt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -376,7 +440,9 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p,
             }
         }
     }
+    ICK_ASTAMP(SK, 4);
     __syncthreads();
+    ICK_ASTAMP(SK, 5);
 
     // ---- dQ = dS K: output tile (qt, jt) per wave, reduction over all keys; lane <-> column 16 jt + li.
     // A = dS rows from LDS (16-byte reads); B[k = key][n = column] comes straight from global memory (K was
@@ -413,6 +479,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p,
             }
         }
     }
+    ICK_ASTAMP(SK, 6);
 }
 
 inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -426,7 +493,7 @@ int set_lds(K kern, size_t bytes) {
 
 template <int NQT, int MAXT>
 int launch_fwd(const ick_attn_args& a, int SP, hipStream_t s) {
-    const size_t fl = std::max<size_t>((size_t)DHP * SP, 4 * NQT * 2 * 256) + (size_t)NQT * 16 * QLD + 6 * NQT * 16;
+    const size_t fl = std::max<size_t>((size_t)DHP * SP, 4 * NQT * 2 * 256) + (size_t)NQT * 16 * QLD + 10 * NQT * 16;
     if (fl * sizeof(float) > 150 * 1024) return kAttnMfmaUnsupported;
     auto kern = attn_fwd_mfma_kernel<NQT, MAXT>;
     static bool attr = false;

@@ -1,6 +1,6 @@
 """Where do the workgroups of a large GEMM spend their time?  Builds a copy of the library with -DICK_GEMM_STAMPS, runs
 one problem and prints, for the workgroups that ran on one CU, the timeline (shader-clock ticks -> us): start, first LDS
-stage ready, K loop done, end.  usage: gemm_stamps.py [M N K [split_mode]]"""
+stage ready, K loop done, end.  usage: gemm_stamps.py [M N K [split_mode [kmajor [split_k]]]]"""
 import collections
 import ctypes
 import os
@@ -22,11 +22,18 @@ from ick_amd import ops  # noqa: E402
 TICKS_PER_US = 2400.0     # s_memtime runs at the shader clock on this part (measured: a workgroup of 22 us = 54 k ticks)
 M, N, K = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (13824, 1800, 300)
 mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+km = int(sys.argv[5]) if len(sys.argv) > 5 else 0          # 1: both operands k-major (weight-gradient form)
+split_k = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 ops.set_gemm_split(mode)
-A, B = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")
-out = torch.empty(M, N, device="cuda")
-for _ in range(3):
-    ops.gemm_raw(A, B, out, M, N, K, K, 1, K, 1, N)
+out = torch.zeros(M, N, device="cuda")
+if km:
+    A, B = torch.randn(K, M, device="cuda"), torch.randn(K, N, device="cuda")
+    for _ in range(3):
+        ops.gemm_raw(A, B, out, M, N, K, 1, M, 1, N, N, atomic=True, split_k=split_k)
+else:
+    A, B = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")
+    for _ in range(3):
+        ops.gemm_raw(A, B, out, M, N, K, K, 1, K, 1, N)
 torch.cuda.synchronize()
 n = 16384
 buf = (ctypes.c_ulonglong * (8 * n))()
