@@ -114,8 +114,10 @@ constexpr uint32_t kOobOffset = 0x80000000u;   // >= any extent the vector path 
 //   k-contiguous operand: plane[row][32 k] in 64-byte rows, 16-byte chunk c of row r at chunk c ^ ((-(r >> 2)) & 3):
 //     the ds_read_b128 of the MFMA operand (lane (i, q) takes k = 8q..8q+7 of row i) is conflict-free for the four
 //     16-lane groups the LDS serves it in, and so are the ds_write_b64 of the stager;
-//   k-major operand: plane[k][rows] with (2 rows + 32)-byte k lines, stored as it arrives (ds_write_b64 of 4 rows) and
-//     read with ds_read_b64_tr_b16, the transposing read: two of them deliver the same 8-k operand.
+//   k-major operand: plane[k][rows] with (2 rows + 64)-byte k lines, stored as it arrives (ds_write_b64 of 4 rows) and
+//     read with ds_read_b64_tr_b16, the transposing read: two of them deliver the same 8-k operand.  The 16-row blocks
+//     of k lines 8-15 and 24-31 are swapped pairwise: the two 16-lane groups a transposing read serves together (k
+//     lines q and q + 8) then fall on different banks (bank search: DESIGN.md).
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -142,7 +144,7 @@ struct Stager {
     static_assert(!SPL || (VEC && BKT == 32), "split operands: vector staging, 32-k slices");
     static constexpr int CH = KM ? R / 4 : BKT / 4;  // float4 chunks along the contiguous dim
     static constexpr int LD = KM ? R + 4 : BKT + 4;
-    static constexpr int KLINE = 2 * R + 32;         // SPL, k-major: bytes per k line of a plane
+    static constexpr int KLINE = 2 * R + 64;         // SPL, k-major: bytes per k line of a plane
     static constexpr int PLANE = KM ? BKT * KLINE : R * 64;   // SPL: bytes per bf16 plane
     static constexpr int FLOATS = SPL ? 3 * PLANE / 4 : (KM ? BKT * LD : R * LD);
     static constexpr int KP = NT / CH;               // k-major: k lines covered per pass
@@ -252,7 +254,8 @@ struct Stager {
                     uint32_t h0, m0, l0, h1, m1, l1;
                     split3(x.x, x.y, h0, m0, l0);
                     split3(x.z, x.w, h1, m1, l1);
-                    char* at = reinterpret_cast<char*>(lds) + (r0 + KP * j) * KLINE + 8 * c;
+                    const int kl = r0 + KP * j;
+                    char* at = reinterpret_cast<char*>(lds) + kl * KLINE + 8 * (c ^ (((kl >> 3) & 1) << 2));
                     *reinterpret_cast<uint2*>(at) = uint2{h0, h1};
                     *reinterpret_cast<uint2*>(at + PLANE) = uint2{m0, m1};
                     *reinterpret_cast<uint2*>(at + 2 * PLANE) = uint2{l0, l1};
@@ -306,8 +309,8 @@ template <int R, bool KM>
 __device__ __forceinline__ void read_frag_spl(const float* lds, int row0, int i, int q, bf16x8_t (&f)[3]) {
     const char* base = reinterpret_cast<const char*>(lds);
     if constexpr (KM) {
-        constexpr int KLINE = 2 * R + 32, PLANE = 32 * KLINE;
-        const char* at = base + (8 * q + (i >> 2)) * KLINE + (row0 + 4 * (i & 3)) * 2;
+        constexpr int KLINE = 2 * R + 64, PLANE = 32 * KLINE;
+        const char* at = base + (8 * q + (i >> 2)) * KLINE + ((row0 ^ ((q & 1) << 4)) + 4 * (i & 3)) * 2;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const s16x4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(at + p * PLANE));
@@ -809,13 +812,13 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
     }
     pl.spl = pl.vec && pl.big && (gemm_split_mode() == 2 || (gemm_split_mode() == 1 && !bkm));
     pl.xl = false;
-    if (pl.spl && split_req == 1) {
+    if (pl.spl) {
         // 128 x 128 tiles: twice the products per staged (and split) element.  One workgroup per CU (98 KB of LDS), so
         // the problem must bring several rounds of tiles and waste little of its last tile column
         static int forced = -2;
         if (forced == -2) { const char* e = getenv("ICK_GEMM_XL"); forced = e ? atoi(e) : -1; }
         const int64_t t128 = (int64_t)ceil_div(a.M, 128) * ceil_div(a.N, 128);
-        const bool fits = a.M >= 128 && a.N >= 128 && t128 >= 512 && ceil_div(a.N, 128) * 128 <= a.N + a.N / 8;
+        const bool fits = split_req == 1 && a.M >= 128 && a.N >= 128 && t128 >= 512 && ceil_div(a.N, 128) * 128 <= a.N + a.N / 8;
         pl.xl = forced < 0 ? fits : (forced > 0 && a.M >= 128 && a.N >= 128);
         if (pl.xl) pl.wide = true;
     }

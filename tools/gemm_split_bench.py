@@ -56,6 +56,12 @@ shapes = [("conv1 12544x300x2048 A k-major   ", 12544, 300, 2048, True, False, 1
           ("K/V wgrad 600x300x13824 split16  ", 600, 300, 13824, True, True, 16),
           ("K/V cfg4 25000x1800x300          ", 25088, 1800, 300, False, False, 1),
           ("square 4096x4096x2048            ", 4096, 4096, 2048, False, False, 1)]
+if os.environ.get("WGRAD_ONLY"):
+    sk = int(os.environ.get("WGRAD_SPLIT", "0"))
+    shapes = [("vocab wgrad 10000x300x1280 ", 10000, 300, 1280, True, True, sk or 2),
+              ("K/V wgrad 600x300x13824    ", 600, 300, 13824, True, True, sk or 16),
+              ("linear1 wgrad 1024x300x1280", 1024, 300, 1280, True, True, sk or 2),
+              ("vocab dgrad 1280x300x10000 ", 1280, 300, 10000, False, True, sk or 9)]
 for s in shapes:
     run(*s)
 ops.set_gemm_split(0)
