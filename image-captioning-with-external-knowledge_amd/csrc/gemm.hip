@@ -343,7 +343,7 @@ __device__ __forceinline__ bool split_major(int& bid, int& zid, int nt, int nspl
 }
 
 // One output tile: workgroup `bid` of the tiles_m x tiles_n grid of problem p, K slice `zid`.
-template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT, bool SPL = false>
+template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT, bool SPL = false, int LSTG = 2>
 __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, int tiles_n, int kchunk, int bid,
                                           int zid, float* smem, bool xcd_remap = true) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -411,31 +411,35 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
     ICK_GSTAMP(1);
     auto phase = [&](int it, auto cur) {
         constexpr int CUR = decltype(cur)::value, NXT = 1 - CUR;
-        const float* As = smem + CUR * STAGE;
+        // LSTG = 1: one LDS buffer (a second workgroup on the CU overlaps its phases with ours instead of a second
+        // buffer); the register sets still hold two slices in flight
+        const float* As = smem + (LSTG == 2 ? CUR * STAGE : 0);
         const float* Bs = As + SA::FLOATS;
         const int k0 = kbeg + it * BK;
         if (it + 2 < nk) { sa.template load<CUR>(k0 + 2 * BK, kend); if (!only) sb.template load<CUR>(k0 + 2 * BK, kend); }
         if constexpr (SPL) {
             if (!only) {
-                // one 16x16x32 block per tile and slice, six bf16 products (smallest first)
-                bf16x8_t af[TM][3], bf[TN][3];
+                // one 16x16x32 block per tile and slice, six bf16 products (smallest first); the B fragments of one
+                // tile column at a time (a 64 x 64 wave tile would hold 96 fragment registers otherwise)
+                bf16x8_t af[TM][3];
 #pragma unroll
                 for (int a = 0; a < TM; ++a) read_frag_spl<BM, AKM>(As, (wm * TM + a) * 16, fi, fq, af[a]);
 #pragma unroll
-                for (int b = 0; b < TN; ++b) read_frag_spl<BN, BKM>(Bs, (wn * TN + b) * 16, fi, fq, bf[b]);
+                for (int b = 0; b < TN; ++b) {
+                    bf16x8_t bf[3];
+                    read_frag_spl<BN, BKM>(Bs, (wn * TN + b) * 16, fi, fq, bf);
 #pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int b = 0; b < TN; ++b) {
+                    for (int a = 0; a < TM; ++a) {
                         f32x4 c = acc[a][b];
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[b][2], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][2], bf[b][0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][1], bf[b][1], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[b][1], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][1], bf[b][0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[b][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][2], bf[0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][1], bf[1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][1], bf[0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[0], c, 0, 0, 0);
                         acc[a][b] = c;
                     }
+                }
             }
         }
         const int nchunk = (only || SPL) ? 0 : min(BK / 16, (kend - k0 + 15) >> 4);
@@ -461,8 +465,9 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
                 for (int k = 0; k < BK; ++k) csum += As[k * SA::LD + threadIdx.x];
             }
         }
+        if constexpr (LSTG == 1) __syncthreads();      // every wave is done with the slice in LDS
         if (it + 1 < nk) {
-            float* An = smem + NXT * STAGE;
+            float* An = smem + (LSTG == 2 ? NXT * STAGE : 0);
             sa.template store<NXT>(An, k0 + BK, kend);
             if (!only) sb.template store<NXT>(An + SA::FLOATS, k0 + BK, kend);
         }
@@ -591,14 +596,14 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
     ICK_GSTAMP(3);
 }
 
-template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT, bool SPL>
+template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, int BKT, bool SPL, int LSTG = 2>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(ick_gemm_args p, int tiles_m, int tiles_n, int kchunk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if constexpr (TM == 1) chain_priority();     // 32 x 32 tiles: the chain GEMMs (single launches, not the grouped weight gradients)
     const int nt = tiles_m * tiles_n;
     int bid = blockIdx.x, zid = blockIdx.z;
     const bool by_split = split_major(bid, zid, nt, gridDim.z);
-    gemm_tile<WM, WN, TM, TN, AKM, BKM, VEC, BKT, SPL>(p, tiles_m, tiles_n, kchunk, bid, zid, smem, !by_split);
+    gemm_tile<WM, WN, TM, TN, AKM, BKM, VEC, BKT, SPL, LSTG>(p, tiles_m, tiles_n, kchunk, bid, zid, smem, !by_split);
 }
 
 // Several independent problems of the same kernel configuration in one launch (the weight-gradient GEMMs of a
@@ -649,25 +654,25 @@ inline size_t lds_floor(int which) {
     return (size_t)v[which];
 }
 
-template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, bool SPL>
+template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, bool SPL, int LSTG = 2>
 int launch_tile_s(const Plan& pl, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = WM * WN * 64;
     constexpr int STAGE = Stager<BM, AKM, VEC, 32, NT, SPL>::FLOATS + Stager<BN, BKM, VEC, 32, NT, SPL>::FLOATS;
-    constexpr size_t smem = 2 * STAGE * sizeof(float);
+    constexpr size_t smem = LSTG * STAGE * sizeof(float);
     static_assert(smem <= 160 * 1024, "tile exceeds the LDS of a CU");
     const size_t lds = (TM > 1) ? std::max(smem, lds_floor(0)) : smem;
     if (lds > 64 * 1024) {
         static bool attr = false;
         if (!attr) {
             hipError_t e = hipFuncSetAttribute(
-                reinterpret_cast<const void*>(gemm_kernel<WM, WN, TM, TN, AKM, BKM, VEC, 32, SPL>),
+                reinterpret_cast<const void*>(gemm_kernel<WM, WN, TM, TN, AKM, BKM, VEC, 32, SPL, LSTG>),
                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
             attr = true;
         }
     }
     const int gx = pl.tiles_m * pl.tiles_n;
-    hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, AKM, BKM, VEC, 32, SPL>), dim3(gx, 1, pl.split),
+    hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, AKM, BKM, VEC, 32, SPL, LSTG>), dim3(gx, 1, pl.split),
                        dim3(NT), lds, s, pl.a, pl.tiles_m, pl.tiles_n, pl.kchunk);
     ICK_LAUNCH_RET();
 }
@@ -684,6 +689,9 @@ template <int TM, int TN, bool AKM, bool BKM, bool VEC>
 int launch_wide(const Plan& pl, hipStream_t s) { return launch_tile<4, 2, TM, TN, AKM, BKM, VEC>(pl, s); }   // 8 waves
 template <int TM, int TN, bool AKM, bool BKM, bool VEC>
 int launch_xl(const Plan& pl, hipStream_t s) { return launch_tile_s<4, 2, TM, TN, AKM, BKM, VEC, true>(pl, s); }
+// 128 x 128, four waves of 64 x 64, one LDS buffer: two workgroups per CU
+template <int TM, int TN, bool AKM, bool BKM, bool VEC>
+int launch_xl4(const Plan& pl, hipStream_t s) { return launch_tile_s<2, 2, TM, TN, AKM, BKM, VEC, true, 1>(pl, s); }
 
 template <int TM, int TN, bool AKM, bool BKM, bool SPL>
 int launch_group_s(const Plan* const* pls, int n, hipStream_t s) {
@@ -841,7 +849,14 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
 
 int launch_plan(const Plan& pl, hipStream_t s) {
     if (!pl.vec) ICK_BY_LAYOUT(launch_one, 2, 2, ICK_COMMA_FALSE, pl, s);
-    if (pl.xl) ICK_BY_LAYOUT(launch_xl, 2, 4, ICK_COMMA_TRUE, pl, s);
+    if (pl.xl) {
+        // four waves of 64 x 64 and one LDS buffer (two workgroups per CU overlap their phases) unless ICK_GEMM_XL4=0
+        // (eight waves, two buffers, one workgroup per CU): cross K/V 140 -> 128 us, train step 1.867 -> 1.839 ms
+        static int four = -1;
+        if (four < 0) { const char* e = getenv("ICK_GEMM_XL4"); four = e ? atoi(e) : 1; }
+        if (four) ICK_BY_LAYOUT(launch_xl4, 4, 4, ICK_COMMA_TRUE, pl, s);
+        ICK_BY_LAYOUT(launch_xl, 2, 4, ICK_COMMA_TRUE, pl, s);
+    }
     if (pl.wide) ICK_BY_LAYOUT(launch_wide, 2, 2, ICK_COMMA_TRUE, pl, s);
     if (pl.big) ICK_BY_LAYOUT(launch_one, 2, 2, ICK_COMMA_TRUE, pl, s);
     ICK_BY_LAYOUT(launch_one, 1, 1, ICK_COMMA_TRUE, pl, s);
@@ -869,7 +884,7 @@ extern "C" int ick_gemm_plan(const ick_gemm_args* in, ick_gemm_plan_info* out) {
     Plan pl;
     if (int rc = make_plan(in, pl)) return rc;
     const int bmn = pl.big ? 64 : 32;
-    out->tile_m = pl.wide ? 128 : bmn; out->tile_n = pl.xl ? 128 : bmn; out->waves = pl.wide ? 8 : 4;
+    out->tile_m = pl.wide ? 128 : bmn; out->tile_n = pl.xl ? 128 : bmn; out->waves = pl.wide ? 8 : 4;   // (xl: 4 or 8, ICK_GEMM_XL4)
     out->tiles_m = pl.tiles_m; out->tiles_n = pl.tiles_n; out->split_k = pl.split;
     out->a_kmajor = pl.akm; out->b_kmajor = pl.bkm; out->vec = pl.vec;
     out->split_bf16 = pl.spl;
