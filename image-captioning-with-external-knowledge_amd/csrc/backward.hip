@@ -544,6 +544,46 @@ __global__ __launch_bounds__(256) void adam_clamp_kernel(float* __restrict__ p, 
     }
 }
 
+// The same update on float4: seven 16-byte streams per lane (the scalar form reaches 0.66 of the HBM rate, 320 MB per
+// cfg2 step).  n4 = n / 4 elements of float4; the launcher sends a tail of n % 4 to the scalar kernel.
+__global__ __launch_bounds__(256) void adam_clamp_vec4_kernel(float4* __restrict__ p, float4* __restrict__ g,
+                                                              float4* __restrict__ m, float4* __restrict__ v, int64_t n4,
+                                                              float gscale, float clip, float lr, float b1, float b2,
+                                                              float eps, int step0, const uint32_t* step_ptr,
+                                                              const float* __restrict__ gscale_den) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    if (gscale_den) {
+        if (!(gscale_den[0] > 0.f)) return;
+        gscale = gscale / gscale_den[0];
+    }
+    const float t = (float)(step0 + (step_ptr ? (int)*step_ptr : 0));
+    const float bc1 = 1.f - powf(b1, t);
+    const float bc2_sqrt = sqrtf(1.f - powf(b2, t));
+    const float step = lr / bc1;
+    const float c1 = 1.f - b1, c2 = 1.f - b2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 gi = g[i];
+        const float4 mo = m[i], vo = v[i];
+        float4 pi = p[i];
+        float ga[4] = {gi.x, gi.y, gi.z, gi.w};
+        const float ma[4] = {mo.x, mo.y, mo.z, mo.w}, va[4] = {vo.x, vo.y, vo.z, vo.w};
+        float pa[4] = {pi.x, pi.y, pi.z, pi.w}, mn[4], vn[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {      // the arithmetic of adam_clamp_kernel, operation for operation
+            float x = ga[k] * gscale;
+            if (clip > 0.f) x = fminf(fmaxf(x, -clip), clip);
+            ga[k] = x;
+            mn[k] = b1 * ma[k] + c1 * x;
+            vn[k] = b2 * va[k] + c2 * x * x;
+            pa[k] -= step * mn[k] / (sqrtf(vn[k]) / bc2_sqrt + eps);
+        }
+        g[i] = make_float4(ga[0], ga[1], ga[2], ga[3]);
+        m[i] = make_float4(mn[0], mn[1], mn[2], mn[3]);
+        v[i] = make_float4(vn[0], vn[1], vn[2], vn[3]);
+        p[i] = make_float4(pa[0], pa[1], pa[2], pa[3]);
+    }
+}
+
 __global__ void counter_add_kernel(uint32_t* c, uint32_t inc) { *c += inc; }
 
 __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, int64_t n, const float* __restrict__ num,
@@ -682,8 +722,20 @@ extern "C" int ick_adam_clamp(float* p, float* g, float* m, float* v, int64_t n,
                               float beta1, float beta2, float eps, int32_t step, const uint32_t* step_ptr,
                               const float* gscale_den, void* stream) {
     ICK_CHECK_ARG(p && g && m && v && n > 0 && (step >= 1 || step_ptr != nullptr));
-    hipLaunchKernelGGL(adam_clamp_kernel, dim3((int)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0,
-                       (hipStream_t)stream, p, g, m, v, n, gscale, clip, lr, beta1, beta2, eps, step, step_ptr, gscale_den);
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    int64_t done = 0;
+    if (n >= 4096 && al16(p) && al16(g) && al16(m) && al16(v)) {
+        const int64_t n4 = n / 4;
+        hipLaunchKernelGGL(adam_clamp_vec4_kernel, dim3((int)std::min<int64_t>(ceil_div(n4, 256), 4096)), dim3(256), 0,
+                           (hipStream_t)stream, reinterpret_cast<float4*>(p), reinterpret_cast<float4*>(g),
+                           reinterpret_cast<float4*>(m), reinterpret_cast<float4*>(v), n4, gscale, clip, lr, beta1, beta2,
+                           eps, step, step_ptr, gscale_den);
+        done = 4 * n4;
+        if (done == n) ICK_LAUNCH_RET();
+    }
+    hipLaunchKernelGGL(adam_clamp_kernel, dim3((int)std::min<int64_t>(ceil_div(n - done, 256), 4096)), dim3(256), 0,
+                       (hipStream_t)stream, p + done, g + done, m + done, v + done, n - done, gscale, clip, lr, beta1,
+                       beta2, eps, step, step_ptr, gscale_den);
     ICK_LAUNCH_RET();
 }
 
