@@ -50,6 +50,8 @@ __device__ __forceinline__ float4 mask_cols(float4 x, int c0, int dh) {
     return x;
 }
 
+__device__ __forceinline__ int wave_id_of(unsigned tid) { return __builtin_amdgcn_readfirstlane((int)(tid >> 6)); }
+
 __device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& b, f32x4 c) {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
@@ -287,6 +289,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p,
     float* Gt = Qt + DHP * TLD;          // DHP * TLD
     float* Ls = Gt + DHP * TLD;          // NQ  lse
     float* Dl = Ls + NQ;                 // NQ  rowsum(dO * O)
+    float* Kw = Dl + NQ + (wave_id_of(threadIdx.x)) * (16 * QLD);   // 4 x 16 x QLD: this wave's current key tile of K
+    float* dQp = Qs;                     // after the key-tile loop: the waves' partial dQ tiles (4 x NQT x 2 x 256)
 
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -366,7 +370,14 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p,
     __syncthreads();
     ICK_ASTAMP(SK, 3);
 
-    // ---- per key tile: S, dP (lane <-> key 16 kt + li, registers <-> queries 16 qt + 4 lq + r), dV^T, dK^T
+    // ---- per key tile: S, dP (lane <-> key 16 kt + li, registers <-> queries 16 qt + 4 lq + r), dV^T, dK^T, and this
+    // tile's share of dQ = dS K (A = the dS rows the wave has just written to LDS, B = its K rows through the wave's
+    // scratch; lane <-> column 16 jt + li, registers <-> queries): the four waves' partial tiles are summed at the end
+    f32x4 dq[NQT][2];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) dq[qt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
         const int kt = wave + 4 * i;
@@ -378,6 +389,9 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p,
             kf[i][t] = mask_cols(kf[i][t], 16 * t + 4 * lq, kok ? dh : 0);
             vf[i][t] = mask_cols(vf[i][t], 16 * t + 4 * lq, kok ? dh : 0);
         }
+        // K rows of this tile for the dQ product below (B operand: k = key, n = column): through the wave's scratch
+#pragma unroll
+        for (int t = 0; t < 2; ++t) *reinterpret_cast<float4*>(Kw + li * QLD + 16 * t + 4 * lq) = kf[i][t];
         f32x4 dvt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         f32x4 dkt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -415,6 +429,25 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p,
                 dkt[jt] = mfma4(qt4, df, dkt[jt]);
             }
         }
+        // dQ += dS(tile) K(tile).  The dS rows and the K scratch were written by other lanes of this wave: LDS
+        // operations of one wave execute in order, the fence keeps the compiler from moving the reads up
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {
+            float4 kq[2];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const float* kc = Kw + (4 * lq) * QLD + 16 * jt + li;
+                kq[jt] = make_float4(kc[0], kc[QLD], kc[2 * QLD], kc[3 * QLD]);
+            }
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt) {
+                const float4 da = *reinterpret_cast<const float4*>(dSs + (16 * qt + li) * SP + 16 * kt + 4 * lq);
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) dq[qt][jt] = mfma4(da, kq[jt], dq[qt][jt]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();     // the next tile overwrites the scratch
         // dV^T / dK^T tiles: lane <-> key, registers <-> columns 16 jt + 4 lq + r (4 consecutive floats of a row):
         // two 8-byte stores per tile where the layout allows (row-major gradients at even offsets), else scalars
         if (kok) {
@@ -441,37 +474,22 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p,
         }
     }
     ICK_ASTAMP(SK, 4);
-    __syncthreads();
+    __syncthreads();                     // every wave is done with Q / dO in LDS: their space takes the partial dQ tiles
     ICK_ASTAMP(SK, 5);
-
-    // ---- dQ = dS K: output tile (qt, jt) per wave, reduction over all keys; lane <-> column 16 jt + li.
-    // A = dS rows from LDS (16-byte reads); B[k = key][n = column] comes straight from global memory (K was
-    // read a moment ago: L2 hits; 16 lanes cover 64 contiguous bytes of a key row) -- keeping a K^T copy in LDS
-    // instead would cost 29 KB and the third workgroup per CU.
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+            *reinterpret_cast<f32x4*>(dQp + ((wave * NQT + qt) * 2 + jt) * 256 + lane * 4) = dq[qt][jt];
+    __syncthreads();
+    // combine the four partial tiles and store: tile (qt, jt), lane <-> column 16 jt + li, registers <-> queries 4 lq + r
     for (int tt = wave; tt < NQT * 2; tt += 4) {
         const int qt = tt >> 1, jt = tt & 1;
         const int j = 16 * jt + li;
-        const bool jok = j < dh;
-        const float* kc = kb + (jok ? j : 0);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        // all K values of this lane's column first (one round trip to L2 instead of one per pair of key tiles)
-        float4 kq[4 * MAXT];
 #pragma unroll
-        for (int kt = 0; kt < 4 * MAXT; ++kt) {
-            const int k0 = 16 * kt + 4 * lq;
-            kq[kt].x = (jok && k0 + 0 < S) ? kc[(int64_t)(k0 + 0) * DHP] : 0.f;
-            kq[kt].y = (jok && k0 + 1 < S) ? kc[(int64_t)(k0 + 1) * DHP] : 0.f;
-            kq[kt].z = (jok && k0 + 2 < S) ? kc[(int64_t)(k0 + 2) * DHP] : 0.f;
-            kq[kt].w = (jok && k0 + 3 < S) ? kc[(int64_t)(k0 + 3) * DHP] : 0.f;
-        }
-#pragma unroll
-        for (int kt = 0; kt < 4 * MAXT; ++kt) {
-            if (kt < nkt) {
-                const float4 da = *reinterpret_cast<const float4*>(dSs + (16 * qt + li) * SP + 16 * kt + 4 * lq);
-                acc = mfma4(da, kq[kt], acc);
-            }
-        }
-        if (jok) {
+        for (int w = 0; w < 4; ++w) acc += *reinterpret_cast<const f32x4*>(dQp + ((w * NQT + qt) * 2 + jt) * 256 + lane * 4);
+        if (j < dh) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int query = 16 * qt + 4 * lq + r;
@@ -507,7 +525,9 @@ int launch_bwd(const ick_attn_bwd_args& a, int SP, hipStream_t s) {
     constexpr int NQ = NQT * 16;
     const size_t tr = (size_t)((a.T + 3) & ~3);
     // the dQ phase reads NQ "rows" of dS: the allocation covers that extent even though only tr rows are written
-    const size_t fl = std::max(tr * SP + 2 * (size_t)NQ * QLD + 2 * (size_t)DHP * (NQ + 4) + 2 * NQ, (size_t)NQ * SP);
+    // (+ the four waves' K scratch; the partial dQ tiles reuse the Q / dO space: 2048 NQT <= 2176 NQT + 256 floats)
+    const size_t fl = std::max(tr * SP + 2 * (size_t)NQ * QLD + 2 * (size_t)DHP * (NQ + 4) + 2 * NQ + 4 * 16 * QLD,
+                               (size_t)NQ * SP + 64);
     if (fl * sizeof(float) > 150 * 1024) return kAttnMfmaUnsupported;
     auto kern = attn_bwd_mfma_kernel<NQT, MAXT>;
     static bool attr = false;
@@ -525,7 +545,7 @@ bool attn_mfma_shape_ok(int T, int S, int dh) {
     if (!(T >= 2 && T <= 64 && S >= 1 && S <= 512 && dh <= DHP)) return false;
     // the backward keeps dS ([query][key]) in LDS
     const size_t nq = (size_t)((T + 15) / 16) * 16, sp = (size_t)((S + 15) / 16) * 16 + 4, tr = (size_t)((T + 3) & ~3);
-    return std::max(tr * sp + 2 * nq * QLD + 2 * DHP * (nq + 4) + 2 * nq, nq * sp) * sizeof(float) <= 150 * 1024;
+    return std::max(tr * sp + 2 * nq * QLD + 2 * DHP * (nq + 4) + 2 * nq + 4 * 16 * QLD, nq * sp + 64) * sizeof(float) <= 150 * 1024;
 }
 
 int launch_attn_mfma(const ick_attn_args& a, hipStream_t s) {

@@ -37,9 +37,9 @@ lib = ctypes.CDLL(dbg)
 assert lib.ick_debug_read_attn_stamps(buf) == 0
 FWD = ["loads issued + Q staged", "barrier", "-", "S^T + row max", "V^T staged + barrier", "exp + P V", "barrier",
        "combine + store"]
-names = {0: ("self fwd", FWD), 1: ("cross fwd", FWD),
-BWD = ["all loads issued", "Q, dO, lse, D staged", "barrier", "S, dP, dS, dV, dK per key tile", "barrier", "dQ"]
-names.update({2: ("self bwd", BWD), 3: ("cross bwd", BWD)})
+BWD = ["all loads issued", "Q, dO, lse, D staged", "barrier", "S, dP, dS, dV, dK, dQ share per key tile", "barrier",
+       "partial dQ tiles summed + stored"]
+names = {0: ("self fwd", FWD), 1: ("cross fwd", FWD), 2: ("self bwd", BWD), 3: ("cross bwd", BWD)}
 for k, (nm, ph) in names.items():
     t = [buf[k * 16 + i] for i in range(len(ph) + 1)]
     print("%-10s total %6.2f us: " % (nm, (t[-1] - t[0]) / 2400.0) +
