@@ -136,6 +136,17 @@ __device__ __forceinline__ void split3(float a, float b, uint32_t& hi, uint32_t&
     lo = pack_bf16(sa, sb);
 }
 __device__ __forceinline__ int kc_swz(int row) { return (-(row >> 2)) & 3; }
+// k-major planes (bank search): 64-row tiles take (2 R + 64)-byte k lines and swap neighbouring 16-row
+// blocks in k lines 8-15 / 24-31; 128-row tiles take (2 R + 32)-byte k lines (the 128 x 64 tile of Encoder.conv1 then
+// needs exactly 80 KB: two workgroups per CU) and swap blocks four apart.  kmajor_swap = log2 of the swap distance in
+// 4-row units.
+constexpr int kmajor_kline(int R) { return R >= 128 ? 2 * R + 32 : 2 * R + 64; }
+constexpr int kmajor_swap(int R) { return R >= 128 ? 4 : 2; }
+#ifdef ICK_KM_NOSWAP   // A/B: no block swap (k lines q and q + 8 of a transposing read then share banks)
+constexpr int kKmSwapOn = 0;
+#else
+constexpr int kKmSwapOn = 1;
+#endif
 
 template <int R, bool KM, bool VEC, int BKT, int NT = 256, bool SPL = false>
 struct Stager {
@@ -144,7 +155,7 @@ struct Stager {
     static_assert(!SPL || (VEC && BKT == 32), "split operands: vector staging, 32-k slices");
     static constexpr int CH = KM ? R / 4 : BKT / 4;  // float4 chunks along the contiguous dim
     static constexpr int LD = KM ? R + 4 : BKT + 4;
-    static constexpr int KLINE = 2 * R + 64;         // SPL, k-major: bytes per k line of a plane
+    static constexpr int KLINE = kmajor_kline(R);    // SPL, k-major: bytes per k line of a plane
     static constexpr int PLANE = KM ? BKT * KLINE : R * 64;   // SPL: bytes per bf16 plane
     static constexpr int FLOATS = SPL ? 3 * PLANE / 4 : (KM ? BKT * LD : R * LD);
     static constexpr int KP = NT / CH;               // k-major: k lines covered per pass
@@ -255,7 +266,7 @@ struct Stager {
                     split3(x.x, x.y, h0, m0, l0);
                     split3(x.z, x.w, h1, m1, l1);
                     const int kl = r0 + KP * j;
-                    char* at = reinterpret_cast<char*>(lds) + kl * KLINE + 8 * (c ^ (((kl >> 3) & 1) << 2));
+                    char* at = reinterpret_cast<char*>(lds) + kl * KLINE + 8 * (c ^ ((kKmSwapOn * ((kl >> 3) & 1)) << kmajor_swap(R)));
                     *reinterpret_cast<uint2*>(at) = uint2{h0, h1};
                     *reinterpret_cast<uint2*>(at + PLANE) = uint2{m0, m1};
                     *reinterpret_cast<uint2*>(at + 2 * PLANE) = uint2{l0, l1};
@@ -309,8 +320,8 @@ template <int R, bool KM>
 __device__ __forceinline__ void read_frag_spl(const float* lds, int row0, int i, int q, bf16x8_t (&f)[3]) {
     const char* base = reinterpret_cast<const char*>(lds);
     if constexpr (KM) {
-        constexpr int KLINE = 2 * R + 64, PLANE = 32 * KLINE;
-        const char* at = base + (8 * q + (i >> 2)) * KLINE + ((row0 ^ ((q & 1) << 4)) + 4 * (i & 3)) * 2;
+        constexpr int KLINE = kmajor_kline(R), PLANE = 32 * KLINE;
+        const char* at = base + (8 * q + (i >> 2)) * KLINE + ((row0 ^ ((kKmSwapOn * (q & 1)) << (kmajor_swap(R) + 2))) + 4 * (i & 3)) * 2;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const s16x4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(at + p * PLANE));
@@ -419,25 +430,48 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
         if (it + 2 < nk) { sa.template load<CUR>(k0 + 2 * BK, kend); if (!only) sb.template load<CUR>(k0 + 2 * BK, kend); }
         if constexpr (SPL) {
             if (!only) {
-                // one 16x16x32 block per tile and slice, six bf16 products (smallest first); the B fragments of one
-                // tile column at a time (a 64 x 64 wave tile would hold 96 fragment registers otherwise)
+                // one 16x16x32 block per tile and slice, six bf16 products (smallest first)
                 bf16x8_t af[TM][3];
 #pragma unroll
                 for (int a = 0; a < TM; ++a) read_frag_spl<BM, AKM>(As, (wm * TM + a) * 16, fi, fq, af[a]);
+                if constexpr (TM * TN <= 8) {
+                    // every fragment is requested before the first MFMA (reading B column by column exposes the LDS
+                    // latency once per column: Encoder.conv1 115 -> 148 us)
+                    bf16x8_t bf[TN][3];
 #pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    bf16x8_t bf[3];
-                    read_frag_spl<BN, BKM>(Bs, (wn * TN + b) * 16, fi, fq, bf);
+                    for (int b = 0; b < TN; ++b) read_frag_spl<BN, BKM>(Bs, (wn * TN + b) * 16, fi, fq, bf[b]);
 #pragma unroll
-                    for (int a = 0; a < TM; ++a) {
-                        f32x4 c = acc[a][b];
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[2], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][2], bf[0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][1], bf[1], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[1], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][1], bf[0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[0], c, 0, 0, 0);
-                        acc[a][b] = c;
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) {
+                            f32x4 c = acc[a][b];
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[b][2], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][2], bf[b][0], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][1], bf[b][1], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[b][1], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][1], bf[b][0], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[b][0], c, 0, 0, 0);
+                            acc[a][b] = c;
+                        }
+                } else {
+                    // 64 x 64 wave tile: the B fragments of one tile column at a time, the next column requested
+                    // before the MFMAs of this one (96 fragment registers otherwise)
+                    bf16x8_t bf[2][3];
+                    read_frag_spl<BN, BKM>(Bs, (wn * TN) * 16, fi, fq, bf[0]);
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        if (b + 1 < TN) read_frag_spl<BN, BKM>(Bs, (wn * TN + b + 1) * 16, fi, fq, bf[(b + 1) & 1]);
+#pragma unroll
+                        for (int a = 0; a < TM; ++a) {
+                            f32x4 c = acc[a][b];
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[b & 1][2], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][2], bf[b & 1][0], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][1], bf[b & 1][1], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[b & 1][1], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][1], bf[b & 1][0], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[b & 1][0], c, 0, 0, 0);
+                            acc[a][b] = c;
+                        }
                     }
                 }
             }
