@@ -271,7 +271,17 @@ __global__ __launch_bounds__(512) void pack_weights_kernel(PackBatch pb) {
         }
     }
     __syncthreads();
-    {   // out: thread (k4 = tid / 64, column l = tid % 64) writes one float4
+    if (m.dst_rs > 0) {   // plain copy: thread (row r = tid / 8, 4 floats along k)
+        const int r = threadIdx.x >> 3, q = threadIdx.x & 7;
+        const int n = slab * 64 + r;
+        if (n < m.N) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = kt * 32 + 4 * q + e;
+                if (k < m.K) m.dst[(int64_t)n * m.dst_rs + k] = tile[r][4 * q + e];
+            }
+        }
+    } else {   // out: thread (k4 = tid / 64, column l = tid % 64) writes one float4
         const int j = threadIdx.x >> 6, l = threadIdx.x & 63;
         const int k4 = kt * 8 + j;
         if (4 * k4 < K16) {
@@ -298,7 +308,8 @@ extern "C" int ick_pack_weights(const ick_pack_item* items, int32_t count, void*
     for (int i = 0; i < count; ++i) {
         const ick_pack_item& m = items[i];
         if (!m.src || !m.dst || m.N <= 0 || m.K <= 0 || m.src_rs <= 0 || m.src_cs <= 0) return ICK_EINVAL;
-        if (reinterpret_cast<uintptr_t>(m.dst) & 15) return ICK_EALIGN;
+        if (m.dst_rs < 0 || (m.dst_rs > 0 && m.dst_rs < m.K)) return ICK_EINVAL;
+        if (m.dst_rs == 0 && (reinterpret_cast<uintptr_t>(m.dst) & 15)) return ICK_EALIGN;
         pb.it[i] = m;
         total += ((m.N + 63) / 64) * ((((m.K + 15) & ~15) + 31) / 32);
         pb.tile_end[i] = total;

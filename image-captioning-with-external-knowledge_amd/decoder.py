@@ -384,14 +384,15 @@ class DecoderTransformer(nn.Module):
             items.append(((key[0], key[1], key[2] + "T"), w.t()))
         return items
 
-    def _chain_pack(self, fresh=False, bwd=False, subset=None, extra=None):
+    def _chain_pack(self, fresh=False, bwd=False, subset=None, extra=None, copies=()):
         """Packed copies (ops.pack_weights) of the weights the row-chain launches read, as {key: tensor} views of one
         persistent buffer (bwd: of the transposed weights, for the data-gradient chains).  Refreshed when a parameter's
         version changed, or on every call with fresh=True (inside the captured training step, where the fused Adam
         updates the weights behind torch's version counters); then `subset` (a predicate on the item key) limits the
         launch to the copies the caller needs first -- the rest follows in a later call.  extra: (key, 2-D view) of
         per-call tensors packed in the same launch into persistent buffers of their own (the transposed all-layer cross
-        K/V weight of the backward pass); their copies are returned under `key`."""
+        K/V weight of the backward pass); their copies are returned under `key`.  copies: plain (src, dst) 2-D copies
+        that ride in the same launch (only with fresh=True)."""
         items = self._chain_items_bwd() if bwd else self._chain_items()
         name = "_chain_cache_bwd" if bwd else "_chain_cache"
         cache = self.__dict__.get(name)
@@ -412,10 +413,11 @@ class DecoderTransformer(nn.Module):
             if buf is None or buf.numel() != n or buf.device != w.device:
                 buf = cache["extra"][k] = torch.empty(n, device=w.device, dtype=torch.float32)
             more.append((w.detach(), buf))
+        assert not copies or fresh
         if fresh and subset is not None:
-            ops.pack_weights([(w.detach(), cache["views"][k]) for k, w in items if subset(k)] + more)
+            ops.pack_weights([(w.detach(), cache["views"][k]) for k, w in items if subset(k)] + more, copies)
         elif fresh or cache["key"] != key:
-            ops.pack_weights([(w.detach(), cache["views"][k]) for k, w in items] + more)
+            ops.pack_weights([(w.detach(), cache["views"][k]) for k, w in items] + more, copies)
             cache["key"] = key
         elif more:
             ops.pack_weights(more)

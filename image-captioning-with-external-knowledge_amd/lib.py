@@ -72,7 +72,7 @@ class RowChainBwdArgs(C.Structure):
 
 
 class PackItem(C.Structure):
-    _fields_ = [("src", vp), ("dst", vp), ("N", i32), ("K", i32), ("src_rs", i64), ("src_cs", i64)]
+    _fields_ = [("src", vp), ("dst", vp), ("N", i32), ("K", i32), ("src_rs", i64), ("src_cs", i64), ("dst_rs", i64)]
 
 
 class GemmPlanInfo(C.Structure):

@@ -209,18 +209,25 @@ def packed_weight_floats(N, K):
     return int(n.value)
 
 
-def pack_weights(pairs):
+def pack_weights(pairs, copies=()):
     """[(m (N, K) 2-D view with positive strides, dst flat float buffer of packed_weight_floats(N, K))]: the packed
     copies the row-chain kernels read (include/ick_amd.h), up to 48 matrices per launch.  A transposed view (w.t())
-    gives the operand of the data-gradient chains."""
-    for i in range(0, len(pairs), 48):
-        chunk = pairs[i:i + 48]
+    gives the operand of the data-gradient chains.  copies: [(src (N, K) view, dst (N, K) view with unit column
+    stride)] plain copies that ride in the same launch."""
+    todo = [(s_, d_, 0) for s_, d_ in pairs] + [(s_, d_, 1) for s_, d_ in copies]
+    for i in range(0, len(todo), 48):
+        chunk = todo[i:i + 48]
         items = (L.PackItem * len(chunk))()
-        for it, (src, dst) in zip(items, chunk):
-            assert src.dim() == 2 and dst.is_contiguous()
-            assert dst.numel() == packed_weight_floats(src.shape[0], src.shape[1])
+        for it, (src, dst, plain) in zip(items, chunk):
+            assert src.dim() == 2
             it.src, it.dst, it.N, it.K = _p(src), _p(dst), src.shape[0], src.shape[1]
-            it.src_rs, it.src_cs = src.stride(0), src.stride(1)
+            it.src_rs, it.src_cs = max(1, src.stride(0)), src.stride(1)
+            if plain:
+                assert dst.shape == src.shape and (dst.stride(1) == 1 or dst.shape[1] == 1)
+                it.dst_rs = max(dst.stride(0), src.shape[1])
+            else:
+                assert dst.is_contiguous() and dst.numel() == packed_weight_floats(src.shape[0], src.shape[1])
+                it.dst_rs = 0
         L.check(L.load().ick_pack_weights(items, len(chunk), _stream()), "ick_pack_weights")
 
 

@@ -252,17 +252,28 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
                                facts=facts if dec.has_facts else None,
                                word_emb=_p(dec.word_embedding.weight) if dec.variant == "news" else None)
         fe = ops.fact_encode(facts, ee, _p(dec.predicate_embedding.weight)) if dec.has_facts else None
+        copies = []
         if fresh_pack:
             layers_ = dec.transformer_decoder.layers
-            wkv = torch.cat([_p(l.multihead_attn.in_proj_weight)[d:] for l in layers_])
-            bkv = torch.cat([_p(l.multihead_attn.in_proj_bias)[d:] for l in layers_])
+            if chain:
+                # the all-layer cross K/V weight and bias gathered by the packing launch below (two torch.cat
+                # launches less in front of Encoder.conv1 and the context chain)
+                wkv = torch.empty(nseg * d, d, device=dev, dtype=torch.float32)
+                bkv = torch.empty(nseg * d, device=dev, dtype=torch.float32)
+                for i_, l in enumerate(layers_):
+                    copies.append((_p(l.multihead_attn.in_proj_weight)[d:], wkv[2 * d * i_:2 * d * (i_ + 1)]))
+                    copies.append((_p(l.multihead_attn.in_proj_bias)[d:].view(1, -1),
+                                   bkv[2 * d * i_:2 * d * (i_ + 1)].view(1, -1)))
+            else:
+                wkv = torch.cat([_p(l.multihead_attn.in_proj_weight)[d:] for l in layers_])
+                bkv = torch.cat([_p(l.multihead_attn.in_proj_bias)[d:] for l in layers_])
         else:
             wkv, bkv = dec._packed_cross_kv()
         # packed weight copies of the row-chain launches.  Inside the captured step they are refreshed in three
         # launches placed where they cost nothing: the context encoders' copies now (the side chain needs them
         # first), the decoder layers' after Encoder.conv1 has been enqueued, the transposed copies of the backward
         # chains on the side stream once the context chain is done (it idles until the backward pass).
-        pk = dec._chain_pack(fresh=fresh_pack, subset=first if staged else None) if chain else None
+        pk = dec._chain_pack(fresh=fresh_pack, subset=first if staged else None, copies=copies) if chain else None
         return ee, fe, wkv, bkv, pk
 
     if head_on_side:
@@ -398,6 +409,19 @@ def _lin_bwd(grads, dy2, x2, lin_w, lin_b, w_rows=None, need_dx=True, dx=None, a
         gb = gb[w_rows] if gb is not None else None
     return ops.linear_bwd(dy2, x2, w, gw, gb, need_dx=need_dx, dx=dx, accumulate_dx=acc, group_now=group_now,
                           gate=gate, gate_scale=gate_scale)
+
+
+def _prezeroed(dec, captions, entities, facts):
+    """Accumulation targets of the backward pass's first kernels (the vocabulary data gradient's split-K sum, the
+    gradient of the encoded entity / fact rows), zeroed where nothing waits for it -- the forward pass's side stream --
+    instead of between the loss and the first backward GEMM (two fills + a gap: ~13 us of the step's critical path)."""
+    B, L = captions.shape[0], captions.shape[1]
+    d, dev = dec.emb_dim, captions.device
+    pre = {"dhv": torch.zeros(B * L, d, device=dev, dtype=torch.float32),
+           "dee": torch.zeros(B, entities.shape[1], d, device=dev, dtype=torch.float32)}
+    if facts is not None:
+        pre["dfe"] = torch.zeros(B, facts.shape[1], d, device=dev, dtype=torch.float32)
+    return pre
 
 
 def _norm_args(t, i, res, layer_norm, grads, M, d, dev):
@@ -695,13 +719,25 @@ def _backward_phases(dec, tape, dscores, grads, want_image_grad=False):
     Vx = dscores.shape[2]
     dsc2 = dscores.view(M, Vx)
     dev = h.device
-    dee = torch.zeros_like(ee)
-    dfe = torch.zeros_like(fe) if fe is not None else None
+    pre = m.get("prezero") or {}
+
+    def zeroed(name, like):
+        t = pre.get(name)
+        return t if t is not None and t.shape == like.shape else torch.zeros_like(like)
+
+    dee = zeroed("dee", ee)
+    dfe = zeroed("dfe", fe) if fe is not None else None
     # ---- score head
     hv = m["hv"] if dec.has_facts else h
     # the vocabulary weight gradient is a large problem of its own: it starts beside its data gradient
-    dhv = _lin_bwd(grads, dsc2[:, :V], hv.view(M, d), dec.fc_vocab.weight, dec.fc_vocab.bias,
-                   group_now=True).view(B, L, d)
+    dhv0 = pre.get("dhv")
+    if dhv0 is not None and dhv0.shape == (M, d) and not ops.is_deterministic():
+        # split-K partial sums add into the buffer the forward pass's side stream zeroed
+        dhv = _lin_bwd(grads, dsc2[:, :V], hv.view(M, d), dec.fc_vocab.weight, dec.fc_vocab.bias, dx=dhv0, acc=True,
+                       group_now=True).view(B, L, d)
+    else:
+        dhv = _lin_bwd(grads, dsc2[:, :V], hv.view(M, d), dec.fc_vocab.weight, dec.fc_vocab.bias,
+                       group_now=True).view(B, L, d)
     if dec.has_facts:
         dh = ops.mul(dhv, m["gate"])
         dgate = ops.mul(dhv, h)
@@ -920,12 +956,14 @@ class TrainStep:
         def tail():      # nothing in the forward pass waits for these: they run on the side stream behind the context chain
             self.flat_g.zero_()
             box["decode_len"] = (lengths.reshape(-1) - 1).to(torch.int32)
+            box["prezero"] = _prezeroed(dec, captions, entities, facts)
 
         scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, gmap=gmap,
                                          seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
                                          overlap=self._overlap("ICK_NO_FWD_OVERLAP"),
                                          side_tail=tail, **self._enc_kwargs(enc_in))
         decode_len = box["decode_len"]
+        tape.misc["prezero"] = box.get("prezero")
         ops.stamp("fwd: scores done")
         # the two scalars of the loss go straight into the tail of the gradient bucket (it was zeroed above; nothing else
         # touches those two floats)
@@ -945,12 +983,14 @@ class TrainStep:
         def tail():
             self.flat_g.zero_()
             box["decode_len"] = (lengths.reshape(-1) - 1).to(torch.int32)
+            box["prezero"] = _prezeroed(dec, captions, entities, facts)
 
         scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, gmap=gmap,
                                          seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
                                          overlap=self._overlap("ICK_NO_FWD_OVERLAP"),
                                          side_tail=tail, **self._enc_kwargs(enc_in))
         decode_len = box["decode_len"]
+        tape.misc["prezero"] = box.get("prezero")
         self._loss = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True,
                                    out_sum=self.flat_g[self.n:self.n + 1], out_count=self.flat_g[self.n + 1:])
         self._bp = BackwardPass(dec, tape, self._loss[2], self.grads,

@@ -198,6 +198,8 @@ int ick_rowchain_bwd(const ick_rowchain_bwd_args* args, void* stream);
  * floats, 16-byte aligned.  count <= 48 matrices per launch. */
 typedef struct {
     const float* src; float* dst; int32_t N, K; int64_t src_rs, src_cs;
+    int64_t dst_rs;   /* 0: the packed layout above.  > 0: a plain copy dst[n * dst_rs + k] = src(n, k) riding in the same
+                       * launch (the all-layer cross K/V weight / bias the step gathers from the layers' in_proj) */
 } ick_pack_item;
 int ick_packed_weight_floats(int32_t N, int32_t K, int64_t* floats);
 int ick_pack_weights(const ick_pack_item* items, int32_t count, void* stream);
