@@ -793,6 +793,16 @@ class SideStream:
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
+    def wait_or_join(self, key):
+        """The main stream waits for signal(key) if deferred work signalled it (after enqueuing that work), else for
+        the whole side stream."""
+        self.flush_group()
+        self.flush()
+        if key in self.signals:
+            self.wait(key)
+        else:
+            self.join()
+
     def submit(self, fn, *tensors):
         self.deferred.append((self.mark(), fn, tensors))
 

@@ -160,7 +160,7 @@ def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds, side=None, pk=No
         if early is not None:
             early.join()
         if side is not None:
-            side.join()    # the context rows of kv (and of the saved memory) come from the side stream
+            side.wait_or_join("ctx")    # the context rows of kv come from the side stream (its tail may still run)
         ops.attention_heads(t["qc"], kv, t["ca"], H, dh, T, S, 0, 2 * li, 2 * li + 1, lse=t["lse_c"], drop=t["d_ca"])
         t["f"] = torch.empty(B, T, layer.linear1.out_features, device=x.device, dtype=torch.float32)
         t["m2"], t["r2"] = ops.rowchain_fwd(
@@ -183,7 +183,7 @@ def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds, side=None, pk=No
     if early is not None:
         early.join()
     if side is not None:
-        side.join()    # the context rows of kv (and of the saved memory) come from the side stream
+        side.wait_or_join("ctx")    # the context rows of kv come from the side stream (its tail may still run)
     ops.attention_heads(t["qc"], kv, t["ca"], H, dh, T, S, 0, 2 * li, 2 * li + 1, lse=t["lse_c"], drop=t["d_ca"])
     t["o2"] = ops.linear(t["ca"], _p(layer.multihead_attn.out_proj.weight), _p(layer.multihead_attn.out_proj.bias))
     t["x2"], t["m2"], t["r2"] = ops.add_layernorm(t["o2"], t["x1"], _p(layer.norm2.weight), _p(layer.norm2.bias),
@@ -291,6 +291,8 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         ctx_e = _context_encoder_fwd(dec, dec.transformer_encoder_entities, ee, tape.enc_layers["entities"], ds, pk=pk,
                                      tag="e", out=mem[:, P:P + K], slim=slim_ctx)
         ops.project_heads(ctx_e, wkv, bkv, nseg, H, S, out=kv, s0=P, grp=K)
+        if side is not None:
+            side.signal("ctx")      # the first cross-attention waits for this point, not for the packing / zeroing below
         ops.stamp("side: context chain done")
         if staged and dec.chain_bwd_supported():
             m["pkb"] = dec._chain_pack(fresh=True, bwd=True, extra=[(("kv", "T"), wkv.t())])
