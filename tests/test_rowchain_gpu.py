@@ -75,6 +75,33 @@ def test_packed_weight_copies():
         assert torch.equal(dd, ref)
 
 
+def test_plain_copies_ride_in_the_packing_launch():
+    """ick_pack_item.dst_rs > 0: a plain (N, K) copy in the same launch -- the training step gathers the all-layer
+    cross K/V weight (rows d.. of every layer's in_proj_weight) and bias this way instead of two torch.cat launches."""
+    from ick_amd import ops
+    g = torch.Generator().manual_seed(5)
+    w = [torch.randn(900, 300, generator=g).cuda() for _ in range(3)]
+    bias = [torch.randn(900, generator=g).cuda() for _ in range(3)]
+    packed_src = torch.randn(300, 300, generator=g).cuda()
+    packed_dst = torch.full((ops.packed_weight_floats(300, 300),), float("nan"), device="cuda")
+    wkv = torch.full((1800, 300), float("nan"), device="cuda")
+    bkv = torch.full((1800,), float("nan"), device="cuda")
+    odd = torch.randn(70, 33, generator=g).cuda()                      # ragged rows / columns, strided destination
+    odd_dst = torch.full((70, 40), float("nan"), device="cuda")
+    copies = []
+    for i in range(3):
+        copies.append((w[i][300:], wkv[600 * i:600 * (i + 1)]))
+        copies.append((bias[i][300:].view(1, -1), bkv[600 * i:600 * (i + 1)].view(1, -1)))
+    copies.append((odd, odd_dst[:, :33]))
+    ops.pack_weights([(packed_src, packed_dst)], copies)
+    assert torch.equal(wkv, torch.cat([x[300:] for x in w]))
+    assert torch.equal(bkv, torch.cat([x[300:] for x in bias]))
+    assert torch.equal(odd_dst[:, :33], odd) and torch.isnan(odd_dst[:, 33:]).all()
+    ref = torch.zeros(5 * 64, 304, device="cuda")
+    ref[:300, :300] = packed_src
+    assert torch.equal(packed_dst, ref.view(5, 64, 76, 4).permute(0, 2, 1, 3).contiguous().view(-1))
+
+
 def test_chain_dropout_masks_and_head_split_equal_the_unfused_kernels():
     from ick_amd import ops
     B, T, d, H, FF = 8, 20, 300, 10, 512
