@@ -162,3 +162,33 @@ def test_forward_scores_with_split_products_match_the_exact_path():
     d = (res[0] - res[1]).abs().max().item()
     assert d < 1e-5 * max(1.0, res[0].abs().max().item()), d
     assert torch.equal(res[0].argmax(-1), res[1].argmax(-1))
+
+
+def test_train_step_with_split_products_matches_the_exact_path():
+    """One captured TrainStep at cfg2 shapes (smaller batch), dropout on with the same counter-based masks, split mode 2
+    (every large tile) against mode 0: loss within 1e-5, the gradient bucket within 2e-5 of its largest entry, the
+    token count identical."""
+    import ick_amd.synth as synth
+    from ick_amd import ops as o
+    from ick_amd.training import TrainStep
+    from test_forward_gpu import build_decoder
+    variant, B, Lc, K, V = "geo", 32, 20, 20, 10000
+    P = synth.make_params(variant, V, 0)
+    batch = {k: v.cuda() for k, v in synth.make_batch(variant, B, Lc, K, V, 0, 5).items()}
+    enc = ick_amd.load_models(variant).Encoder(emb_dim=300).cuda().eval()
+    feats = synth.make_feats(B, 5).cuda()
+    res = []
+    try:
+        for mode in (0, 2):
+            o.set_gemm_split(mode)
+            dec = build_decoder(variant, V, P).train()
+            ts = TrainStep(dec, lr=4e-4, grad_clip=5.0, seed=7, encoder=enc)
+            loss = ts(batch["captions"], feats, batch["caption_masks"], batch["caption_lengths"], batch["entities"])
+            res.append((loss.item(), ts.flat_g.clone(), ts.n))
+    finally:
+        o.set_gemm_split(0)
+    (l0, g0, n), (l1, g1, _) = res
+    assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0)), (l0, l1)
+    assert g0[n + 1].item() == g1[n + 1].item()
+    scale = g0[:n].abs().max().item()
+    assert (g0[:n] - g1[:n]).abs().max().item() < 2e-5 * max(scale, 1e-3), ((g0[:n] - g1[:n]).abs().max().item(), scale)
