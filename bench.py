@@ -2,6 +2,8 @@
 
     python bench.py [--gpus N --steps K --warmup W] [--mode train|forward|greedy|beam] [--config cfg2] [--no-modes]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+(`python bench.py --gpus N` with N > 1 and no WORLD_SIZE starts that torch.distributed.run line itself, as a child
+process, and relays rank 0's JSON line; `ranks_seen` in the line is what the probe all-reduce returned.)
 
 One *step* = one pass of the hot path over one batch of synthetic input resident in HBM, on cfg2 =
 B 64 x L 20 decode positions, 14x14x2048 features, K=20 knowledge rows, vocab 10k => 1280 decode-steps
@@ -322,17 +324,43 @@ def _gemm_mode():
     return ops.gemm_split_mode()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without torchrun: start `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    as a CHILD process and relay rank 0's JSON line.  The parent makes no GPU call before this (importing torch does
+    not initialise HIP) and never replaces itself: an exec from a process that has touched the GPU takes the node down."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL's intra-node transport needs it here
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    for ln in r.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    raise SystemExit(r.returncode if r.returncode else (0 if lines else 1))
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU" % (args.gpus, world))
     import torch.distributed as dist
     torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
     backend = "none"
+    ranks_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL on ROCm.  ICK_BENCH_BACKEND=gloo is an explicit opt-in (several ranks sharing one GPU in the
@@ -343,7 +371,8 @@ def main():
         probe = torch.ones(1, device="cuda")
         dist.all_reduce(probe)              # the first collective builds the communicators: fail here, not mid-run
         torch.cuda.synchronize()
-        assert probe.item() == world, "all-reduce probe returned %s for %d ranks" % (probe.item(), world)
+        ranks_seen = int(probe.item())
+        assert ranks_seen == world, "all-reduce probe returned %s for %d ranks" % (probe.item(), world)
         backend = dist.get_backend()
 
     cfgname = args.config or ("cfg5" if args.mode in ("greedy", "beam") else "cfg2")
@@ -355,7 +384,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "decode_steps_per_sec", "value": res["value"],
-            "unit": "decode-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "decode-steps/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": res["ms_per_step"], "repeats": res["repeats"], "timed_region_s": res["timed_region_s"],
             "block_s_min_median_max": res["block_s_min_median_max"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -453,14 +482,16 @@ def main():
             modes[name] = entry
         out["modes"] = modes
 
+    if world > 1:
+        # every rank leaves the job before rank 0 spends its seconds on the host baseline (no rank waits in a collective)
+        torch.cuda.synchronize()
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, seed, args.cpu_seconds,
                                                {"train": "train", "greedy": "greedy", "beam": "greedy"}.get(args.mode, "forward"))
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

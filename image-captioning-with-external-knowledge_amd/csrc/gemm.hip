@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "gemm_common.h"
 
 // Diagnostic build (-DICK_GEMM_STAMPS, tools/debug/gemm_stamps.py): every workgroup of a single-problem launch records
 // where it ran (HW_ID) and the realtime clock (100 MHz) at its start, after its first LDS stage, after its K loop and
@@ -41,55 +42,12 @@ extern "C" int ick_debug_read_gemm_stamps(unsigned long long* out, int n) {
 #endif
 
 namespace ick {
+
+int launch_gemm_ps(const ick_gemm_args& a, bool akm, bool wide, int tiles_m, int tiles_n, int kchunk, int split,
+                   hipStream_t s);      // gemm_ps.hip
+
 namespace {
 
-
-struct RowMap {  // offset of logical row r:  goff(r / grp) + (r % grp) * rs
-    int grp;
-    int64_t gs;
-    const int32_t* gmap;
-    int64_t rs;
-    __device__ __forceinline__ int64_t operator()(int r) const {
-        if (grp <= 0) return (int64_t)r * rs;
-        const int g = r / grp;
-        const int i = r - g * grp;
-        const int64_t gg = gmap ? (int64_t)gmap[g] : (int64_t)g;
-        return gg * gs + (int64_t)i * rs;
-    }
-};
-
-// Offsets of N valid rows at once: the group-map lookups of all rows are issued together (one memory round trip
-// instead of one per row: a conditional load is followed by its own s_waitcnt).
-template <int N>
-__device__ __forceinline__ void map_rows(const RowMap& m, const int (&rows)[N], int64_t (&off)[N]) {
-    if (m.grp <= 0) {            // uniform
-#pragma unroll
-        for (int i = 0; i < N; ++i) off[i] = (int64_t)rows[i] * m.rs;
-        return;
-    }
-    int g[N], in[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) { g[i] = rows[i] / m.grp; in[i] = rows[i] - g[i] * m.grp; }
-    if (m.gmap != nullptr) {     // uniform
-        int gg[N];
-#pragma unroll
-        for (int i = 0; i < N; ++i) gg[i] = m.gmap[g[i]];
-#pragma unroll
-        for (int i = 0; i < N; ++i) g[i] = gg[i];
-    }
-#pragma unroll
-    for (int i = 0; i < N; ++i) off[i] = (int64_t)g[i] * m.gs + (int64_t)in[i] * m.rs;
-}
-
-// Column offset inside an output row: the column itself, or the head-split scatter
-// [segment][head][position][dhp] (see include/ick_amd.h).
-__device__ __forceinline__ int64_t col_offset(const ick_gemm_args& p, int col) {
-    if (p.hs_dh <= 0) return col;
-    const int hd = p.hs_H * p.hs_dh;
-    const int seg = col / hd, r = col - seg * hd;
-    const int h = r / p.hs_dh, j = r - h * p.hs_dh;
-    return ((int64_t)seg * p.hs_H + h) * ((int64_t)p.hs_S * p.hs_dhp) + j;
-}
 
 // Global -> register -> LDS stager for one operand tile of R rows x BK k.
 // VEC: every row offset / K / base pointer is 16-byte friendly.  The tile is fetched with
@@ -99,43 +57,6 @@ __device__ __forceinline__ int64_t col_offset(const ick_gemm_args& p, int col) {
 // for anything out of bounds -- no address arithmetic, selects or branches in the loop, so the loads of
 // two slices stay in flight behind the MFMAs.  Only the last, partial K slice is masked (at LDS-store time).
 // !VEC is the generic element-wise fallback for ragged / unaligned operands.
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-constexpr uint32_t kOobOffset = 0x80000000u;   // >= any extent the vector path accepts (< 2 GiB)
-
-// ---- split operands (SPL): fp32 products on the bf16 matrix pipe --------------------------------------------------
-// gfx950 has no reduced-precision fp32 MFMA, and the exact one runs at 1/16 of the bf16 rate.  Every fp32 value is the
-// EXACT sum of three bf16 numbers (x = hi + mid + lo: 3 x 8 significand bits, round-to-nearest at each level, the
-// residuals are exact fp32 subtractions), so a product a*b is the sum of nine bf16 x bf16 products, each of which the
-// matrix pipe forms exactly and accumulates in fp32.  The three smallest (mid*lo, lo*mid, lo*lo: <= 2^-24 of a*b
-// together) are dropped: six v_mfma_f32_16x16x32_bf16 per 16x16x32 block instead of eight v_mfma_f32_16x16x4_f32 at
-// a sixteenth of the rate -- 2.7 x the matrix throughput at an error below one fp32 rounding of the product
-// (measured against fp64 beside the exact path: tests/test_gemm_split_gpu.py).  The split happens once per staged
-// element, between the global load and the LDS store; LDS holds three bf16 planes per operand tile:
-//   k-contiguous operand: plane[row][32 k] in 64-byte rows, 16-byte chunk c of row r at chunk c ^ ((-(r >> 2)) & 3):
-//     the ds_read_b128 of the MFMA operand (lane (i, q) takes k = 8q..8q+7 of row i) is conflict-free for the four
-//     16-lane groups the LDS serves it in, and so are the ds_write_b64 of the stager;
-//   k-major operand: plane[k][rows] with (2 rows + 64)-byte k lines, stored as it arrives (ds_write_b64 of 4 rows) and
-//     read with ds_read_b64_tr_b16, the transposing read: two of them deliver the same 8-k operand.  The 16-row blocks
-//     of k lines 8-15 and 24-31 are swapped pairwise: the two 16-lane groups a transposing read serves together (k
-//     lines q and q + 8) then fall on different banks (bank search: DESIGN.md).
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
-
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
-}
-// (a, b) -> packed (hi, mid, lo) pairs, a in the low half
-__device__ __forceinline__ void split3(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-    hi = pack_bf16(a, b);
-    const float ra = a - __builtin_bit_cast(float, hi << 16), rb = b - __builtin_bit_cast(float, hi & 0xffff0000u);
-    mid = pack_bf16(ra, rb);
-    const float sa = ra - __builtin_bit_cast(float, mid << 16), sb = rb - __builtin_bit_cast(float, mid & 0xffff0000u);
-    lo = pack_bf16(sa, sb);
-}
-__device__ __forceinline__ int kc_swz(int row) { return (-(row >> 2)) & 3; }
 // k-major planes (bank search): 64-row tiles take (2 R + 64)-byte k lines and swap neighbouring 16-row
 // blocks in k lines 8-15 / 24-31; 128-row tiles take (2 R + 32)-byte k lines (the 128 x 64 tile of Encoder.conv1 then
 // needs exactly 80 KB: two workgroups per CU) and swap blocks four apart.  kmajor_swap = log2 of the swap distance in
@@ -526,107 +447,7 @@ __device__ __forceinline__ void gemm_tile(const ick_gemm_args& p, int tiles_m, i
     if (colsum && threadIdx.x < BM && m0 + (int)threadIdx.x < p.M) atomicAdd(p.colsum_a + m0 + threadIdx.x, csum);
     if (only) return;
 
-    // Epilogue.  C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.
-    const bool hs = p.hs_dh > 0;
-    const RowMap cmap{p.c_grp, p.c_gs, p.c_gmap, hs ? (int64_t)p.hs_dhp : p.c_rs};
-    const int64_t row_bias = hs ? (int64_t)p.hs_s0 * p.hs_dhp : 0;
-    const bool relu = p.flags & ICK_GEMM_RELU;
-    const int mode = (p.flags & ICK_GEMM_ATOMIC) ? 2 : ((p.flags & ICK_GEMM_ACCUM) ? 1 : 0);
-    float bv[TN];
-    int cols[TN];
-    int64_t co[TN];
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        cols[b] = n0 + (wn * TN + b) * 16 + fi;
-        co[b] = col_offset(p, cols[b]);
-        bv[b] = (p.bias != nullptr && zid == 0 && cols[b] < p.N) ? p.bias[cols[b]] : 0.f;
-    }
-    const float alpha = p.alpha;
-    int64_t coff[TM][4];
-    int rowid[TM][4];
-    const Dropout drop = make_dropout(p.drop_p, p.drop_epoch ? p.drop_seed + *p.drop_epoch : p.drop_seed, p.drop_site);
-    {
-        int rws[TM * 4];
-        int64_t mo[TM * 4];
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                rowid[a][r] = m0 + (wm * TM + a) * 16 + fq * 4 + r;
-                rws[a * 4 + r] = min(rowid[a][r], p.M - 1);
-            }
-        map_rows<TM * 4>(cmap, rws, mo);
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) coff[a][r] = rowid[a][r] < p.M ? mo[a * 4 + r] + row_bias : -1;
-    }
-    ICK_GSTAMP(4);
-    // Values first, memory second: vmcnt counts loads and stores in one queue, so a load between two stores (the gate,
-    // the old value of an accumulating epilogue) makes every row wait for the previous row's stores to be acknowledged
-    // (measured on the cross K/V projection: 4.1 of a workgroup's 22 us).  Every load of the epilogue is issued before
-    // its first store.
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                float v = acc[a][b][r] * alpha + bv[b];
-                if (relu) v = fmaxf(v, 0.f);
-                if (drop.on()) v *= drop.mask((uint32_t)rowid[a][r] * (uint32_t)p.N + (uint32_t)cols[b]);
-                acc[a][b][r] = v;
-            }
-    if (p.gate != nullptr) {      // uniform
-        float g[TM][4][TN];
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    // unconditional loads (element 0 stands in for what lies outside the matrix; never stored)
-                    g[a][r][b] = p.gate[(coff[a][r] >= 0 && cols[b] < p.N) ? (int64_t)rowid[a][r] * p.gate_rs + cols[b] : 0];
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int b = 0; b < TN; ++b) acc[a][b][r] = g[a][r][b] > 0.f ? acc[a][b][r] * p.gate_scale : 0.f;
-    }
-    if (mode == 1) {              // uniform
-        float old[TM][4][TN];
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    old[a][r][b] = p.C[(coff[a][r] >= 0 && cols[b] < p.N) ? coff[a][r] + co[b] : 0];
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int b = 0; b < TN; ++b) acc[a][b][r] += old[a][r][b];
-    }
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (coff[a][r] < 0) continue;
-            float* crow = p.C + coff[a][r];
-            if (mode != 2) {
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    if (cols[b] < p.N) crow[co[b]] = acc[a][b][r];
-            } else {
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    if (cols[b] < p.N) atomicAdd(crow + co[b], acc[a][b][r]);
-            }
-        }
-    }
+    gemm_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, fi, fq, zid);
     ICK_GSTAMP(3);
 }
 
@@ -673,12 +494,14 @@ struct Plan {
     bool wide;                   // 128 x 64 tiles, 8 waves (single launches only)
     bool spl;                    // split-bf16 products (64 x 64 and 128 x 64 tiles of the vector path)
     bool xl;                     // 128 x 128 tiles, 8 waves, split products only (single launches only; implies wide)
+    bool ps, ps_wide;            // B read from its pre-split copy (gemm_ps.hip): 128 x 128 tiles, or 64 x 320 when ps_wide
     int tiles_m, tiles_n, kchunk, split;
 };
 
 // Occupancy cap for the large-tile kernels: a workgroup that declares more LDS than it uses leaves wave slots,
 // registers and LDS of its CU to the latency-bound chain kernels that run beside it on the other stream.
-// ICK_GEMM_LDS_SINGLE / ICK_GEMM_LDS_GROUP: bytes of LDS a 64x64 / 128x64 workgroup declares (<= 65536).
+// ICK_GEMM_LDS_SINGLE / ICK_GEMM_LDS_GROUP: bytes of LDS a 64x64 / 128x64 workgroup declares (<= 160 KB; above 64 KB
+// the launchers raise the kernel's dynamic-LDS limit first).
 inline size_t lds_floor(int which) {
     static long v[2] = {-1, -1};
     if (v[which] < 0) {
@@ -745,7 +568,18 @@ int launch_group_s(const Plan* const* pls, int n, hipStream_t s) {
     for (int i = n; i < kGroupMax; ++i) {
         ga.wg_end[i] = total; ga.tiles_m[i] = ga.tiles_n[i] = 1; ga.kchunk[i] = 32; ga.split[i] = 0; ga.g[i] = pls[0]->a;
     }
+    static_assert(smem <= 160 * 1024, "tile exceeds the LDS of a CU");
     const size_t lds = (TM > 1) ? std::max(smem, lds_floor(1)) : smem;
+    if (lds > 64 * 1024) {      // split planes of two k-major operands: 72 KB, above the default dynamic-LDS limit
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(
+                reinterpret_cast<const void*>(gemm_group_kernel<2, 2, TM, TN, AKM, BKM, true, 32, SPL>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr = true;
+        }
+    }
     hipLaunchKernelGGL((gemm_group_kernel<2, 2, TM, TN, AKM, BKM, true, 32, SPL>), dim3(total), dim3(256), lds, s, ga);
     ICK_LAUNCH_RET();
 }
@@ -757,15 +591,16 @@ int launch_group(const Plan* const* pls, int n, hipStream_t s) {
     return launch_group_s<TM, TN, AKM, BKM, false>(pls, n, s);
 }
 
-// Split-bf16 products for the 64 x 64 / 128 x 64 / 128 x 128 tiles.  Opt-in: ICK_GEMM_SPLIT=1 (or ick_set_gemm_split(1))
-// takes them where they are faster than the exact fp32 MFMA (B operand k-contiguous: the forward GEMMs and the feature
-// projection); 2 takes them for every large-tile problem (the k-major forms gain nothing yet: tools/gemm_split_bench.py).
-// Default 0: every product on v_mfma_f32_16x16x4_f32.
+// Split-bf16 products for the 64 x 64 / 128 x 64 / 128 x 128 tiles.  Mode 1 (the DEFAULT since round 4: the reference-pinned
+// parity suite runs in every mode, tests/conftest.py gemm_split) takes them where they are faster than the exact fp32 MFMA
+// (B operand k-contiguous or pre-split: the forward GEMMs, the feature projection, the vocabulary data gradient); 2 takes
+// them for every large-tile problem (the k-major forms gain little: tools/gemm_split_bench.py); ICK_GEMM_SPLIT=0 /
+// ick_set_gemm_split(0): every product on v_mfma_f32_16x16x4_f32.
 int g_gemm_split = -1;
 inline int gemm_split_mode() {
     if (g_gemm_split < 0) {
         const char* e = getenv("ICK_GEMM_SPLIT");
-        g_gemm_split = e ? std::min(2, std::max(0, atoi(e))) : 0;
+        g_gemm_split = e ? std::min(2, std::max(0, atoi(e))) : 1;
     }
     return g_gemm_split;
 }
@@ -868,6 +703,22 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
     pl.tiles_m = ceil_div(a.M, pl.wide ? 128 : BMN); pl.tiles_n = ceil_div(a.N, pl.xl ? 128 : BMN);
     pl.kchunk = ceil_div(ceil_div(a.K, split_req), 32) * 32;
     pl.split = ceil_div(a.K, pl.kchunk);
+    // B pre-split by the caller (b_ps): both operands staged by LDS-DMA, only the A fragments split in the kernel
+    // (gemm_ps.hip).  Needs the vector conditions on A (16-byte pieces) and a problem large enough for its tiles.
+    pl.ps = pl.ps_wide = false;
+    if (a.b_ps != nullptr && gemm_split_mode() >= 1 && avec && aligned16(a.b_ps) && a.a_extent >= 4 &&
+        a_need <= a.a_extent + 3 && a.colsum_a == nullptr && !(a.flags & ICK_GEMM_COLSUM_ONLY)) {
+        static int ps_on = -1;
+        if (ps_on < 0) { const char* e = getenv("ICK_GEMM_PS"); ps_on = e ? atoi(e) : 1; }
+        const bool wide_n = a.N <= 320;
+        const double flop = 2.0 * a.M * a.N * a.K;
+        if (ps_on && flop >= 1.0e9 && a.M >= 256 && a.N >= 128) {
+            pl.ps = true; pl.ps_wide = wide_n;
+            pl.spl = true; pl.big = true; pl.wide = pl.xl = false;
+            pl.tiles_m = ceil_div(a.M, wide_n ? 64 : 128);
+            pl.tiles_n = wide_n ? 1 : ceil_div(a.N, 128);
+        }
+    }
     return ICK_OK;
 }
 
@@ -882,6 +733,7 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
 #define ICK_COMMA_FALSE , false
 
 int launch_plan(const Plan& pl, hipStream_t s) {
+    if (pl.ps) return launch_gemm_ps(pl.a, pl.akm, pl.ps_wide, pl.tiles_m, pl.tiles_n, pl.kchunk, pl.split, s);
     if (!pl.vec) ICK_BY_LAYOUT(launch_one, 2, 2, ICK_COMMA_FALSE, pl, s);
     if (pl.xl) {
         // four waves of 64 x 64 and one LDS buffer (two workgroups per CU overlap their phases) unless ICK_GEMM_XL4=0
@@ -919,6 +771,8 @@ extern "C" int ick_gemm_plan(const ick_gemm_args* in, ick_gemm_plan_info* out) {
     if (int rc = make_plan(in, pl)) return rc;
     const int bmn = pl.big ? 64 : 32;
     out->tile_m = pl.wide ? 128 : bmn; out->tile_n = pl.xl ? 128 : bmn; out->waves = pl.wide ? 8 : 4;   // (xl: 4 or 8, ICK_GEMM_XL4)
+    out->presplit = pl.ps;
+    if (pl.ps) { out->tile_m = pl.ps_wide ? 64 : 128; out->tile_n = pl.ps_wide ? 320 : 128; out->waves = 8; }
     out->tiles_m = pl.tiles_m; out->tiles_n = pl.tiles_n; out->split_k = pl.split;
     out->a_kmajor = pl.akm; out->b_kmajor = pl.bkm; out->vec = pl.vec;
     out->split_bf16 = pl.spl;
@@ -957,7 +811,7 @@ extern "C" int ick_gemm_grouped(const ick_gemm_args* problems, int32_t count, vo
     bool done[64] = {false};
     for (int i = 0; i < count; ++i) {
         if (done[i]) continue;
-        if (!plans[i].vec || plans[i].wide) {   // element-wise staging / 8-wave tiles: no grouped instantiation
+        if (!plans[i].vec || plans[i].wide || plans[i].ps) {   // element-wise staging / 8-wave tiles: no grouped instantiation
             done[i] = true;
             if (int rc = launch_plan(plans[i], s)) return rc;
             continue;
@@ -965,7 +819,7 @@ extern "C" int ick_gemm_grouped(const ick_gemm_args* problems, int32_t count, vo
         const Plan* grp[kGroupMax];
         int n = 0;
         for (int j = i; j < count && n < kGroupMax; ++j) {
-            if (done[j] || !plans[j].vec || plans[j].wide || plans[j].akm != plans[i].akm || plans[j].bkm != plans[i].bkm ||
+            if (done[j] || !plans[j].vec || plans[j].wide || plans[j].ps || plans[j].akm != plans[i].akm || plans[j].bkm != plans[i].bkm ||
                 plans[j].big != plans[i].big || plans[j].spl != plans[i].spl) continue;
             grp[n++] = &plans[j];
             done[j] = true;

@@ -1,0 +1,361 @@
+// fp32 GEMM with split-bf16 products whose B operand (an nn.Linear / 1x1 conv weight) arrives PRE-SPLIT.
+//
+//   C[m, n] = epilogue( sum_k A(m,k) * B(n,k) ),   A fp32 activations,  B = hi + mid + lo bf16 planes (ick_presplit_weights)
+//
+// Call sites (include/ick_amd.h, ick_gemm with b_ps set): Encoder.conv1 (geo-aware/models.py:32,45), the cross K/V
+// projection of the image rows and fc_vocab (geo-aware/models.py:241-242,303), and fc_vocab's data gradient.
+//
+// Why a kernel of its own (csrc/gemm.hip splits BOTH operands between the global load and the LDS store): there the
+// split costs 5.5 VALU instructions per staged element and the vector issue port, not the matrix pipe, bounds the
+// kernel.  A weight is the same for the whole step, so it is split once per step by the packing launch; what is left to
+// split is the activation operand, and that is done on the 16 x 32 MFMA fragment a wave is about to use (8 elements per
+// lane and slice).  Nothing is staged through registers any more:
+//   * every tile slice travels global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction): the
+//     pre-split B planes in the MFMA operand's image (64-byte rows, XOR-swizzled chunks -- the swizzle is applied to
+//     the SOURCE address, the LDS side of a DMA is lane-linear), the A tile as raw fp32;
+//   * B is double buffered, A two or three deep (AST): with one workgroup per CU the A slices (read from HBM exactly
+//     once) get two MFMA phases to land; the only waits are counted s_waitcnt vmcnt(N) + one raw s_barrier per slice;
+//   * a wave owns 16 rows x (TN x 16) columns: it reads its raw A fragment (k-major: eight ds_read_b32 from a line
+//     image rotated by 16 floats per 8 k lines; k-contiguous: two ds_read_b128 from 128-byte rows with XOR-swizzled
+//     chunks -- both conflict free), splits it (44 VALU) and issues 6 x TN v_mfma_f32_16x16x32_bf16 against B fragments
+//     that are read one block ahead;
+//   * two tile shapes: 64 x 320 (8 waves as 4 x 2, one workgroup per CU, 144 KB of LDS) for outputs at most 320 wide --
+//     Encoder.conv1 (N = 300) and the vocabulary data gradient read their big A operand ONCE instead of once per 64-wide
+//     column tile; 128 x 128 (8 waves as 8 x 1, 80 KB, two workgroups per CU) for the wide outputs.
+#include <algorithm>
+
+#include "gemm_common.h"
+
+namespace ick {
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+inline int64_t ps_rows(int N) { return (int64_t)ceil_div(N, 64) * 64; }
+inline int64_t ps_bytes(int N, int K) { return (int64_t)ceil_div(K, 32) * 3 * ps_rows(N) * 64; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pre-split copies: dst[slice s][plane p][row n < Np][32 k] bf16, zero beyond N / K.
+constexpr int kPsMaxItems = 16;
+struct PsBatch {
+    int count;
+    int first[kPsMaxItems + 1];     // first workgroup of every item
+    ick_presplit_item it[kPsMaxItems];
+};
+
+__global__ __launch_bounds__(256) void presplit_kernel(PsBatch b) {
+    __shared__ float tile[64][33];
+    int gi = 0;
+    while (gi + 1 < b.count && (int)blockIdx.x >= b.first[gi + 1]) ++gi;
+    const ick_presplit_item it = b.it[gi];
+    const int local = blockIdx.x - b.first[gi];
+    const int blocks_n = (it.N + 63) / 64;
+    const int nb = local % blocks_n, s = local / blocks_n;
+    const int t = threadIdx.x;
+    const float* src = it.src;
+    if (it.src_cs == 1) {                 // k contiguous: 8 consecutive k of one row per thread
+        const int r = t >> 2, kk = (t & 3) * 8;
+        const int n = nb * 64 + r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 32 * s + kk + j;
+            tile[r][kk + j] = (n < it.N && k < it.K) ? src[(int64_t)n * it.src_rs + k] : 0.f;
+        }
+    } else {                              // rows contiguous (a transposed view): 8 consecutive rows at one k per thread
+        const int kk = t >> 3, r0 = (t & 7) * 8;
+        const int k = 32 * s + kk;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = nb * 64 + r0 + j;
+            tile[r0 + j][kk] = (n < it.N && k < it.K) ? src[(int64_t)n * it.src_rs + (int64_t)k * it.src_cs] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int r = t >> 2, c = t & 3;
+    uint32_t h[4], m[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split3(tile[r][8 * c + 2 * j], tile[r][8 * c + 2 * j + 1], h[j], m[j], l[j]);
+    const int64_t np = (int64_t)blocks_n * 64;
+    char* dst = reinterpret_cast<char*>(it.dst) + ((int64_t)s * 3 * np + nb * 64 + r) * 64 + c * 16;
+    *reinterpret_cast<uint4*>(dst) = uint4{h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<uint4*>(dst + np * 64) = uint4{m[0], m[1], m[2], m[3]};
+    *reinterpret_cast<uint4*>(dst + 2 * np * 64) = uint4{l[0], l[1], l[2], l[3]};
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <int WM_, int WN_, int TN_, bool AKM_, int AST_>
+struct PsCfg {
+    static constexpr int WM = WM_, WN = WN_, TN = TN_, AST = AST_;
+    static constexpr bool AKM = AKM_;
+    static constexpr int BM = WM * 16, BN = WN * TN * 16, NW = WM * WN, NT = NW * 64;
+    static constexpr int A_STAGE = BM * 32 * 4;          // bytes: raw fp32 slice of the A tile
+    static constexpr int B_PLANE = BN * 64;              // bytes: one bf16 plane of the B tile slice
+    static constexpr int B_STAGE = 3 * B_PLANE;
+    static constexpr int LDS = AST * A_STAGE + 2 * B_STAGE;
+    static constexpr int NPA = BM / 8;                   // 1 KiB DMA pieces of an A slice
+    static constexpr int NPB = 3 * BN / 16;              // ... of a B slice (16 rows of one plane each)
+    static constexpr int PA_W = NPA / NW;                // pieces per wave
+    static constexpr int PB_W = (NPB + NW - 1) / NW;
+    static_assert(NPA % NW == 0 && PA_W >= 1, "every wave issues the same number of A pieces (counted vmcnt)");
+    static_assert(AST == 2 || AST == 3, "A ring depth");
+    static_assert(LDS <= 160 * 1024, "tile exceeds the LDS of a CU");
+};
+
+#define ICK_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+// every wave is done reading the slice (its LDS reads have been consumed by MFMAs; the explicit wait covers reads the
+// compiler may have left in flight) and its DMA pieces have landed: one barrier publishes both
+#define ICK_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// One slice of the B tile / of the A tile by LDS-DMA: this wave's 1 KiB pieces (see the kernel below).
+template <class C>
+__device__ __forceinline__ void ps_dma_b(const __amdgpu_buffer_rsrc_t& rsrc, char* Bs, int buf, int wave, uint32_t bvoff,
+                                         int slice, bool valid, int n0, int np_rows) {
+#pragma unroll
+    for (int j = 0; j < C::PB_W; ++j) {
+        const int g = wave + C::NW * j;
+        if (g < C::NPB) {               // wave-uniform
+            const int plane = g / (C::BN / 16), rblk = g % (C::BN / 16);
+            const bool in = valid && (n0 + rblk * 16 < np_rows);
+            const uint32_t soff = (uint32_t)((((int64_t)slice * 3 + plane) * np_rows + rblk * 16) * 64);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(Bs + buf * C::B_STAGE + plane * C::B_PLANE + rblk * 1024),
+                                                     16, in ? bvoff : kOobOffset, in ? soff : 0u, 0, 0);
+        }
+    }
+}
+template <class C>
+__device__ __forceinline__ void ps_dma_a(const __amdgpu_buffer_rsrc_t& rsrc, char* As, int buf, int wave,
+                                         const uint32_t (&avoff)[C::PA_W], const int (&akl)[C::PA_W], int k0, int kend,
+                                         uint32_t soff) {
+#pragma unroll
+    for (int j = 0; j < C::PA_W; ++j) {
+        const int g = wave + C::NW * j;
+        const bool in = k0 + akl[j] < kend;      // also false for every lane of a slice beyond the K range
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(As + buf * C::A_STAGE + g * 1024), 16,
+                                                 in ? avoff[j] : kOobOffset, soff, 0, 0);
+    }
+}
+
+template <int WM_, int WN_, int TN_, bool AKM_, int AST_>
+__global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_ps_kernel(ick_gemm_args p, int np_rows, int64_t bps_bytes, int tiles_m,
+                                                                 int tiles_n, int kchunk) {
+    using C = PsCfg<WM_, WN_, TN_, AKM_, AST_>;
+    constexpr int BM = C::BM, BN = C::BN, TN = C::TN, NW = C::NW, AST = C::AST;
+    constexpr bool AKM = C::AKM;
+    extern __shared__ __attribute__((aligned(1024))) char smem_ps[];
+    char* const As = smem_ps;
+    char* const Bs = smem_ps + AST * C::A_STAGE;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr int WN = C::WN;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fi = lane & 15, fq = lane >> 4;
+
+    // tile of this workgroup: XCD-aware order (workgroups b, b + 8, ... share an XCD: each XCD walks a contiguous run)
+    int bid = blockIdx.x;
+    const int zid = blockIdx.z;
+    {
+        const int nwg = tiles_m * tiles_n;
+        const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    }
+    int tm, tn;
+    if (tiles_m <= tiles_n) { tm = bid % tiles_m; tn = bid / tiles_m; }
+    else { tn = bid % tiles_n; tm = bid / tiles_n; }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = zid * kchunk;
+    const int kend = min(p.K, kbeg + kchunk);
+    const int nk = (kend - kbeg + 31) >> 5;
+    const int s0 = kbeg >> 5;
+
+    // ---- A: per-lane source offsets of this wave's pieces (fixed for the whole K loop; the K position is the scalar offset)
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), (short)0, (int)(p.a_extent * 4), 0x00020000);
+    const RowMap amap{p.a_grp, p.a_gs, p.a_gmap, p.a_rs};
+    uint32_t avoff[C::PA_W];
+    int akl[C::PA_W];                       // k (relative to the slice) of the lane's 16 bytes
+#pragma unroll
+    for (int j = 0; j < C::PA_W; ++j) {
+        const int g = wave + NW * j;
+        int row, extra;
+        if constexpr (AKM) {
+            constexpr int LPK = BM / 4, KPP = 64 / LPK;        // lanes per k line, k lines per piece
+            const int kl = g * KPP + lane / LPK, cpos = lane % LPK;
+            const int c = (cpos - 4 * ((kl >> 3) & 3)) & (LPK - 1);   // the line image is rotated by 16 floats per 8 k lines
+            row = m0 + 4 * c;
+            akl[j] = kl;
+            extra = 0;
+            const int one[1] = {min(row, p.M - 1)};
+            int64_t mo[1];
+            map_rows<1>(amap, one, mo);
+            avoff[j] = row < p.M ? (uint32_t)(mo[0] * 4) + (uint32_t)((int64_t)kl * p.a_ks * 4) : kOobOffset;
+        } else {
+            const int rt = g * 8 + (lane >> 3), cpos = lane & 7;
+            const int c = cpos ^ ((rt >> 1) & 7);
+            row = m0 + rt;
+            akl[j] = 4 * c;
+            extra = 4 * c;
+            const int one[1] = {min(row, p.M - 1)};
+            int64_t mo[1];
+            map_rows<1>(amap, one, mo);
+            avoff[j] = row < p.M ? (uint32_t)((mo[0] + extra) * 4) : kOobOffset;
+        }
+    }
+    // ---- B: one per-lane offset; plane / 16-row block / slice are scalar
+    const __amdgpu_buffer_rsrc_t rsrc_b =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.b_ps), (short)0, (int)bps_bytes, 0x00020000);
+    const uint32_t bvoff = (uint32_t)((n0 + (lane >> 2)) * 64 + (((lane & 3) ^ ((-(lane >> 4)) & 3)) * 16));
+
+    auto dma_b = [&](int it, int buf) { ps_dma_b<C>(rsrc_b, Bs, buf, wave, bvoff, s0 + it, it < nk, n0, np_rows); };
+    auto dma_a = [&](int it, int buf) {
+        const int k0 = kbeg + 32 * it;
+        const uint32_t soff = it < nk ? (uint32_t)(AKM ? (int64_t)k0 * p.a_ks * 4 : (int64_t)k0 * 4) : 0u;
+        ps_dma_a<C>(rsrc_a, As, buf, wave, avoff, akl, k0, kend, soff);
+    };
+
+    f32x4 acc[1][TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[0][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: B(0), A(0) [, A(1)]
+    dma_b(0, 0);
+    dma_a(0, 0);
+    if constexpr (AST == 3) {
+        dma_a(1, 1);
+        ICK_WAIT_VMCNT(C::PA_W);
+    } else {
+        ICK_WAIT_VMCNT(0);
+    }
+    ICK_LDS_BARRIER();
+
+    int abuf = 0;                            // A buffer holding slice `it`
+    for (int it = 0; it < nk; ++it) {
+        const int bbuf = it & 1;
+        // requests first: B one slice ahead, A AST - 1 slices ahead (slices beyond the range are zero fills that touch
+        // no memory: the counts stay constant, so the waits below are immediates)
+        dma_b(it + 1, bbuf ^ 1);
+        {
+            int nb = abuf + (AST - 1);
+            if (nb >= AST) nb -= AST;
+            dma_a(it + AST - 1, nb);
+        }
+        // the wave's A fragment: 16 rows x 32 k, raw fp32 -> three bf16 planes
+        float x[8];
+        const char* at = As + abuf * C::A_STAGE;
+        if constexpr (AKM) {
+            const int pos = (wm * 16 + fi + 16 * fq) & (BM - 1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const float*>(at + ((8 * fq + j) * BM + pos) * 4);
+        } else {
+            const int row = wm * 16 + fi, sw = (row >> 1) & 7;
+            const float4 u = *reinterpret_cast<const float4*>(at + row * 128 + 16 * ((2 * fq) ^ sw));
+            const float4 v = *reinterpret_cast<const float4*>(at + row * 128 + 16 * ((2 * fq + 1) ^ sw));
+            x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
+        }
+        uint32_t h[4], m[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split3(x[2 * j], x[2 * j + 1], h[j], m[j], l[j]);
+        bf16x8_t af[3];
+        af[0] = __builtin_bit_cast(bf16x8_t, u32x4_t{h[0], h[1], h[2], h[3]});
+        af[1] = __builtin_bit_cast(bf16x8_t, u32x4_t{m[0], m[1], m[2], m[3]});
+        af[2] = __builtin_bit_cast(bf16x8_t, u32x4_t{l[0], l[1], l[2], l[3]});
+
+        // B fragments one block ahead of their MFMAs
+        const char* bt = Bs + bbuf * C::B_STAGE;
+        auto read_b = [&](int b, bf16x8_t (&f)[3]) {
+            const int row = (wn * TN + b) * 16 + fi;
+            const char* ptr = bt + row * 64 + 16 * (fq ^ kc_swz(row));
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                f[pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(ptr + pl * C::B_PLANE));
+        };
+        bf16x8_t bf[2][3];
+        read_b(0, bf[0]);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            if (b + 1 < TN) read_b(b + 1, bf[(b + 1) & 1]);
+            f32x4 c = acc[0][b];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[b & 1][2], c, 0, 0, 0);     // smallest products first
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[b & 1][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[b & 1][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[b & 1][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[b & 1][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[b & 1][0], c, 0, 0, 0);
+            acc[0][b] = c;
+        }
+        // B(it + 1) and A(it + 1) have landed (in-order completion: only the A pieces issued last may remain)
+        if constexpr (AST == 3) ICK_WAIT_VMCNT(C::PA_W);
+        else ICK_WAIT_VMCNT(0);
+        ICK_LDS_BARRIER();
+        if (++abuf == AST) abuf = 0;
+    }
+    ICK_WAIT_VMCNT(0);       // the zero fills of the last iterations write LDS too: none may outlive the workgroup
+    gemm_epilogue<1, TN>(p, acc, m0, n0, wm, wn, fi, fq, zid);
+}
+
+
+namespace {
+
+template <class C>
+int launch_ps_cfg(const ick_gemm_args& a, int np_rows, int64_t bytes, int tiles_m, int tiles_n, int kchunk, int split,
+                  hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ps_kernel<C::WM, C::WN, C::TN, C::AKM, C::AST>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_ps_kernel<C::WM, C::WN, C::TN, C::AKM, C::AST>), dim3(tiles_m * tiles_n, 1, split), dim3(C::NT), C::LDS, s, a, np_rows, bytes,
+                       tiles_m, tiles_n, kchunk);
+    ICK_LAUNCH_RET();
+}
+
+}  // namespace
+
+// Called by ick_gemm (gemm.hip) once its plan has chosen the pre-split path.  wide: the 64 x 320 tile (N <= 320).
+int launch_gemm_ps(const ick_gemm_args& a, bool akm, bool wide, int tiles_m, int tiles_n, int kchunk, int split,
+                   hipStream_t s) {
+    const int np = (int)ps_rows(a.N);
+    const int64_t bytes = ps_bytes(a.N, a.K);
+    if (bytes >= ((int64_t)1 << 31)) return ICK_EINVAL;
+    if (wide) {
+        if (akm) return launch_ps_cfg<PsCfg<4, 2, 10, true, 3>>(a, np, bytes, tiles_m, tiles_n, kchunk, split, s);
+        return launch_ps_cfg<PsCfg<4, 2, 10, false, 3>>(a, np, bytes, tiles_m, tiles_n, kchunk, split, s);
+    }
+    if (akm) return launch_ps_cfg<PsCfg<8, 1, 8, true, 2>>(a, np, bytes, tiles_m, tiles_n, kchunk, split, s);
+    return launch_ps_cfg<PsCfg<8, 1, 8, false, 2>>(a, np, bytes, tiles_m, tiles_n, kchunk, split, s);
+}
+
+}  // namespace ick
+
+extern "C" int ick_presplit_bytes(int32_t N, int32_t K, int64_t* bytes) {
+    if (N <= 0 || K <= 0 || !bytes) return ICK_EINVAL;
+    *bytes = ick::ps_bytes(N, K);
+    return ICK_OK;
+}
+
+extern "C" int ick_presplit_weights(const ick_presplit_item* items, int32_t count, void* stream) {
+    using namespace ick;
+    if (!items || count <= 0) return ICK_EINVAL;
+    for (int i0 = 0; i0 < count; i0 += kPsMaxItems) {
+        PsBatch b;
+        b.count = std::min(kPsMaxItems, count - i0);
+        int total = 0;
+        for (int i = 0; i < b.count; ++i) {
+            const ick_presplit_item& it = items[i0 + i];
+            ICK_CHECK_ARG(it.src && it.dst && it.N > 0 && it.K > 0);
+            ICK_CHECK_ARG(it.src_cs == 1 || it.src_rs == 1);
+            ICK_CHECK_ARG((reinterpret_cast<uintptr_t>(it.dst) & 15) == 0);
+            b.it[i] = it;
+            b.first[i] = total;
+            total += ceil_div(it.N, 64) * ceil_div(it.K, 32);
+        }
+        b.first[b.count] = total;
+        hipLaunchKernelGGL(presplit_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, b);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    return ICK_OK;
+}

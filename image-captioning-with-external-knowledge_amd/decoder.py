@@ -123,7 +123,7 @@ class _Conv1Fn(torch.autograd.Function):
         B, Cc, Hh, Ww = feats.shape
         P, d = Hh * Ww, weight.shape[0]
         out = torch.empty(B, P, d, device=feats.device, dtype=torch.float32)
-        ops.gemm_raw(feats, weight.view(d, Cc), out, B * P, d, Cc, 1, P, Cc, 1, d, bias=bias, a_grp=P, a_gs=Cc * P)
+        ops.gemm_raw(feats, weight.detach().view(d, Cc), out, B * P, d, Cc, 1, P, Cc, 1, d, bias=bias, a_grp=P, a_gs=Cc * P)
         ctx.save_for_backward(feats, weight)
         return out
 
@@ -212,8 +212,14 @@ class Encoder(nn.Module):
         out = torch.empty(B, P, d, device=feats.device, dtype=torch.float32)
         w = self.conv1.weight.detach().view(d, Cc)
         ops.gemm_raw(feats, w, out, B * P, d, Cc, 1, P, Cc, 1, d, bias=self.conv1.bias.detach(),
-                     a_grp=P, a_gs=Cc * P)
+                     a_grp=P, a_gs=Cc * P, b_ps=self.conv1_presplit())
         return out.permute(0, 2, 1)
+
+    def conv1_presplit(self):
+        """The pre-split copy of conv1's (emb_dim, encoder_dim) weight for ick_gemm's b_ps (refreshed in place when the
+        weight changes; None in the exact-fp32 product mode)."""
+        w = self.conv1.weight
+        return ops.presplit_cached(self, "conv1", w.detach().view(w.shape[0], -1), (w._version, w.data_ptr()))
 
     def fine_tune(self, fine_tune=True):
         """Convolutional blocks 2-4 of the trunk train iff fine_tune (geo-aware/models.py:49-60); conv1 is left
@@ -340,6 +346,17 @@ class DecoderTransformer(nn.Module):
             cache = (key, w, b)
             self.__dict__["_kv_pack"] = cache
         return cache[1], cache[2]
+
+    def _cross_kv_presplit(self, wkv):
+        """Pre-split copy of the all-layer cross K/V weight (the image rows' projection reads it as b_ps)."""
+        layers = self.transformer_decoder.layers
+        key = tuple(l.multihead_attn.in_proj_weight._version for l in layers) + (
+            wkv.data_ptr(), self.__dict__.get("_param_epoch", 0))
+        return ops.presplit_cached(self, "wkv", wkv, key)
+
+    def _vocab_presplit(self):
+        w = self.fc_vocab.weight
+        return ops.presplit_cached(self, "vocab", w.detach(), (w._version, w.data_ptr(), self.__dict__.get("_param_epoch", 0)))
 
     def _chain_items(self):
         """(key, weight view) of every nn.Linear that a row-chain launch (ops.rowchain_fwd) multiplies with: per layer
@@ -510,6 +527,7 @@ class DecoderTransformer(nn.Module):
             Fn = facts.shape[1]
             fe = ops.fact_encode(facts, ee, self.predicate_embedding.weight.detach())
         wkv, bkv = self._packed_cross_kv()
+        wkv_ps = self._cross_kv_presplit(wkv)
         if self.chain_supported():
             self._chain_pack()      # refreshed (if stale) on the main stream, before the side stream forks
         nseg = wkv.shape[0] // d
@@ -537,10 +555,12 @@ class DecoderTransformer(nn.Module):
             # a chain beside the large projection does not: cfg4 forward 1.84 -> 1.72 ms), the image rows follow
             fact_chain()
             side.flush()
-            ops.project_heads(enc_tok, wkv, bkv, nseg, H, S, out=kv, s0=0, grp=P, a_gmap=gmap, a_gs=enc_tok.stride(0))
+            ops.project_heads(enc_tok, wkv, bkv, nseg, H, S, out=kv, s0=0, grp=P, a_gmap=gmap, a_gs=enc_tok.stride(0),
+                              w_ps=wkv_ps)
         else:
             # image rows (gathered through gmap = sort order)
-            ops.project_heads(enc_tok, wkv, bkv, nseg, H, S, out=kv, s0=0, grp=P, a_gmap=gmap, a_gs=enc_tok.stride(0))
+            ops.project_heads(enc_tok, wkv, bkv, nseg, H, S, out=kv, s0=0, grp=P, a_gmap=gmap, a_gs=enc_tok.stride(0),
+                              w_ps=wkv_ps)
             side.flush()
         ctx_e, ctx_f = ctx
         return ee, fe, kv, (ctx_e, ctx_f), side
@@ -615,7 +635,7 @@ class DecoderTransformer(nn.Module):
             out = torch.empty(B, T, Vx, device=h.device, dtype=torch.float32)
         hv = ops.mul(h, gate) if self.has_facts else h
         ops.gemm_raw(hv, self.fc_vocab.weight.detach(), out, B * T, V, d, d, 1, d, 1, Vx,
-                     bias=self.fc_vocab.bias.detach())
+                     bias=self.fc_vocab.bias.detach(), b_ps=self._vocab_presplit() if B * T >= 256 else None)
         ops.pointer_scores(h, ee, self.fc_entity.weight.detach(), self.fc_entity.bias.detach(), out, V)
         if self.has_facts:
             ops.pointer_scores(h, fe, self.fc_fact.weight.detach(), self.fc_fact.bias.detach(), out, V + K, ind=eib)

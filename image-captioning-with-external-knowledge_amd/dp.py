@@ -64,11 +64,14 @@ def broadcast_bucket(flat, group=None, src=0):
 
 
 def _outside(t, skip):
-    """Is tensor t outside the byte range (lo, hi) of `skip`?"""
+    """Is the whole storage interval [data_ptr, data_ptr + nbytes) of tensor t outside the byte range (lo, hi) of
+    `skip`?  A tensor that straddles an edge of the range counts as outside (it is not covered by the bucket)."""
     if skip is None:
         return True
     lo, hi = skip
-    return not (lo <= t.data_ptr() < hi)
+    a = t.data_ptr()
+    b = a + t.numel() * t.element_size()
+    return not (lo <= a and b <= hi)
 
 
 def module_state(modules, skip_range=None):
@@ -100,30 +103,60 @@ def broadcast_module_state(modules, skip_range=None, group=None, src=0):
 
 
 def module_state_agrees(modules, skip_range=None, group=None):
-    """True when every rank holds bit-identical copies of that state (one checksum all-reduce per tensor dtype)."""
+    """True when every rank holds bit-identical copies of that state, whatever its dtype (the checksum is taken over
+    the raw bytes: int64 buffers such as BatchNorm's num_batches_tracked are not rounded through float32)."""
     if world_size(group) <= 1:
         return True
     ok = True
     for t in module_state(modules, skip_range):
-        if t.dtype == torch.float32:
-            ok = replicas_agree(t, group) and ok
-        else:
-            ok = replicas_agree(t.detach().to(torch.float32), group) and ok
+        ok = replicas_agree(t, group) and ok
     return ok
 
 
+def _raw_words(t):
+    """The bytes of t as int64 values 0..255 (any dtype, any size)."""
+    return t.detach().contiguous().view(-1).view(torch.uint8).to(torch.int64)
+
+
 def replicas_agree(flat, group=None):
-    """True when every rank holds bit-identical `flat` (compares all-reduced MIN and MAX of a 64-bit checksum of the
-    raw bits; cheap enough to call once per epoch)."""
+    """True when every rank holds bit-identical `flat` (compares all-reduced MIN and MAX of two 64-bit checksums of the
+    raw bytes; cheap enough to call once per epoch)."""
     if world_size(group) <= 1:
         return True
-    bits = flat.detach().contiguous().view(-1).view(torch.int32).to(torch.int64)
-    w = torch.arange(1, bits.numel() + 1, device=bits.device, dtype=torch.int64) % 1000003
-    cs = (bits * w).sum().view(1)
+    t = flat.detach().contiguous().view(-1)
+    if t.element_size() % 4 == 0:
+        bits = t.view(torch.int32).to(torch.int64)          # 32-bit words: a quarter of the byte form's work
+    else:
+        bits = _raw_words(t)
+    idx = torch.arange(1, bits.numel() + 1, device=bits.device, dtype=torch.int64)
+    cs = torch.stack([(bits * (idx % 1000003)).sum(), (bits * (idx % 998244353 + 7)).sum()])
     lo, hi = cs.clone(), cs.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
-    return bool((lo == hi).item())
+    return bool((lo == hi).all().item())
+
+
+def time_all_reduce(flat, group=None, repeats=3):
+    """Milliseconds one all_reduce(SUM) of `flat` takes (median of `repeats` after a warm-up, MAX over ranks so that
+    every rank holds the same number).  The bucket's contents are restored (the sum of equal copies would scale it)."""
+    import time
+    if world_size(group) <= 1:
+        return 0.0
+    keep = flat.clone()
+    sync = torch.cuda.synchronize if flat.is_cuda else (lambda: None)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    times = []
+    for _ in range(repeats):
+        sync()
+        dist.barrier(group=group)
+        t0 = time.perf_counter()
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        sync()
+        times.append(time.perf_counter() - t0)
+    flat.copy_(keep)
+    t = torch.tensor([sorted(times)[len(times) // 2] * 1e3], dtype=torch.float64, device=flat.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
 
 
 def reduce_sum_count(loss_sum, count, device=None, group=None):

@@ -34,6 +34,7 @@ class GemmArgs(C.Structure):
         ("drop_p", f32), ("drop_seed", u32), ("drop_site", u32), ("drop_epoch", vp),
         ("a_extent", i64), ("b_extent", i64), ("colsum_a", vp),
         ("gate", vp), ("gate_rs", i64), ("gate_scale", f32),
+        ("b_ps", vp),
     ]
 
 
@@ -77,7 +78,11 @@ class PackItem(C.Structure):
 
 class GemmPlanInfo(C.Structure):
     _fields_ = [(n, i32) for n in ("tile_m", "tile_n", "waves", "tiles_m", "tiles_n", "split_k", "a_kmajor", "b_kmajor",
-                                   "vec", "split_bf16")]
+                                   "vec", "split_bf16", "presplit")]
+
+
+class PresplitItem(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("N", i32), ("K", i32), ("src_rs", i64), ("src_cs", i64)]
 
 
 class AttnArgs(C.Structure):
@@ -137,6 +142,8 @@ SIGNATURES = {
     "ick_gemm_plan": [C.POINTER(GemmArgs), C.POINTER(GemmPlanInfo)],
     "ick_set_gemm_split": [i32],
     "ick_get_gemm_split": [],
+    "ick_presplit_bytes": [i32, i32, C.POINTER(i64)],
+    "ick_presplit_weights": [C.POINTER(PresplitItem), i32, vp],
     "ick_rowchain_supported": [i32, i32, i32],
     "ick_rowchain_fwd": [C.POINTER(RowChainArgs), vp],
     "ick_rowchain_bwd_supported": [i32, i32, i32],

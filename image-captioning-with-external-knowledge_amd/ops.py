@@ -49,10 +49,11 @@ def _dargs(drop):
 
 def gemm_args(A, B, Cout, M, N, K, a_rs, a_ks, b_rs, b_ks, c_rs, bias=None, a_grp=0, a_gs=0, a_gmap=None,
               c_grp=0, c_gs=0, c_gmap=None, relu=False, accumulate=False, atomic=False, split_k=1, alpha=1.0,
-              drop=None, colsum_a=None, gate=None, gate_scale=1.0):
+              drop=None, colsum_a=None, gate=None, gate_scale=1.0, b_ps=None):
     """ick_gemm_args for C[m,n] = act(alpha * sum_k A(m,k) B(n,k) + bias[n]) with explicit element strides; A/B/Cout
     are tensors (only their data pointers are used -- the caller guarantees the strides stay in bounds).
-    colsum_a (k-major A only): colsum_a[m] += sum_k A(m,k)."""
+    colsum_a (k-major A only): colsum_a[m] += sum_k A(m,k).  b_ps: the pre-split copy of the (N, K) matrix B
+    (presplit_weights): large problems then run on the LDS-DMA kernel of csrc/gemm_ps.hip."""
     for t in (A, B, Cout):
         if t.dtype != torch.float32:
             raise L.IckError("ick_gemm operands must be float32, got %s" % t.dtype)
@@ -69,8 +70,54 @@ def gemm_args(A, B, Cout, M, N, K, a_rs, a_ks, b_rs, b_ks, c_rs, bias=None, a_gr
     a.colsum_a = _p(colsum_a)
     if gate is not None:
         a.gate, a.gate_rs, a.gate_scale = _p(gate), gate.stride(0), gate_scale
+    if b_ps is not None:
+        assert b_ps.numel() * b_ps.element_size() == presplit_bytes(N, K), "b_ps is not the pre-split copy of an (N, K) matrix"
+        a.b_ps = _p(b_ps)
     _drop(a, drop)
     return a
+
+
+DEFAULT_GEMM_SPLIT = 1      # the library's product mode when ICK_GEMM_SPLIT is not set (csrc/gemm.hip)
+
+
+def presplit_bytes(N, K):
+    n = L.i64()
+    L.check(L.load_raw().ick_presplit_bytes(int(N), int(K), C.byref(n)), "ick_presplit_bytes")
+    return int(n.value)
+
+
+def presplit_weights(pairs):
+    """[(w (N, K) 2-D view with one unit stride -- a weight or its transposed view, dst uint8 buffer of
+    presplit_bytes(N, K))]: the exact three-way bf16 split of every matrix in the image ick_gemm's b_ps wants
+    (include/ick_amd.h, ick_presplit_weights); up to 16 matrices per launch."""
+    items = (L.PresplitItem * len(pairs))()
+    for it, (src, dst) in zip(items, pairs):
+        assert src.dim() == 2 and src.dtype == torch.float32 and (src.stride(1) == 1 or src.stride(0) == 1)
+        assert dst.numel() * dst.element_size() == presplit_bytes(src.shape[0], src.shape[1])
+        it.src, it.dst, it.N, it.K = _p(src), _p(dst), src.shape[0], src.shape[1]
+        it.src_rs, it.src_cs = src.stride(0), src.stride(1)
+    L.check(L.load().ick_presplit_weights(items, len(pairs), _stream()), "ick_presplit_weights")
+
+
+def presplit_buffer(N, K, device):
+    return torch.empty(presplit_bytes(N, K), device=device, dtype=torch.uint8)
+
+
+def presplit_cached(holder, name, w2d, key):
+    """Persistent pre-split copy of the 2-D weight view `w2d`, kept in holder.__dict__ and refreshed IN PLACE (captured
+    graphs keep reading the same buffer) when `key` (parameter versions / data pointers) changes.  None when the
+    library's product mode is the exact fp32 MFMA: ick_gemm then never looks at it."""
+    if gemm_split_mode() == 0:
+        return None
+    cache = holder.__dict__.setdefault("_ps_cache", {})
+    ent = cache.get(name)
+    nbytes = presplit_bytes(w2d.shape[0], w2d.shape[1])
+    if ent is None or ent[1].numel() != nbytes or ent[1].device != w2d.device:
+        ent = cache[name] = [None, torch.empty(nbytes, device=w2d.device, dtype=torch.uint8)]
+    if ent[0] != key:
+        presplit_weights([(w2d, ent[1])])
+        ent[0] = key
+    return ent[1]
 
 
 def colsum_problem(a2d, out):
@@ -162,7 +209,7 @@ def gemm_grouped(problems):
         L.check(L.load().ick_gemm_grouped(arr, len(chunk), _stream()), "ick_gemm_grouped")
 
 
-def linear(x, w, bias=None, out=None, relu=False, drop=None):
+def linear(x, w, bias=None, out=None, relu=False, drop=None, w_ps=None):
     """y = x @ w.T + bias for x (..., K) with contiguous last dim and uniform row stride, w (N, K)."""
     _f32c(x, "x"); _f32c(w, "w")
     K = x.shape[-1]
@@ -174,7 +221,8 @@ def linear(x, w, bias=None, out=None, relu=False, drop=None):
     if out is None:
         out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32)
     o2 = out.view(-1, N) if out.is_contiguous() else out
-    gemm_raw(x2, w, o2, M, N, K, x2.stride(0), 1, w.stride(0), 1, o2.stride(0), bias=bias, relu=relu, drop=drop)
+    gemm_raw(x2, w, o2, M, N, K, x2.stride(0), 1, w.stride(0), 1, o2.stride(0), bias=bias, relu=relu, drop=drop,
+             b_ps=w_ps)
     return out
 
 
@@ -384,7 +432,7 @@ def attention(q, k, v, H, causal=False):
 DHP = 32  # padded head width of the head-major projection buffers
 
 
-def project_heads(x, w, bias, nseg, H, S, out=None, s0=0, grp=None, a_gmap=None, a_gs=None):
+def project_heads(x, w, bias, nseg, H, S, out=None, s0=0, grp=None, a_gmap=None, a_gs=None, w_ps=None):
     """Packed projection x (B*grp rows, K) @ w.T (nseg*d, K) scattered into the head-major layout
     out (B, nseg, H, S, DHP) at positions s0 .. s0+grp-1 (ick_gemm head-split epilogue)."""
     d = w.shape[0] // nseg
@@ -415,6 +463,9 @@ def project_heads(x, w, bias, nseg, H, S, out=None, s0=0, grp=None, a_gmap=None,
     a.split_k, a.alpha = 1, 1.0
     a.a_extent, a.b_extent = _extent(x2), _extent(w)
     a.hs_dh, a.hs_dhp, a.hs_H, a.hs_S, a.hs_s0 = d // H, DHP, H, S, s0
+    if w_ps is not None:
+        assert w_ps.numel() == presplit_bytes(w.shape[0], K)
+        a.b_ps = _p(w_ps)
     _log_plan(a)
     L.check(L.load().ick_gemm(C.byref(a), _stream()), "ick_gemm(head-split)")
     return out
@@ -830,10 +881,11 @@ SIDE = None   # set by training.TrainStep / backward_from_tape for the duration 
 
 
 def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False, group_now=False, gate=None,
-               gate_scale=1.0):
+               gate_scale=1.0, wt_ps=None):
     """Backward of y = x @ w.T + b for row-major 2-D views dy (M,N), x (M,K), w (N,K):
     dw += dy.T @ x (split-K over M, float atomics), db += colsum(dy), dx = dy @ w.
-    With a SideStream installed the two parameter gradients run beside the data gradient."""
+    With a SideStream installed the two parameter gradients run beside the data gradient.
+    wt_ps: the pre-split copy of w.t() (presplit_weights) -- the data gradient's B operand."""
     M, N = dy.shape
     K = x.shape[1]
 
@@ -871,12 +923,16 @@ def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False, gro
             # the output already holds the residual-path gradient: K slices of ~300 can simply add to it
             # (1280 x 300 x 900: 22 -> ~10 us; the kernel is bound by the latency of its K loop)
             split = max(1, min(8, (N + 150) // 300))
+        if wt_ps is not None and split > 1 and gemm_split_mode() >= 1 and K <= 320:
+            # the pre-split kernel's 64 x 320 tile covers every output column: ~256 workgroups = row tiles x K slices
+            split = max(1, min(16, N // 512, 256 // ((M + 63) // 64)))
         if split > 1:
             if dx is None:
                 dx = torch.zeros(M, K, device=dy.device, dtype=torch.float32)
             elif not accumulate_dx:
                 dx.zero_()
-            gemm_raw(dy, w, dx, M, K, N, dy.stride(0), 1, 1, w.stride(0), dx.stride(0), atomic=True, split_k=split)
+            gemm_raw(dy, w, dx, M, K, N, dy.stride(0), 1, 1, w.stride(0), dx.stride(0), atomic=True, split_k=split,
+                     b_ps=wt_ps)
         else:
             if dx is None:
                 dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)

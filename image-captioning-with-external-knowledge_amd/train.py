@@ -55,6 +55,9 @@ class Config:
     loader_threads: int = 4                            # TRAIN batches fetched by threads of this process (0: DataLoader
                                                        # worker processes, `workers` of them, as the reference)
     half_features: bool = True                         # float16 feature files travel as float16, widened on the device
+    deterministic: object = None                       # True / False: fixed-order reductions on / off; None: what
+                                                       # ICK_DETERMINISTIC says at the time main() runs, else the
+                                                       # library's current mode
 
 
 def _batch_to_device(batch, device, has_facts):
@@ -361,8 +364,11 @@ def main(cfg=None):
         # seed: the dropout stream, one per rank (the ranks hold different samples); the constructor broadcasts rank
         # 0's weights, so a decoder that was randomly initialised per process starts identical everywhere
         # encoder=: with the frozen encoder the step takes the feature map itself (Encoder.conv1 inside the captured step)
+        det = cfg.deterministic
+        if det is None and os.environ.get("ICK_DETERMINISTIC") is not None:
+            det = os.environ["ICK_DETERMINISTIC"] not in ("", "0")      # the script's switch, read when main() runs
         step = TrainStep(decoder, lr=cfg.decoder_lr, grad_clip=cfg.grad_clip, seed=cfg.seed * 1000 + rank,
-                         encoder=encoder if cfg.prefetch else None)
+                         encoder=encoder if cfg.prefetch else None, deterministic=det)
         if decoder_optimizer is not None:
             # resume: Adam moments, step count (bias correction + dropout stream position) and the decayed lr come
             # back from the pickled optimizer (ours or one written by the reference, geo-aware/utils.py:32-46)

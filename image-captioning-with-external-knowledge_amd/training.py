@@ -237,10 +237,10 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     conv1_done = False
     if head_on_side:
         ev0 = side.mark()
-        cw, cb = conv1
+        cw, cb = conv1[0], conv1[1]
         Cc = feats.shape[1]
         ops.gemm_raw(feats, cw.view(d, Cc), mem, B * P, d, Cc, 1, P, Cc, 1, d, bias=cb, a_grp=P, a_gs=Cc * P,
-                     c_grp=P, c_gs=S * d)
+                     c_grp=P, c_gs=S * d, b_ps=conv1[2] if len(conv1) > 2 else None)
         conv1_done = True
 
     chain = dec.chain_supported()
@@ -274,6 +274,21 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         # first), the decoder layers' after Encoder.conv1 has been enqueued, the transposed copies of the backward
         # chains on the side stream once the context chain is done (it idles until the backward pass).
         pk = dec._chain_pack(fresh=fresh_pack, subset=first if staged else None, copies=copies) if chain else None
+        # pre-split copies (three bf16 planes) of the weights the large GEMMs multiply with: the all-layer cross K/V
+        # weight, fc_vocab, and fc_vocab transposed for its data gradient (ick_gemm's b_ps, csrc/gemm_ps.hip)
+        if ops.gemm_split_mode() >= 1 and not ops.is_deterministic():
+            vw = _p(dec.fc_vocab.weight)
+            if fresh_pack:
+                m["wkv_ps"] = ops.presplit_buffer(nseg * d, d, dev)
+                m["vocab_ps"] = ops.presplit_buffer(V, d, dev)
+                m["vocab_t_ps"] = ops.presplit_buffer(d, V, dev)
+                ops.presplit_weights([(wkv, m["wkv_ps"]), (vw, m["vocab_ps"]), (vw.t(), m["vocab_t_ps"])])
+            else:
+                m["wkv_ps"] = dec._cross_kv_presplit(wkv)
+                m["vocab_ps"] = dec._vocab_presplit()
+                w_ = dec.fc_vocab.weight
+                m["vocab_t_ps"] = ops.presplit_cached(dec, "vocab_t", vw.t(), (w_._version, w_.data_ptr(),
+                                                                              dec.__dict__.get("_param_epoch", 0)))
         return ee, fe, wkv, bkv, pk
 
     if head_on_side:
@@ -332,10 +347,10 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     if conv1_done:
         pass
     elif feats is not None:
-        cw, cb = conv1
+        cw, cb = conv1[0], conv1[1]
         Cc = feats.shape[1]
         ops.gemm_raw(feats, cw.view(d, Cc), mem, B * P, d, Cc, 1, P, Cc, 1, d, bias=cb, a_grp=P, a_gs=Cc * P,
-                     c_grp=P, c_gs=S * d)
+                     c_grp=P, c_gs=S * d, b_ps=conv1[2] if len(conv1) > 2 else None)
     else:
         mem[:, :P].copy_(img)
     if side is not None:
@@ -355,7 +370,7 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     # One GEMM for the image rows of every layer.  Projecting the later layers' rows on the side stream after the
     # chain was measured (device time stamps): the chain ends 70 us earlier, the first decoder layer 90 us later --
     # a 5000-workgroup GEMM beside a chain of small kernels delays the chain by about its own duration either way.
-    ops.project_heads(img, wkv, bkv, nseg, H, S, out=kv, s0=0, grp=P)
+    ops.project_heads(img, wkv, bkv, nseg, H, S, out=kv, s0=0, grp=P, w_ps=m.get("wkv_ps"))
     ops.stamp("fwd: image K/V projection done")
     if early is None:
         layer0_self_block()
@@ -379,7 +394,7 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     ld = (Vx + 3) // 4 * 4
     scores = torch.empty(B, L, ld, device=x.device, dtype=torch.float32)[:, :, :Vx]
     ops.gemm_raw(hv if dec.has_facts else x, _p(dec.fc_vocab.weight), scores, B * L, V, d, d, 1, d, 1, ld,
-                 bias=_p(dec.fc_vocab.bias))
+                 bias=_p(dec.fc_vocab.bias), b_ps=m.get("vocab_ps"))
     ops.pointer_scores(x, ee, _p(dec.fc_entity.weight), _p(dec.fc_entity.bias), scores, V)
     if dec.has_facts:
         ops.pointer_scores(x, fe, _p(dec.fc_fact.weight), _p(dec.fc_fact.bias), scores, V + K, ind=eib)
@@ -401,7 +416,7 @@ def _g(grads, param):
 
 
 def _lin_bwd(grads, dy2, x2, lin_w, lin_b, w_rows=None, need_dx=True, dx=None, acc=False, group_now=False,
-             gate=None, gate_scale=1.0):
+             gate=None, gate_scale=1.0, wt_ps=None):
     """Backward of a Linear whose weight is `lin_w` (optionally the row slice w_rows of it)."""
     gw, gb = _g(grads, lin_w), _g(grads, lin_b)
     w = _p(lin_w)
@@ -410,7 +425,7 @@ def _lin_bwd(grads, dy2, x2, lin_w, lin_b, w_rows=None, need_dx=True, dx=None, a
         gw = gw[w_rows] if gw is not None else None
         gb = gb[w_rows] if gb is not None else None
     return ops.linear_bwd(dy2, x2, w, gw, gb, need_dx=need_dx, dx=dx, accumulate_dx=acc, group_now=group_now,
-                          gate=gate, gate_scale=gate_scale)
+                          gate=gate, gate_scale=gate_scale, wt_ps=wt_ps)
 
 
 def _prezeroed(dec, captions, entities, facts):
@@ -736,10 +751,10 @@ def _backward_phases(dec, tape, dscores, grads, want_image_grad=False):
     if dhv0 is not None and dhv0.shape == (M, d) and not ops.is_deterministic():
         # split-K partial sums add into the buffer the forward pass's side stream zeroed
         dhv = _lin_bwd(grads, dsc2[:, :V], hv.view(M, d), dec.fc_vocab.weight, dec.fc_vocab.bias, dx=dhv0, acc=True,
-                       group_now=True).view(B, L, d)
+                       group_now=True, wt_ps=m.get("vocab_t_ps")).view(B, L, d)
     else:
         dhv = _lin_bwd(grads, dsc2[:, :V], hv.view(M, d), dec.fc_vocab.weight, dec.fc_vocab.bias,
-                       group_now=True).view(B, L, d)
+                       group_now=True, wt_ps=m.get("vocab_t_ps")).view(B, L, d)
     if dec.has_facts:
         dh = ops.mul(dhv, m["gate"])
         dgate = ops.mul(dhv, h)
@@ -880,11 +895,14 @@ class TrainStep:
         self.dec = decoder
         # deterministic (default: ICK_DETERMINISTIC=1 in the environment): the library's fixed-order reductions, no
         # split GEMMs, everything on one stream -- two runs of the same steps end bit-identical (cost: DESIGN.md)
+        # None inherits the library's current mode (ick_get_deterministic: ICK_DETERMINISTIC in the environment unless
+        # ops.set_deterministic was called); only an explicit True / False changes the process-wide flag, and a step
+        # refuses to run when the flag no longer is what its graphs were captured under.
         if deterministic is None:
-            deterministic = os.environ.get("ICK_DETERMINISTIC", "0") not in ("", "0")
+            deterministic = ops.is_deterministic()
+        else:
+            ops.set_deterministic(bool(deterministic))
         self.deterministic = bool(deterministic)
-        if self.deterministic or ops.is_deterministic():
-            ops.set_deterministic(self.deterministic)
         # with an encoder the step also accepts the (B, 2048, 14, 14) feature map: Encoder.conv1 (frozen, as in the
         # reference's default fine_tune_encoder=False) then runs inside graph A straight into the memory buffer
         self.enc = encoder
@@ -926,14 +944,23 @@ class TrainStep:
         # several ranks: every replica starts from rank 0's weights (a freshly built decoder is randomly initialised
         # per process; the reference has a single process, geo-aware/train.py:16-18).  One broadcast of the bucket.
         dp.broadcast_bucket(self.flat_p, self.pg)
-        # Several ranks: the step runs as two graphs around two all-reduces -- the early half of the bucket (score head,
-        # decoder stack: gradients complete first) travels while the late half (cross K/V projection, context encoders,
-        # embeddings) is computed, and only the late half's all-reduce is exposed.  Measured on one GPU the split itself
-        # costs ~130 us (a join in the middle of the backward pass, one more graph launch); the 45.7 MB all-reduce of cfg2
-        # is 0.3-0.5 ms on xGMI by SURVEY.md 5's link arithmetic, so with ranks > 1 the split is the default.  Same bits
-        # as the single all-reduce (tests/test_deterministic_gpu.py).  ICK_SPLIT_ALLREDUCE=0 / 1 overrides.
-        env = os.environ.get("ICK_SPLIT_ALLREDUCE")
-        self.split = (env != "0") if env not in (None, "") else dp.world_size(self.pg) > 1
+        # Several ranks, ICK_SPLIT_ALLREDUCE=1: the step runs as two graphs around two all-reduces -- the early half of
+        # the bucket (score head, decoder stack: gradients complete first) travels while the late half (cross K/V
+        # projection, context encoders, embeddings) is computed, and only the late half's all-reduce is exposed.  Measured
+        # on one GPU the split itself costs ~130 us (a join in the middle of the backward pass, one more graph launch),
+        # and nothing has been measured on a multi-GPU node to win that back, so the DEFAULT IS OFF (one all-reduce
+        # between graph A and graph B) until a scaling run shows the gain; same bits either way
+        # (tests/test_deterministic_gpu.py).  ICK_SPLIT_ALLREDUCE=auto decides from a timed all-reduce of the bucket at
+        # construction (split when the collective costs more than twice what the split does; every rank takes the
+        # max-reduced time, so every rank decides alike).  allreduce_probe_ms keeps that measurement for bench.py.
+        env = os.environ.get("ICK_SPLIT_ALLREDUCE", "0")
+        self.allreduce_probe_ms = None
+        if dp.world_size(self.pg) > 1 and (env == "auto" or os.environ.get("ICK_ALLREDUCE_PROBE") == "1"):
+            self.allreduce_probe_ms = dp.time_all_reduce(self.flat_g, self.pg)
+        if env == "auto":
+            self.split = self.allreduce_probe_ms is not None and self.allreduce_probe_ms > 0.26
+        else:
+            self.split = env not in ("", "0")       # an explicit 1 also splits a single rank's step (tests, A/B runs)
 
     # ---- device-only halves -------------------------------------------------------------------
     def _overlap(self, off_switch):
@@ -947,7 +974,7 @@ class TrainStep:
     def _enc_kwargs(self, enc_in):
         if enc_in.dim() == 4:
             c1 = self.enc.conv1
-            return dict(enc_tok=None, feats=enc_in, conv1=(c1.weight.detach(), c1.bias.detach()))
+            return dict(enc_tok=None, feats=enc_in, conv1=(c1.weight.detach(), c1.bias.detach(), self.enc.conv1_presplit()))
         return dict(enc_tok=enc_in)
 
     def _part_a(self, captions, caption_masks, entities, facts, enc_in, gmap, lengths):
@@ -1153,11 +1180,17 @@ class TrainStep:
             if self.enc is None:
                 raise IckError("TrainStep got a (B, C, H, W) feature map but was built without encoder=")
             enc_in = encoder_out
+            self.enc.conv1_presplit()      # refreshed in place, OUTSIDE the captured graphs, if conv1's weight changed
         else:
             enc_in = dec._token_major(encoder_out)
         lengths = caption_lengths.to(dev, non_blocking=True)
         inputs = [captions, caption_masks, entities, facts, enc_in, None, lengths]
-        key = tuple(None if t is None else tuple(t.shape) for t in inputs)
+        if ops.is_deterministic() != self.deterministic:
+            raise IckError("the library's deterministic mode is %s but this TrainStep was built with %s: captured graphs "
+                           "keep the mode they were captured in (call ops.set_deterministic before building the step)"
+                           % (ops.is_deterministic(), self.deterministic))
+        # the large GEMM tiles' product mode is baked into a capture as well
+        key = tuple(None if t is None else tuple(t.shape) for t in inputs) + (ops.gemm_split_mode(),)
         if self.use_graph and key not in self._graphs:
             if len(self._graphs) >= 4:
                 self._graphs.clear()

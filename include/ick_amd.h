@@ -79,6 +79,11 @@ typedef struct {
                                      applied last -- the ReLU (+ dropout) backward of the FFN rides on the data-gradient
                                      GEMM of linear2 (gate = the saved activation, gate_scale = 1/(1-p)) */
     int64_t gate_rs; float gate_scale;
+    const void* b_ps;             /* optional: the pre-split copy of B (ick_presplit_weights of the same (N, K) matrix).  With
+                                     it, and the split-bf16 product mode on, large problems run on the kernel that stages both
+                                     operands by LDS-DMA and splits only the A fragments (csrc/gemm_ps.hip); B itself must
+                                     still be valid (the other kernels read it).  The caller refreshes the copy whenever B
+                                     changes (training: once per step, in the packing launches) */
 } ick_gemm_args;
 
 #define ICK_GEMM_RELU 1
@@ -95,14 +100,30 @@ typedef struct {
     int32_t tile_m, tile_n, waves, tiles_m, tiles_n, split_k, a_kmajor, b_kmajor, vec;
     int32_t split_bf16;   /* 1: products formed as six bf16 x bf16 partial products of the exact three-way bf16 split of
                            * both fp32 operands, accumulated in fp32 (64x64 / 128x64 tiles); 0: v_mfma_f32_16x16x4_f32 */
+    int32_t presplit;     /* 1: the B operand is read from its pre-split copy (b_ps): 64 x 320 or 128 x 128 tiles of
+                           * csrc/gemm_ps.hip, both operands staged by LDS-DMA */
 } ick_gemm_plan_info;
 int ick_gemm_plan(const ick_gemm_args* args, ick_gemm_plan_info* out);
-/* Process-wide mode of the split-bf16 product path of the large GEMM tiles.  0 (default; environment ICK_GEMM_SPLIT
- * unset): every product on the exact fp32 MFMA.  1: split products where they are faster (B operand k-contiguous: forward
- * GEMMs, Encoder.conv1).  2: for every large-tile problem.  The split is exact (x = hi + mid + lo in bf16), six of the
+/* Process-wide mode of the split-bf16 product path of the large GEMM tiles.  0: every product on the exact fp32 MFMA
+ * (v_mfma_f32_16x16x4_f32).  1 (DEFAULT; environment ICK_GEMM_SPLIT overrides): split products where they are faster (B
+ * operand k-contiguous or pre-split: forward GEMMs, Encoder.conv1, the vocabulary data gradient).  2: for every large-tile
+ * problem.  The split is exact (x = hi + mid + lo in bf16), six of the
  * nine partial products are formed; error against fp64 no larger than the exact path's (tests/test_gemm_split_gpu.py). */
 int ick_set_gemm_split(int mode);
 int ick_get_gemm_split(void);
+/* Pre-split copies of weight matrices for ick_gemm's b_ps: the exact three-way bf16 split (hi + mid + lo) of the (N, K)
+ * matrix whose element (n, k) is src[n * src_rs + k * src_cs] (one of the two strides must be 1: a weight or its
+ * transposed view), stored as dst[K slice of 32][plane hi | mid | lo][row n, padded to a multiple of 64][32 k] bf16 with
+ * zeros beyond N and K -- the image the matrix cores' B operand is read in.  ick_presplit_bytes gives the size of dst
+ * (16-byte aligned).  One launch for up to 16 matrices.  Call sites: the weights of Encoder.conv1, of the all-layer cross
+ * K/V projection and of fc_vocab (and fc_vocab's transposed view for its data gradient), geo-aware/models.py:32,241-242,303. */
+typedef struct {
+    const float* src; void* dst;
+    int32_t N, K;
+    int64_t src_rs, src_cs;
+} ick_presplit_item;
+int ick_presplit_bytes(int32_t N, int32_t K, int64_t* bytes);
+int ick_presplit_weights(const ick_presplit_item* items, int32_t count, void* stream);
 /* `count` (<= 64) independent problems; those that select the same kernel configuration share one launch (up to 8
  * per launch).  Used for the weight-gradient GEMMs of a layer (geo-aware/train.py:284 `loss.backward()`), each of
  * which alone is a latency-bound launch of a few hundred workgroups. */

@@ -178,13 +178,29 @@ def digest_columns(Vx, V, n=128, seed=0):
     return torch.cat([cols, torch.arange(V, Vx)])
 
 
-def big_vocab_digest(name, variant, B, L, K, V, Fn, seed):
+def big_vocab_digest(name, variant, B, L, K, V, Fn, seed, conv1=False):
     """The reference's forward at a vocabulary too wide to store whole (cfg4: 64 x 20 x 50 071 floats = 256 MB): the
     fixture keeps 128 sampled vocabulary columns, every pointer column, and per-row logsumexp / argmax / max over ALL
     columns (any wrong vocabulary column moves the logsumexp or the argmax), plus the loss of train.py's criterion."""
     dec, P, wm = build_reference_decoder(variant, V, seed)
     batch = synth.make_batch(variant, B, L, K, V, Fn, seed)
-    enc_out = synth.make_enc_out(B, seed)
+    extra = {}
+    if conv1:
+        # the whole bench step's input: 14 x 14 x 2048 features through the stock nn.Conv2d(2048, 300, 1) + view that is
+        # the hot-path part of the reference's Encoder (geo-aware/models.py:32,45-46; Encoder itself cannot be built
+        # offline), then the reference's DecoderTransformer.forward on its output
+        w, b = synth.make_conv1(seed)
+        conv = torch.nn.Conv2d(2048, 300, 1)
+        with torch.no_grad():
+            conv.weight.copy_(w)
+            conv.bias.copy_(b)
+            enc_out = conv(synth.make_feats(B, seed)).view(B, 300, -1)
+        g = torch.Generator().manual_seed(seed)
+        pos = torch.randperm(196, generator=g)[:8].sort().values
+        extra = dict(conv1=1, enc_pos=pos.numpy(), enc_out_pos=enc_out[:, :, pos].numpy(),
+                     enc_out_sum=enc_out.double().sum(dim=(1, 2)).numpy())
+    else:
+        enc_out = synth.make_enc_out(B, seed)
     args = [batch["captions"], enc_out, batch["caption_masks"], batch["caption_lengths"], batch["entities"]]
     if variant != "geo":
         args.append(batch["facts"])
@@ -200,7 +216,7 @@ def big_vocab_digest(name, variant, B, L, K, V, Fn, seed):
                         param_checksum=checksum(P), cols=cols.numpy(), scores_cols=scores[:, :, cols].numpy(),
                         lse=scores.double().logsumexp(dim=2).numpy(), argmax=scores.argmax(dim=2).numpy(),
                         rowmax=scores.max(dim=2).values.numpy(), captions_sorted=caps_sorted.numpy(),
-                        decode_lengths=np.array(dl), loss=np.array([loss.item()]))
+                        decode_lengths=np.array(dl), loss=np.array([loss.item()]), **extra)
     print("wrote", name, tuple(scores.shape), "loss", loss.item())
 
 
@@ -245,9 +261,19 @@ def round3_cases():
     big_vocab_digest("digest_news_v50k", "news", B=8, L=20, K=51, V=50000, Fn=51, seed=42)
 
 
+def round4_cases():
+    """Added in round 4: the headline workload itself -- cfg2 at its bench batch (B = 64, L = 20,
+    K = 20, V = 10 000), features -> stock conv1 -> the real reference's forward -- in the digest layout of cfg4."""
+    c = synth.CONFIGS["cfg2"]
+    big_vocab_digest("digest_cfg2_b64", c["variant"], c["B"], c["L"], c["K"], c["V"], c["F"], seed=44, conv1=True)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(4)
+    if "--round4" in sys.argv:
+        round4_cases()
+        sys.exit(0)
     if "--round3" in sys.argv:
         round3_cases()
         sys.exit(0)

@@ -44,7 +44,7 @@ def make_encoder(seed):
     return enc.cuda().eval(), cw, cb
 
 
-def test_conv1_at_bench_batch(plan_log):
+def test_conv1_at_bench_batch(plan_log, gemm_split):
     """B=64: M = 64*196 = 12 544 rows, the shape whose kernel bench.py's roofline block times."""
     B, seed = 64, 21
     enc, cw, cb = make_encoder(seed)
@@ -57,6 +57,18 @@ def test_conv1_at_bench_batch(plan_log):
     assert len(pl) == 1
     # the long-K narrow-N instantiation (a dispatch change must update this line AND keep the parity above)
     assert pl[0]["vec"] == 1 and pl[0]["a_kmajor"] == 1 and (pl[0]["tile_m"], pl[0]["tile_n"]) == ick_amd.ops.CONV1_TILE
+    assert pl[0]["split_bf16"] == (1 if gemm_split else 0)
+
+
+_REF_STEPS = {}
+
+
+def reference_train_step_cached(key, cfg, P, batch, enc_out):
+    """The oracle's step is the same for every product mode of the GEMM tiles: computed once per case."""
+    if key not in _REF_STEPS:
+        _REF_STEPS.clear()              # one case at a time (cfg4's gradients are 160 MB)
+        _REF_STEPS[key] = reference_train_step(cfg, P, batch, enc_out)
+    return _REF_STEPS[key]
 
 
 def reference_train_step(cfg, P, batch, enc_out, lr=4e-4, clip=5.0):
@@ -84,7 +96,7 @@ def run_train_step_vs_oracle(variant, B, L, K, V, Fn, seed, plan_log):
     cfg = R.config_from_word_map(variant, wm)
     batch = synth.make_batch(variant, B, L, K, V, Fn, seed)
     enc_out = synth.make_enc_out(B, seed)
-    loss_ref, grads_ref, P_after = reference_train_step(cfg, P, batch, enc_out)
+    loss_ref, grads_ref, P_after = reference_train_step_cached((variant, B, L, K, V, Fn, seed), cfg, P, batch, enc_out)
     dec = zero_dropout(build_decoder(variant, V, P).train())
     ts = TrainStep(dec, lr=4e-4, grad_clip=5.0)      # use_graph=True: the captured step the bench replays
     args = [batch["captions"].cuda(), enc_out.cuda(), batch["caption_masks"].cuda(), batch["caption_lengths"].cuda(),
@@ -140,7 +152,7 @@ def run_train_step_vs_oracle(variant, B, L, K, V, Fn, seed, plan_log):
     return ts, plan_log
 
 
-def test_cfg2_train_step_vs_oracle(plan_log):
+def test_cfg2_train_step_vs_oracle(plan_log, gemm_split):
     """The bench workload itself: B=64, L=20, K=20, V=10 000 (1280 decode positions, score width 10 020)."""
     c = synth.CONFIGS["cfg2"]
     B, L, K, V = c["B"], c["L"], c["K"], c["V"]
@@ -151,6 +163,8 @@ def test_cfg2_train_step_vs_oracle(plan_log):
     assert vocab_fwd and vocab_dgrad, "vocabulary GEMMs were not logged"
     assert vocab_fwd[0]["tile_m"] >= 64 and vocab_fwd[0]["vec"] == 1      # large tiles above 512 workgroups
     assert vocab_dgrad[0]["split_k"] >= 2                                  # long reduction split over workgroups
+    assert vocab_fwd[0]["split_bf16"] == (1 if gemm_split else 0)          # the product mode under test really ran
+    assert vocab_dgrad[0]["split_bf16"] == (1 if gemm_split == 2 else 0)   # k-major B operand: only in mode 2
     kv = plans_of(log, B * 196, 1800, 300)
     assert kv and kv[0]["tile_m"] >= 64
     assert (V + K) % 4 == 0 and V + K <= 10240      # => packed CE keeps these rows in registers (score_head.hip)

@@ -216,7 +216,15 @@ def _state_worker(rank, world, port, out):
     before = dp.module_state_agrees([enc, dec], rng)
     n = dp.broadcast_module_state([enc, dec], rng)
     after = dp.module_state_agrees([enc, dec], rng)
-    torch.save({"before": before, "after": after, "n": n, "conv": enc.weight.detach().clone(), "pe": dec.pe.clone(),
+    # raw-byte checksums: an int64 buffer that differs only beyond float32's 24 bits, a bool mask, and a
+    # tensor that merely STARTS inside the bucket range but ends outside it is not "covered by the bucket"
+    big = dp.replicas_agree(torch.tensor([2 ** 30 + rank, 7], dtype=torch.int64))
+    big_same = dp.replicas_agree(torch.tensor([2 ** 30 + 1, 7], dtype=torch.int64))
+    flags = dp.replicas_agree(torch.tensor([True, rank == 0, True]))
+    outside = dp._outside(torch.empty(0).set_(bucket.untyped_storage(), 60, (4,)), (rng[0], rng[0] + 4 * 62))
+    inside = dp._outside(bucket[4:8], rng)
+    torch.save({"before": before, "after": after, "n": n, "big": big, "big_same": big_same, "flags": flags,
+                "outside": outside, "inside": inside, "conv": enc.weight.detach().clone(), "pe": dec.pe.clone(),
                 "w": dec.weight.detach().clone(), "bias": dec.bias.detach().clone()}, out + str(rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -231,3 +239,5 @@ def test_two_rank_broadcast_of_state_outside_the_bucket(tmp_path):
     for k in ("conv", "pe", "w"):
         assert torch.equal(r0[k], r1[k]), k
     assert not torch.equal(r0["bias"], r1["bias"])             # inside the bucket range: left to TrainStep's broadcast
+    for r in (r0, r1):
+        assert not r["big"] and r["big_same"] and not r["flags"] and r["outside"] and not r["inside"]

@@ -1,4 +1,4 @@
-"""Split-bf16 products of the large GEMM tiles (ick_set_gemm_split; csrc/gemm.hip, opt-in).
+"""Split-bf16 products of the large GEMM tiles (ick_set_gemm_split; csrc/gemm.hip, csrc/gemm_ps.hip; mode 1 is the default).
 
 Every fp32 operand value is split exactly into three bf16 numbers, six of the nine partial products run on the bf16
 matrix pipe with fp32 accumulation.  The claim tested here: against an fp64 product of the same fp32 operands the split
@@ -19,8 +19,9 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture()
 def ops():
     from ick_amd import ops as o
+    before = o.gemm_split_mode()
     yield o
-    o.set_gemm_split(0)
+    o.set_gemm_split(before)
 
 
 def rnd(*shape, seed, scale=1.0):
@@ -35,10 +36,11 @@ def errs(out, ref):
 
 def both(ops, fn):
     res = []
+    before = ops.gemm_split_mode()
     for mode in (0, 2):
         ops.set_gemm_split(mode)
         res.append(fn())
-    ops.set_gemm_split(0)
+    ops.set_gemm_split(before)
     return res
 
 
@@ -149,6 +151,7 @@ def test_forward_scores_with_split_products_match_the_exact_path():
     feats = synth.make_feats(B, 3).cuda()
     dec = build_decoder(variant, V, P).eval()
     res = []
+    before = o.gemm_split_mode()
     try:
         for mode in (0, 1):
             o.set_gemm_split(mode)
@@ -158,7 +161,7 @@ def test_forward_scores_with_split_products_match_the_exact_path():
                               batch["caption_lengths"].cuda(), batch["entities"])
             res.append(s.clone())
     finally:
-        o.set_gemm_split(0)
+        o.set_gemm_split(before)
     d = (res[0] - res[1]).abs().max().item()
     assert d < 1e-5 * max(1.0, res[0].abs().max().item()), d
     assert torch.equal(res[0].argmax(-1), res[1].argmax(-1))
@@ -178,6 +181,7 @@ def test_train_step_with_split_products_matches_the_exact_path():
     enc = ick_amd.load_models(variant).Encoder(emb_dim=300).cuda().eval()
     feats = synth.make_feats(B, 5).cuda()
     res = []
+    before = o.gemm_split_mode()
     try:
         for mode in (0, 2):
             o.set_gemm_split(mode)
@@ -186,9 +190,117 @@ def test_train_step_with_split_products_matches_the_exact_path():
             loss = ts(batch["captions"], feats, batch["caption_masks"], batch["caption_lengths"], batch["entities"])
             res.append((loss.item(), ts.flat_g.clone(), ts.n))
     finally:
-        o.set_gemm_split(0)
+        o.set_gemm_split(before)
     (l0, g0, n), (l1, g1, _) = res
     assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0)), (l0, l1)
     assert g0[n + 1].item() == g1[n + 1].item()
     scale = g0[:n].abs().max().item()
     assert (g0[:n] - g1[:n]).abs().max().item() < 2e-5 * max(scale, 1e-3), ((g0[:n] - g1[:n]).abs().max().item(), scale)
+
+
+# ------------------------------------------------------------------------------------------------ pre-split B operand
+def bf16_planes(buf, N, K):
+    """(S, 3, Np, 32) float64 view of a pre-split copy."""
+    S, Np = (K + 31) // 32, (N + 63) // 64 * 64
+    return buf.view(torch.bfloat16).view(S, 3, Np, 32).double()
+
+
+@pytest.mark.parametrize("N,K,transposed", [(300, 2048, False), (1800, 300, False), (300, 10000, True), (70, 45, False),
+                                            (130, 33, True)])
+def test_presplit_copy_is_the_exact_three_way_split(ops, N, K, transposed):
+    """hi + mid + lo reproduces every fp32 weight EXACTLY (three bf16 numbers carry the 24-bit significand), the planes
+    are ordered by magnitude, rows beyond N and k beyond K are zero."""
+    w = (rnd(K, N, seed=5).t() if transposed else rnd(N, K, seed=5))
+    w = w * torch.logspace(-6, 3, N, device="cuda").view(N, 1)
+    buf = ops.presplit_buffer(N, K, "cuda")
+    buf.fill_(0x7f)
+    ops.presplit_weights([(w, buf)])
+    pl = bf16_planes(buf, N, K)
+    S, Np = pl.shape[0], pl.shape[2]
+    full = pl.permute(1, 2, 0, 3).reshape(3, Np, S * 32)        # (plane, n, k)
+    rec = full.sum(0)
+    assert torch.equal(rec[:N, :K], w.double())
+    assert rec[N:].abs().max().item() == 0 if Np > N else True
+    assert rec[:, K:].abs().max().item() == 0 if S * 32 > K else True
+    assert (full[1].abs() <= full[0].abs() * 2.0 ** -8 + 1e-45).all() and (full[2].abs() <= full[0].abs() * 2.0 ** -16 + 1e-45).all()
+
+
+@pytest.mark.parametrize("M,N,K,akm,grp,split_k,tile", [
+    (12544, 300, 2048, True, 196, 1, (64, 320)),      # Encoder.conv1: k-major NCHW map, 196 positions per sample
+    (1280, 300, 10000, False, 0, 12, (64, 320)),      # vocabulary data gradient: split K, atomics
+    (1280, 10000, 300, False, 0, 1, (128, 128)),      # vocabulary projection (K tail of 12)
+    (12544, 1800, 300, False, 0, 1, (128, 128)),      # cross K/V projection of the image rows
+    (2052, 132, 516, False, 0, 1, (64, 320)),         # ragged: M tail, N < 320 (pieces beyond the padded rows), K tail of 4
+    (2052, 1028, 516, False, 0, 1, (128, 128)),       # ragged edges of the square tile
+    (2052, 1028, 516, True, 0, 1, (128, 128)),        # k-major A on the square tile
+    (2052, 260, 100, True, 0, 1, (64, 320)),          # k-major A, K tail of 4 k lines
+])
+def test_presplit_gemm_error_not_above_exact_path(ops, M, N, K, akm, grp, split_k, tile):
+    if grp:
+        Bn = M // grp
+        A = rnd(Bn, K, grp, seed=1)                    # (sample, k, position): element (m, k) = A[m // grp, k, m % grp]
+        Amat = A.permute(0, 2, 1).reshape(M, K).double()
+    else:
+        A = rnd(K, M, seed=1) if akm else rnd(M, K, seed=1)
+        Amat = A.double().t() if akm else A.double()
+    W = rnd(N, K, seed=2, scale=0.1)
+    bias = rnd(N, seed=3)
+    ref = Amat @ W.double().t() + (bias.double() if split_k == 1 else 0)
+    ps = ops.presplit_buffer(N, K, "cuda")
+    ops.presplit_weights([(W, ps)])
+
+    def run(b_ps):
+        out = torch.zeros(M, N, device="cuda")
+        if grp:
+            args = (A, W, out, M, N, K, 1, grp, K, 1, N)
+            kw = dict(a_grp=grp, a_gs=K * grp)
+        else:
+            args = (A, W, out, M, N, K, 1 if akm else K, M if akm else 1, K, 1, N)
+            kw = {}
+        kw.update(atomic=split_k > 1, split_k=split_k, bias=bias if split_k == 1 else None, b_ps=b_ps)
+        info = plan_of(ops, ops.gemm_args(*args, **kw))
+        ops.gemm_raw(*args, **kw)
+        torch.cuda.synchronize()
+        return out, info
+
+    before = ops.gemm_split_mode()
+    ops.set_gemm_split(0)
+    exact, pe = run(ps)
+    ops.set_gemm_split(1)
+    split, pp = run(ps)
+    ops.set_gemm_split(before)
+    assert pe.presplit == 0 and pe.split_bf16 == 0
+    assert pp.presplit == 1 and pp.split_bf16 == 1 and (pp.tile_m, pp.tile_n) == tile and pp.split_k == split_k
+    emax, erms = errs(exact, ref)
+    smax, srms = errs(split, ref)
+    assert srms <= 1.05 * erms, (srms, erms)
+    assert smax <= 1.5 * emax, (smax, emax)
+    unit = 2.0 ** -24 * math.sqrt(K) * 0.1
+    assert smax < 200 * unit and (split - exact).abs().max().item() < 250 * unit
+
+
+def test_presplit_gemm_epilogues(ops):
+    """The K/V projection's epilogue (grouped source rows through a sample map, head-split scatter) and the
+    accumulate form, pre-split against the exact path bit-layout for bit-layout."""
+    Bn, P, d, H, nseg = 20, 196, 300, 10, 6
+    S = P + 20
+    enc = rnd(Bn, P, d, seed=1)
+    w, b = rnd(nseg * d, d, seed=2, scale=0.1), rnd(nseg * d, seed=3)
+    gmap = torch.randperm(Bn, generator=torch.Generator().manual_seed(0)).to(torch.int32).cuda()
+    ps = ops.presplit_buffer(nseg * d, d, "cuda")
+    ops.presplit_weights([(w, ps)])
+    before = ops.gemm_split_mode()
+    outs = []
+    for mode in (0, 1):
+        ops.set_gemm_split(mode)
+        kv = torch.full((Bn, nseg, H, S, ops.DHP), 7.0, device="cuda")
+        ops.PLAN_LOG = []
+        ops.project_heads(enc, w, b, nseg, H, S, out=kv, s0=0, grp=P, a_gmap=gmap, a_gs=enc.stride(0), w_ps=ps)
+        plan = ops.PLAN_LOG[-1][3]
+        ops.PLAN_LOG = None
+        assert plan["presplit"] == mode
+        outs.append(kv)
+    ops.set_gemm_split(before)
+    exact, split = outs
+    assert (split - exact).abs().max().item() < 2e-5
+    assert torch.equal(split[..., 30:], exact[..., 30:]) and torch.equal(split[:, :, :, P:], exact[:, :, :, P:])   # untouched pads / rows

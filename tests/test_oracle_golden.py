@@ -168,6 +168,27 @@ def test_big_vocab_digest(name):
     assert abs(loss.item() - float(g["loss"][0])) < 1e-5
 
 
+def test_cfg2_b64_digest_with_conv1():
+    """Round 4: the headline workload (cfg2, B = 64, V = 10 000, K = 20) from the features on -- the oracle's feature
+    projection against the stock nn.Conv2d's output rows the fixture keeps, then the oracle's forward against the digest
+    of the real reference's forward on that output."""
+    g = load_golden("digest_cfg2_b64")
+    cfg, P, wm, batch, _ = case_from_golden(g)
+    B, seed = int(g["B"]), int(g["seed"])
+    assert (B, int(g["L"]), int(g["K"]), int(g["V"])) == (64, 20, 20, 10000) and int(g["conv1"]) == 1
+    cw, cb = synth.make_conv1(seed)
+    with torch.no_grad():
+        enc_out = R.feat_proj(synth.make_feats(B, seed), cw, cb)
+        assert (enc_out[:, :, t(g["enc_pos"])] - t(g["enc_out_pos"])).abs().max().item() < 2e-5
+        assert (enc_out.double().sum(dim=(1, 2)) - t(g["enc_out_sum"])).abs().max().item() < 1e-2
+        scores, caps, dl = R.forward(cfg, P, batch["captions"], enc_out, batch["caption_masks"],
+                                     batch["caption_lengths"], batch["entities"])
+        loss = R.packed_ce_loss(cfg, scores, caps, dl)
+    assert dl == g["decode_lengths"].tolist() and torch.equal(caps, t(g["captions_sorted"]))
+    check_digest(g, scores)
+    assert abs(loss.item() - float(g["loss"][0])) < 1e-5
+
+
 def unpack_pi(g, tag, num_pred):
     return t(np.unpackbits(g["pi_" + tag], axis=2)[:, :, :num_pred]).float()
 

@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 
 
 # ------------------------------------------------------------------------------------------------ cfg4 at B = 64
-def test_cfg4_b64_forward_vs_reference_digest(plan_log):
+def test_cfg4_b64_forward_vs_reference_digest(plan_log, gemm_split):
     g = load_golden("digest_cfg4_b64")
     cfg, P, wm, batch, enc_out = case_from_golden(g)
     assert (int(g["B"]), int(g["V"]), int(g["F"])) == (64, 50000, 51)
@@ -37,11 +37,12 @@ def test_cfg4_b64_forward_vs_reference_digest(plan_log):
     M = 64 * 20
     vocab = plans_of(plan_log, M, 50000, 300)
     assert vocab and vocab[0]["tile_m"] >= 64 and vocab[0]["vec"] == 1
+    assert vocab[0]["split_bf16"] == (1 if gemm_split else 0)      # the mode under test really ran on this GEMM
     kv = plans_of(plan_log, 64 * 196, 1800, 300)
     assert kv and kv[0]["tile_m"] >= 64
 
 
-def test_cfg4_b64_train_step_vs_oracle(plan_log):
+def test_cfg4_b64_train_step_vs_oracle(plan_log, gemm_split):
     """One captured TrainStep of the knowledge variant at the bench batch against CE -> backward -> clamp -> Adam on the
     oracle (which the digest above pins to the real reference at this very size)."""
     c = synth.CONFIGS["cfg4"]
@@ -52,7 +53,7 @@ def test_cfg4_b64_train_step_vs_oracle(plan_log):
 
 
 # ------------------------------------------------------------------------------------------------ news at V = 50 000
-def test_news_v50k_forward_vs_reference_digest():
+def test_news_v50k_forward_vs_reference_digest(gemm_split):
     g = load_golden("digest_news_v50k")
     cfg, P, wm, batch, enc_out = case_from_golden(g)
     assert cfg.variant == "news" and int(g["V"]) == 50000 and int(g["K"]) == 51 and int(g["F"]) == 51
@@ -101,7 +102,7 @@ def test_cfg5_beam5_at_bench_size():
     assert torch.equal(dec.predict_beam(enc.cuda(), max_len, ents, beam_size=1), dec.predict(enc.cuda(), max_len, ents))
 
 
-def test_cfg5_greedy_at_bench_size_vs_oracle():
+def test_cfg5_greedy_at_bench_size_vs_oracle(gemm_split):
     """Greedy at cfg5's size: 32 captions decoded together == each caption decoded by the oracle's full recompute."""
     variant, B, K, V, max_len, seed = "geo", 32, 20, 10000, 20, 52
     P = synth.make_params(variant, V, seed)

@@ -400,30 +400,29 @@ def test_train_step_split_allreduce_path_equals_single_graph(monkeypatch):
 
 
 def test_bench_two_ranks_share_the_gpu_over_gloo():
-    """The driver's multi-GPU launch line, rehearsed with two ranks on the one GPU of this box (collectives
-    over gloo instead of RCCL): rendezvous, per-rank shards, the bucket all-reduce inside the timed loop and
-    the single JSON line from rank 0."""
+    """`python bench.py --gpus 2` exactly as the driver types it, WITHOUT torchrun: bench.py starts torch.distributed.run
+    itself as a child process (two ranks on the one GPU of this box, collectives over gloo instead of RCCL): rendezvous,
+    per-rank shards, the bucket all-reduce inside the timed loop, the single JSON line relayed from rank 0 with the number
+    of ranks the probe all-reduce saw and the host baseline."""
     import json
     import os
-    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, ICK_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "2", "--no-cpu-baseline", "--min-seconds", "0.2"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(ICK_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--cpu-seconds", "2", "--min-seconds", "0.2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["config"]["global_batch"] == 128 and d["value"] > 0
+    assert d["scaling"] == "weak" and d["config"]["collective_backend"] == "gloo"
     assert d["config"]["graph"] is True and d["repeats"] >= 1 and d["steps"] == 3 and "modes" not in d
     assert "pass_frac" not in d["roofline"] and d["roofline"]["pass_frac_executed"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
 
 
 def test_train_step_from_features_and_in_place_input_buffers():
