@@ -387,7 +387,11 @@ def main():
             "unit": "decode-steps/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": res["ms_per_step"], "repeats": res["repeats"], "timed_region_s": res["timed_region_s"],
             "block_s_min_median_max": res["block_s_min_median_max"], "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            # arithmetic type: fp32 in, fp32 out, fp32 accumulation everywhere; with the split product mode the large GEMM
+            # tiles form each fp32 product from bf16 partial products of the exact 3-way split (config.gemm_products)
+            "dtype": "f32" if _gemm_mode() == 0 else "f32 (3xbf16 split products, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": wl.describe(),
                        "mode": {"train": "train_step (Encoder.conv1 + forward + packed CE + backward + gradient "
                                          "all-reduce + clamp + Adam; dropout 0.5/0.5/0.1 as the reference's train.py "
@@ -426,8 +430,17 @@ def main():
                     "sum_kernel_us_per_step": sum(r["us_per_step"] for r in by_kernel),
                     "by_kernel": by_kernel,
                     "how": "HIP events on the launch stream around every C-ABI launch of %d eager single-stream steps "
-                           "after the timed region; work = algorithmic FLOP (fp32 MFMA peak %.1f TFLOP/s) or bytes "
-                           "(HBM peak %.0f GB/s)" % (args.profile_steps, PEAK_FP32_MFMA_TFLOPS, PEAK_HBM_GBS)}
+                           "after the timed region; work = algorithmic FLOP (fp32 MFMA peak %.1f TFLOP/s; kernels whose "
+                           "products are six bf16 MFMAs: bf16 dense peak 2500 / 6 = %.1f TFLOP/s fp32-equivalent) or bytes "
+                           "(HBM peak %.0f GB/s)" % (args.profile_steps, PEAK_FP32_MFMA_TFLOPS, 2500.0 / 6, PEAK_HBM_GBS)}
+        if by_kernel:
+            # sum over the kernel classes of (algorithmic work / that class's own peak): what the step would take if
+            # every kernel ran at its roofline, back to back -- the whole step's fraction against a peak that mixes the
+            # exact-fp32 pipe, the bf16 pipe of the split-product kernels and HBM
+            floor_us = sum(r["work_per_launch"] * r["launches_per_step"] / (r["peak"] * (1e12 if r["unit"] == "TFLOP/s" else 1e9))
+                           for r in by_kernel if r.get("peak")) * 1e6
+            roof["pass_floor_us"] = floor_us
+            roof["pass_frac_of_floor"] = floor_us / (res["ms_per_step"] * 1e3)
         pf = pass_fraction(cfgname, args.mode, res["ms_per_step"], L)
         if pf is not None:
             roof["pass_frac_executed"] = pf["frac"]
@@ -447,21 +460,23 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         torch.cuda.synchronize()
-        # the *_split legs: the same workloads with the opt-in split-bf16 products of the large GEMM tiles
-        # (ICK_GEMM_SPLIT=1; fp32-accurate, tests/test_gemm_split_gpu.py) -- the headline stays on the exact fp32 MFMA
-        for name, mode, cname, steps, split in (("forward_cfg2", "forward", "cfg2", 50, 0),
-                                                ("greedy_cfg5", "greedy", "cfg5", 20, 0),
-                                                ("beam5_cfg5", "beam", "cfg5", 10, 0),
-                                                ("train_cfg4", "train", "cfg4", 20, 0),
-                                                ("train_cfg2_split_gemm", "train", "cfg2", 50, 1),
-                                                ("forward_cfg2_split_gemm", "forward", "cfg2", 50, 1)):
-            if (mode, cname) == (args.mode, cfgname) and not split:
+        # the *_exact_fp32 legs: the headline workloads with every product on the exact fp32 MFMA (ICK_GEMM_SPLIT=0), kept
+        # beside the default (split-bf16 products on the large GEMM tiles; all modes are held to the same reference-made
+        # goldens and tolerances by the parity suite, tests/conftest.py gemm_split)
+        for name, mode, cname, steps, exact in (("forward_cfg2", "forward", "cfg2", 50, False),
+                                                ("greedy_cfg5", "greedy", "cfg5", 20, False),
+                                                ("beam5_cfg5", "beam", "cfg5", 10, False),
+                                                ("train_cfg4", "train", "cfg4", 20, False),
+                                                ("train_cfg2_exact_fp32", "train", "cfg2", 50, True),
+                                                ("forward_cfg2_exact_fp32", "forward", "cfg2", 50, True)):
+            if (mode, cname) == (args.mode, cfgname) and (not exact or _gemm_mode() == 0):
                 continue
             cmd = [sys.executable, os.path.abspath(__file__), "--mode", mode, "--config", cname, "--steps", str(steps),
                    "--warmup", "3", "--min-seconds", "0.5", "--no-modes", "--no-cpu-baseline", "--profile-steps",
                    "0" if args.no_profile else "2"] + (["--no-profile"] if args.no_profile else [])
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-            env["ICK_GEMM_SPLIT"] = str(split)
+            if exact:
+                env["ICK_GEMM_SPLIT"] = "0"
             r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not lines:
@@ -470,11 +485,13 @@ def main():
             c = json.loads(lines[-1])
             entry = {"workload": c["config"]["workload"], "mode": mode, "steps": steps, "repeats": c["repeats"],
                      "ms_per_step": c["ms_per_step"], "value": c["value"], "unit": c["unit"], "graph": c["config"]["graph"],
-                     "gemm_products": c["config"].get("gemm_products")}
+                     "gemm_products": c["config"].get("gemm_products"), "dtype": c.get("dtype")}
             rf = c.get("roofline", {})
             if "pass_frac_executed" in rf:
                 entry["pass_frac"] = rf["pass_frac_executed"]
                 entry["pass_bound"] = rf["pass_bound"]
+            if "pass_frac_of_floor" in rf:
+                entry["pass_frac_of_floor"] = rf["pass_frac_of_floor"]
             if rf.get("kernel"):
                 entry["dominant_kernel"] = {"name": rf["kernel"], "avg_us": rf["kernel_avg_us"],
                                             "launches_per_step": rf["launches_per_step"], "frac": rf.get("frac"),

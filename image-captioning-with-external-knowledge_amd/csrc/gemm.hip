@@ -19,6 +19,7 @@
 //   * the tile index is remapped so the 8 XCDs (round-robin over blockIdx) each walk a
 //     contiguous run of tiles and the smaller operand panel stays in that XCD's L2.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -43,8 +44,10 @@ extern "C" int ick_debug_read_gemm_stamps(unsigned long long* out, int n) {
 
 namespace ick {
 
-int launch_gemm_ps(const ick_gemm_args& a, bool akm, bool wide, int tiles_m, int tiles_n, int kchunk, int split,
+int launch_gemm_ps(const ick_gemm_args& a, bool akm, int tile, int tiles_m, int tiles_n, int kchunk, int split, int a_nt,
                    hipStream_t s);      // gemm_ps.hip
+void gemm_ps_tile_dims(int tile, int* bm, int* bn, int* wgs_per_cu);
+int gemm_ps_tile_count();
 
 namespace {
 
@@ -494,7 +497,8 @@ struct Plan {
     bool wide;                   // 128 x 64 tiles, 8 waves (single launches only)
     bool spl;                    // split-bf16 products (64 x 64 and 128 x 64 tiles of the vector path)
     bool xl;                     // 128 x 128 tiles, 8 waves, split products only (single launches only; implies wide)
-    bool ps, ps_wide;            // B read from its pre-split copy (gemm_ps.hip): 128 x 128 tiles, or 64 x 320 when ps_wide
+    bool ps;                     // B read from its pre-split copy (gemm_ps.hip) ...
+    int ps_tile, ps_nt;          // ... on tile shape ps_tile (gemm_ps_tile_dims), A loads non-temporal when ps_nt
     int tiles_m, tiles_n, kchunk, split;
 };
 
@@ -705,18 +709,31 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
     pl.split = ceil_div(a.K, pl.kchunk);
     // B pre-split by the caller (b_ps): both operands staged by LDS-DMA, only the A fragments split in the kernel
     // (gemm_ps.hip).  Needs the vector conditions on A (16-byte pieces) and a problem large enough for its tiles.
-    pl.ps = pl.ps_wide = false;
+    pl.ps = false; pl.ps_tile = 0; pl.ps_nt = 0;
     if (a.b_ps != nullptr && gemm_split_mode() >= 1 && avec && aligned16(a.b_ps) && a.a_extent >= 4 &&
         a_need <= a.a_extent + 3 && a.colsum_a == nullptr && !(a.flags & ICK_GEMM_COLSUM_ONLY)) {
-        static int ps_on = -1;
-        if (ps_on < 0) { const char* e = getenv("ICK_GEMM_PS"); ps_on = e ? atoi(e) : 1; }
-        const bool wide_n = a.N <= 320;
+        static int ps_on = -1, ps_tile_env = -2, ps_nt_env = -2;
+        if (ps_on < 0) {
+            const char* e = getenv("ICK_GEMM_PS"); ps_on = e ? atoi(e) : 1;
+            e = getenv("ICK_PS_TILE"); ps_tile_env = e ? atoi(e) : -1;
+            e = getenv("ICK_PS_NT"); ps_nt_env = e ? atoi(e) : -1;
+        }
         const double flop = 2.0 * a.M * a.N * a.K;
         if (ps_on && flop >= 1.0e9 && a.M >= 256 && a.N >= 128) {
-            pl.ps = true; pl.ps_wide = wide_n;
+            // Tile choice, measured (tools/gemm_ps_bench.py, profiles/r04_e_gemm_ps_tiles.txt: every tile x every shape):
+            // 128 x 128 with two workgroups per CU wins wherever the output is wider than 320 columns (cross K/V 100 us
+            // against 129-143 on the other tiles, vocabulary 65 against 80-88); outputs at most 320 wide (Encoder.conv1,
+            // the vocabulary data gradient) read their A operand once on 128 x 160 (121 us against 139-187).  Larger tiles
+            // and deeper rings bought nothing: every variant settles near 120-135 TFLOP/s fp32-equivalent, ~60 % of what
+            // the bf16 pipe holds on random data at the clock the chip keeps under MFMA load (MI355X_MICROARCH.md).
+            int best = a.N <= 320 ? 2 : 1;
+            if (ps_tile_env >= 0 && ps_tile_env < gemm_ps_tile_count()) best = ps_tile_env;
+            int bm, bn, wpc; gemm_ps_tile_dims(best, &bm, &bn, &wpc);
+            pl.ps = true; pl.ps_tile = best;
             pl.spl = true; pl.big = true; pl.wide = pl.xl = false;
-            pl.tiles_m = ceil_div(a.M, wide_n ? 64 : 128);
-            pl.tiles_n = wide_n ? 1 : ceil_div(a.N, 128);
+            pl.tiles_m = ceil_div(a.M, bm);
+            pl.tiles_n = ceil_div(a.N, bn);
+            pl.ps_nt = ps_nt_env >= 0 ? ps_nt_env : 0;    // non-temporal A loads: measured, no gain (same file)
         }
     }
     return ICK_OK;
@@ -733,7 +750,7 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
 #define ICK_COMMA_FALSE , false
 
 int launch_plan(const Plan& pl, hipStream_t s) {
-    if (pl.ps) return launch_gemm_ps(pl.a, pl.akm, pl.ps_wide, pl.tiles_m, pl.tiles_n, pl.kchunk, pl.split, s);
+    if (pl.ps) return launch_gemm_ps(pl.a, pl.akm, pl.ps_tile, pl.tiles_m, pl.tiles_n, pl.kchunk, pl.split, pl.ps_nt, s);
     if (!pl.vec) ICK_BY_LAYOUT(launch_one, 2, 2, ICK_COMMA_FALSE, pl, s);
     if (pl.xl) {
         // four waves of 64 x 64 and one LDS buffer (two workgroups per CU overlap their phases) unless ICK_GEMM_XL4=0
@@ -772,7 +789,7 @@ extern "C" int ick_gemm_plan(const ick_gemm_args* in, ick_gemm_plan_info* out) {
     const int bmn = pl.big ? 64 : 32;
     out->tile_m = pl.wide ? 128 : bmn; out->tile_n = pl.xl ? 128 : bmn; out->waves = pl.wide ? 8 : 4;   // (xl: 4 or 8, ICK_GEMM_XL4)
     out->presplit = pl.ps;
-    if (pl.ps) { out->tile_m = pl.ps_wide ? 64 : 128; out->tile_n = pl.ps_wide ? 320 : 128; out->waves = 8; }
+    if (pl.ps) { int wpc; gemm_ps_tile_dims(pl.ps_tile, &out->tile_m, &out->tile_n, &wpc); out->waves = 8; }
     out->tiles_m = pl.tiles_m; out->tiles_n = pl.tiles_n; out->split_k = pl.split;
     out->a_kmajor = pl.akm; out->b_kmajor = pl.bkm; out->vec = pl.vec;
     out->split_bf16 = pl.spl;

@@ -13,15 +13,20 @@
 //   * every tile slice travels global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction): the
 //     pre-split B planes in the MFMA operand's image (64-byte rows, XOR-swizzled chunks -- the swizzle is applied to
 //     the SOURCE address, the LDS side of a DMA is lane-linear), the A tile as raw fp32;
-//   * B is double buffered, A two or three deep (AST): with one workgroup per CU the A slices (read from HBM exactly
-//     once) get two MFMA phases to land; the only waits are counted s_waitcnt vmcnt(N) + one raw s_barrier per slice;
-//   * a wave owns 16 rows x (TN x 16) columns: it reads its raw A fragment (k-major: eight ds_read_b32 from a line
-//     image rotated by 16 floats per 8 k lines; k-contiguous: two ds_read_b128 from 128-byte rows with XOR-swizzled
-//     chunks -- both conflict free), splits it (44 VALU) and issues 6 x TN v_mfma_f32_16x16x32_bf16 against B fragments
-//     that are read one block ahead;
-//   * two tile shapes: 64 x 320 (8 waves as 4 x 2, one workgroup per CU, 144 KB of LDS) for outputs at most 320 wide --
-//     Encoder.conv1 (N = 300) and the vocabulary data gradient read their big A operand ONCE instead of once per 64-wide
-//     column tile; 128 x 128 (8 waves as 8 x 1, 80 KB, two workgroups per CU) for the wide outputs.
+//   * both operands run through rings of D + 1 LDS buffers, D slices in flight ahead of the one being read; the only
+//     waits are counted s_waitcnt vmcnt(N) + one raw s_barrier per slice (with D = 2 every wave issues the same number
+//     of pieces per slice -- a zero fill into a scratch KiB where a wave has one piece less -- so N is an immediate);
+//   * a wave owns TM x 16 rows x (TN x 16) columns: it requests its B fragments (PF blocks ahead, or the whole slice),
+//     reads its raw A fragment (k-major: eight ds_read_b32 from a line image rotated by 16 floats per 8 k lines;
+//     k-contiguous: two ds_read_b128 from 128-byte rows with XOR-swizzled chunks -- both conflict free: PMC
+//     SQ_LDS_BANK_CONFLICT = 0), splits it (44 VALU) and issues 6 x TM x TN v_mfma_f32_16x16x32_bf16;
+//   * tile shapes: see launch_gemm_ps below.  Measured (tools/gemm_ps_bench.py, profiles/r04_*_gemm_ps_tiles.txt, PMC
+//     profiles/r04_c_pmc_gemm_ps.txt): 128 x 128 with two workgroups per CU is the fastest wherever the output is wider
+//     than 320 columns (cross K/V 128 -> 100 us, vocabulary 76 -> 65 us against the stager-split kernel), 128 x 160 for
+//     Encoder.conv1 (121 us: level with the stager-split 128 x 64 tile).  Ring depth, fragment prefetch depth, tile
+//     size and non-temporal A loads all leave the rate at 120-135 TFLOP/s fp32-equivalent with the matrix pipe ~50 %
+//     busy on the CUs in use -- about 60 % of what bf16 MFMA loops hold on random data at the clock the chip keeps under
+//     that load (MI355X_MICROARCH.md, DVFS give-back: 1.25 PFLOP/s at 1.9 GHz, i.e. ~208 TFLOP/s fp32-equivalent).
 #include <algorithm>
 
 #include "gemm_common.h"
@@ -85,21 +90,29 @@ __global__ __launch_bounds__(256) void presplit_kernel(PsBatch b) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <int WM_, int WN_, int TN_, bool AKM_, int AST_>
+template <int WM_, int WN_, int TM_, int TN_, bool AKM_, int D_, int PF_>
 struct PsCfg {
-    static constexpr int WM = WM_, WN = WN_, TN = TN_, AST = AST_;
+    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, D = D_;   // D: slices in flight ahead of the one being read
+    static constexpr int PF = PF_ < TN_ ? PF_ : TN_;   // B fragment blocks requested from LDS ahead of the MFMAs that use them
+    static constexpr int ST = D + 1;                                         // ring buffers per operand
     static constexpr bool AKM = AKM_;
-    static constexpr int BM = WM * 16, BN = WN * TN * 16, NW = WM * WN, NT = NW * 64;
+    static constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NW = WM * WN, NT = NW * 64;
     static constexpr int A_STAGE = BM * 32 * 4;          // bytes: raw fp32 slice of the A tile
     static constexpr int B_PLANE = BN * 64;              // bytes: one bf16 plane of the B tile slice
     static constexpr int B_STAGE = 3 * B_PLANE;
-    static constexpr int LDS = AST * A_STAGE + 2 * B_STAGE;
     static constexpr int NPA = BM / 8;                   // 1 KiB DMA pieces of an A slice
     static constexpr int NPB = 3 * BN / 16;              // ... of a B slice (16 rows of one plane each)
     static constexpr int PA_W = NPA / NW;                // pieces per wave
     static constexpr int PB_W = (NPB + NW - 1) / NW;
+    // D >= 2: the waits are counted (s_waitcnt vmcnt(N) with N pieces of the younger slices still in flight), so every
+    // wave must issue the SAME number of pieces per slice: the waves that have one B piece less send a zero fill into a
+    // 1 KiB scratch area instead
+    static constexpr bool UNIFORM = D >= 2;
+    static constexpr int SCRATCH = UNIFORM && (NPB % NW != 0) ? 1024 : 0;
+    static constexpr int LDS = ST * (A_STAGE + B_STAGE) + SCRATCH;
+    static constexpr int IN_FLIGHT = (D - 1) * (PA_W + PB_W);   // pieces of the younger slices at the end of an iteration
     static_assert(NPA % NW == 0 && PA_W >= 1, "every wave issues the same number of A pieces (counted vmcnt)");
-    static_assert(AST == 2 || AST == 3, "A ring depth");
+    static_assert(D == 1 || D == 2, "ring depth");
     static_assert(LDS <= 160 * 1024, "tile exceeds the LDS of a CU");
 };
 
@@ -110,8 +123,8 @@ struct PsCfg {
 
 // One slice of the B tile / of the A tile by LDS-DMA: this wave's 1 KiB pieces (see the kernel below).
 template <class C>
-__device__ __forceinline__ void ps_dma_b(const __amdgpu_buffer_rsrc_t& rsrc, char* Bs, int buf, int wave, uint32_t bvoff,
-                                         int slice, bool valid, int n0, int np_rows) {
+__device__ __forceinline__ void ps_dma_b(const __amdgpu_buffer_rsrc_t& rsrc, char* Bs, char* scratch, int buf, int wave,
+                                         uint32_t bvoff, int slice, bool valid, int n0, int np_rows) {
 #pragma unroll
     for (int j = 0; j < C::PB_W; ++j) {
         const int g = wave + C::NW * j;
@@ -121,31 +134,40 @@ __device__ __forceinline__ void ps_dma_b(const __amdgpu_buffer_rsrc_t& rsrc, cha
             const uint32_t soff = (uint32_t)((((int64_t)slice * 3 + plane) * np_rows + rblk * 16) * 64);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(Bs + buf * C::B_STAGE + plane * C::B_PLANE + rblk * 1024),
                                                      16, in ? bvoff : kOobOffset, in ? soff : 0u, 0, 0);
+        } else if (C::UNIFORM) {        // keeps this wave's piece count equal to the others': a zero fill nobody reads
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)scratch, 16, kOobOffset, 0u, 0, 0);
         }
     }
 }
+// nt: the A operand is read once by the whole launch (one column tile): a non-temporal load keeps it from evicting the
+// weight planes, which every workgroup of the XCD re-reads, from that XCD's L2
 template <class C>
 __device__ __forceinline__ void ps_dma_a(const __amdgpu_buffer_rsrc_t& rsrc, char* As, int buf, int wave,
                                          const uint32_t (&avoff)[C::PA_W], const int (&akl)[C::PA_W], int k0, int kend,
-                                         uint32_t soff) {
+                                         uint32_t soff, bool nt) {
 #pragma unroll
     for (int j = 0; j < C::PA_W; ++j) {
         const int g = wave + C::NW * j;
         const bool in = k0 + akl[j] < kend;      // also false for every lane of a slice beyond the K range
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(As + buf * C::A_STAGE + g * 1024), 16,
-                                                 in ? avoff[j] : kOobOffset, soff, 0, 0);
+        lds_void_ptr dst = (lds_void_ptr)(As + buf * C::A_STAGE + g * 1024);
+        if (nt) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, in ? avoff[j] : kOobOffset, soff, 0, 2);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, in ? avoff[j] : kOobOffset, soff, 0, 0);
     }
 }
 
-template <int WM_, int WN_, int TN_, bool AKM_, int AST_>
-__global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_ps_kernel(ick_gemm_args p, int np_rows, int64_t bps_bytes, int tiles_m,
-                                                                 int tiles_n, int kchunk) {
-    using C = PsCfg<WM_, WN_, TN_, AKM_, AST_>;
-    constexpr int BM = C::BM, BN = C::BN, TN = C::TN, NW = C::NW, AST = C::AST;
+// waves per SIMD the register allocator may plan for: 2 when the tile's LDS footprint leaves room for one workgroup per CU
+// (8 waves on 4 SIMDs: 256 VGPRs each, enough to hold a whole slice's B fragments), 4 for the two-workgroup tile
+template <int WM_, int WN_, int TM_, int TN_, bool AKM_, int D_, int PF_>
+__global__ __launch_bounds__(WM_ * WN_ * 64)
+__attribute__((amdgpu_waves_per_eu(1, (PsCfg<WM_, WN_, TM_, TN_, AKM_, D_, PF_>::LDS > 80 * 1024 ? 2 : 4)))) void gemm_ps_kernel(ick_gemm_args p, int np_rows, int64_t bps_bytes, int tiles_m,
+                                                                 int tiles_n, int kchunk, int a_nt) {
+    using C = PsCfg<WM_, WN_, TM_, TN_, AKM_, D_, PF_>;
+    constexpr int BM = C::BM, BN = C::BN, TM = C::TM, TN = C::TN, NW = C::NW, D = C::D, ST = C::ST;
     constexpr bool AKM = C::AKM;
     extern __shared__ __attribute__((aligned(1024))) char smem_ps[];
     char* const As = smem_ps;
-    char* const Bs = smem_ps + AST * C::A_STAGE;
+    char* const Bs = smem_ps + ST * C::A_STAGE;
+    char* const scratch = Bs + ST * C::B_STAGE;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     constexpr int WN = C::WN;
@@ -207,61 +229,38 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_ps_kernel(ick_gemm_args p
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.b_ps), (short)0, (int)bps_bytes, 0x00020000);
     const uint32_t bvoff = (uint32_t)((n0 + (lane >> 2)) * 64 + (((lane & 3) ^ ((-(lane >> 4)) & 3)) * 16));
 
-    auto dma_b = [&](int it, int buf) { ps_dma_b<C>(rsrc_b, Bs, buf, wave, bvoff, s0 + it, it < nk, n0, np_rows); };
+    auto dma_b = [&](int it, int buf) { ps_dma_b<C>(rsrc_b, Bs, scratch, buf, wave, bvoff, s0 + it, it < nk, n0, np_rows); };
     auto dma_a = [&](int it, int buf) {
         const int k0 = kbeg + 32 * it;
         const uint32_t soff = it < nk ? (uint32_t)(AKM ? (int64_t)k0 * p.a_ks * 4 : (int64_t)k0 * 4) : 0u;
-        ps_dma_a<C>(rsrc_a, As, buf, wave, avoff, akl, k0, kend, soff);
+        ps_dma_a<C>(rsrc_a, As, buf, wave, avoff, akl, k0, kend, soff, a_nt != 0);
     };
 
-    f32x4 acc[1][TN];
+    f32x4 acc[TM][TN];
 #pragma unroll
-    for (int b = 0; b < TN; ++b) acc[0][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // prologue: B(0), A(0) [, A(1)]
-    dma_b(0, 0);
-    dma_a(0, 0);
-    if constexpr (AST == 3) {
-        dma_a(1, 1);
-        ICK_WAIT_VMCNT(C::PA_W);
-    } else {
-        ICK_WAIT_VMCNT(0);
-    }
+    // prologue: slices 0 .. D-1 (B then A of each); the first must have landed
+#pragma unroll
+    for (int i = 0; i < D; ++i) { dma_b(i, i); dma_a(i, i); }
+    ICK_WAIT_VMCNT(C::IN_FLIGHT);
     ICK_LDS_BARRIER();
 
-    int abuf = 0;                            // A buffer holding slice `it`
+    int buf = 0;                             // ring buffer holding slice `it`
     for (int it = 0; it < nk; ++it) {
-        const int bbuf = it & 1;
-        // requests first: B one slice ahead, A AST - 1 slices ahead (slices beyond the range are zero fills that touch
-        // no memory: the counts stay constant, so the waits below are immediates)
-        dma_b(it + 1, bbuf ^ 1);
+        // requests first: slice it + D into the buffer that was read in iteration it - 1 (slices beyond the range are zero
+        // fills that touch no memory: the piece counts stay constant, so the waits below are immediates)
         {
-            int nb = abuf + (AST - 1);
-            if (nb >= AST) nb -= AST;
-            dma_a(it + AST - 1, nb);
+            int nb = buf + D;
+            if (nb >= ST) nb -= ST;
+            dma_b(it + D, nb);
+            dma_a(it + D, nb);
         }
-        // the wave's A fragment: 16 rows x 32 k, raw fp32 -> three bf16 planes
-        float x[8];
-        const char* at = As + abuf * C::A_STAGE;
-        if constexpr (AKM) {
-            const int pos = (wm * 16 + fi + 16 * fq) & (BM - 1);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const float*>(at + ((8 * fq + j) * BM + pos) * 4);
-        } else {
-            const int row = wm * 16 + fi, sw = (row >> 1) & 7;
-            const float4 u = *reinterpret_cast<const float4*>(at + row * 128 + 16 * ((2 * fq) ^ sw));
-            const float4 v = *reinterpret_cast<const float4*>(at + row * 128 + 16 * ((2 * fq + 1) ^ sw));
-            x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
-        }
-        uint32_t h[4], m[4], l[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) split3(x[2 * j], x[2 * j + 1], h[j], m[j], l[j]);
-        bf16x8_t af[3];
-        af[0] = __builtin_bit_cast(bf16x8_t, u32x4_t{h[0], h[1], h[2], h[3]});
-        af[1] = __builtin_bit_cast(bf16x8_t, u32x4_t{m[0], m[1], m[2], m[3]});
-        af[2] = __builtin_bit_cast(bf16x8_t, u32x4_t{l[0], l[1], l[2], l[3]});
-
-        // B fragments one block ahead of their MFMAs
+        const int abuf = buf, bbuf = buf;
+        // B fragments PF blocks ahead of their MFMAs (PF = TN: the whole slice is requested first, so the LDS latency is
+        // paid once per slice and the 6 x TM x TN MFMAs then issue back to back; the ds_reads return in order)
         const char* bt = Bs + bbuf * C::B_STAGE;
         auto read_b = [&](int b, bf16x8_t (&f)[3]) {
             const int row = (wn * TN + b) * 16 + fi;
@@ -270,28 +269,58 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_ps_kernel(ick_gemm_args p
             for (int pl = 0; pl < 3; ++pl)
                 f[pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(ptr + pl * C::B_PLANE));
         };
-        bf16x8_t bf[2][3];
-        read_b(0, bf[0]);
+        bf16x8_t bf[TN][3];
+#pragma unroll
+        for (int b = 0; b < C::PF; ++b) read_b(b, bf[b]);
+        // the wave's A fragments (TM x 16 rows x 32 k): raw fp32 -> three bf16 planes each (the split's ~44 VALU
+        // instructions per fragment run while the B fragments are on their way)
+        bf16x8_t af[TM][3];
+        const char* at = As + abuf * C::A_STAGE;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            float x[8];
+            const int r0 = (wm * TM + a) * 16;
+            if constexpr (AKM) {
+                const int pos = (r0 + fi + 16 * fq) & (BM - 1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const float*>(at + ((8 * fq + j) * BM + pos) * 4);
+            } else {
+                const int row = r0 + fi, sw = (row >> 1) & 7;
+                const float4 u = *reinterpret_cast<const float4*>(at + row * 128 + 16 * ((2 * fq) ^ sw));
+                const float4 v = *reinterpret_cast<const float4*>(at + row * 128 + 16 * ((2 * fq + 1) ^ sw));
+                x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
+            }
+            uint32_t h[4], m[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split3(x[2 * j], x[2 * j + 1], h[j], m[j], l[j]);
+            af[a][0] = __builtin_bit_cast(bf16x8_t, u32x4_t{h[0], h[1], h[2], h[3]});
+            af[a][1] = __builtin_bit_cast(bf16x8_t, u32x4_t{m[0], m[1], m[2], m[3]});
+            af[a][2] = __builtin_bit_cast(bf16x8_t, u32x4_t{l[0], l[1], l[2], l[3]});
+        }
+        // the scheduler must not sink the fragment requests back to their uses (it would, to save registers)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-            if (b + 1 < TN) read_b(b + 1, bf[(b + 1) & 1]);
-            f32x4 c = acc[0][b];
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[b & 1][2], c, 0, 0, 0);     // smallest products first
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[b & 1][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[b & 1][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[b & 1][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[b & 1][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[b & 1][0], c, 0, 0, 0);
-            acc[0][b] = c;
+            if (b + C::PF < TN) read_b(b + C::PF, bf[b + C::PF]);
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                f32x4 c = acc[a][b];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[b][2], c, 0, 0, 0);     // smallest products first
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][2], bf[b][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][1], bf[b][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[b][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][1], bf[b][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[b][0], c, 0, 0, 0);
+                acc[a][b] = c;
+            }
         }
-        // B(it + 1) and A(it + 1) have landed (in-order completion: only the A pieces issued last may remain)
-        if constexpr (AST == 3) ICK_WAIT_VMCNT(C::PA_W);
-        else ICK_WAIT_VMCNT(0);
+        // slice it + 1 has landed (in-order completion: only the pieces of the D - 1 younger slices may remain)
+        ICK_WAIT_VMCNT(C::IN_FLIGHT);
         ICK_LDS_BARRIER();
-        if (++abuf == AST) abuf = 0;
+        if (++buf == ST) buf = 0;
     }
     ICK_WAIT_VMCNT(0);       // the zero fills of the last iterations write LDS too: none may outlive the workgroup
-    gemm_epilogue<1, TN>(p, acc, m0, n0, wm, wn, fi, fq, zid);
+    gemm_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, fi, fq, zid);
 }
 
 
@@ -299,33 +328,56 @@ namespace {
 
 template <class C>
 int launch_ps_cfg(const ick_gemm_args& a, int np_rows, int64_t bytes, int tiles_m, int tiles_n, int kchunk, int split,
-                  hipStream_t s) {
+                  int a_nt, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ps_kernel<C::WM, C::WN, C::TN, C::AKM, C::AST>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ps_kernel<C::WM, C::WN, C::TM, C::TN, C::AKM, C::D, C::PF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_ps_kernel<C::WM, C::WN, C::TN, C::AKM, C::AST>), dim3(tiles_m * tiles_n, 1, split), dim3(C::NT), C::LDS, s, a, np_rows, bytes,
-                       tiles_m, tiles_n, kchunk);
+    hipLaunchKernelGGL((gemm_ps_kernel<C::WM, C::WN, C::TM, C::TN, C::AKM, C::D, C::PF>), dim3(tiles_m * tiles_n, 1, split),
+                       dim3(C::NT), C::LDS, s, a, np_rows, bytes, tiles_m, tiles_n, kchunk, a_nt);
     ICK_LAUNCH_RET();
+}
+
+template <int WM, int WN, int TM, int TN, int D, int PF>
+int launch_ps_tile(const ick_gemm_args& a, bool akm, int np, int64_t bytes, int tiles_m, int tiles_n, int kchunk, int split,
+                   int a_nt, hipStream_t s) {
+    if (akm) return launch_ps_cfg<PsCfg<WM, WN, TM, TN, true, D, PF>>(a, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
+    return launch_ps_cfg<PsCfg<WM, WN, TM, TN, false, D, PF>>(a, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
 }
 
 }  // namespace
 
-// Called by ick_gemm (gemm.hip) once its plan has chosen the pre-split path.  wide: the 64 x 320 tile (N <= 320).
-int launch_gemm_ps(const ick_gemm_args& a, bool akm, bool wide, int tiles_m, int tiles_n, int kchunk, int split,
+// Tile shapes of the pre-split kernel (ick_gemm's plan picks one; bm x bn, waves as WM x WN, wave tile TM x TN blocks,
+// D slices in flight):
+//   0: 64 x 320   4 x 2 waves of 16 x 160, D 1, 136 KB of LDS
+//   1: 128 x 128  8 x 1 waves of 16 x 128, D 1,  80 KB: two workgroups per CU cover each other's waits
+//   2: 128 x 160  8 x 1 waves of 16 x 160, D 2, 139 KB
+//   3: 128 x 320  4 x 2 waves of 32 x 160, D 1, 152 KB
+//   4: 128 x 128  8 x 1 waves of 16 x 128, D 2, 120 KB: one workgroup per CU, the LDS-DMA latency (~1.1 us from issue to
+//                 landing, longer than a slice's MFMA phase) hidden by the deeper ring instead
+constexpr int kPsTiles = 5;
+void gemm_ps_tile_dims(int tile, int* bm, int* bn, int* wgs_per_cu) {
+    static const int dims[kPsTiles][3] = {{64, 320, 1}, {128, 128, 2}, {128, 160, 1}, {128, 320, 1}, {128, 128, 1}};
+    *bm = dims[tile][0]; *bn = dims[tile][1]; *wgs_per_cu = dims[tile][2];
+}
+int gemm_ps_tile_count() { return kPsTiles; }
+
+int launch_gemm_ps(const ick_gemm_args& a, bool akm, int tile, int tiles_m, int tiles_n, int kchunk, int split, int a_nt,
                    hipStream_t s) {
     const int np = (int)ps_rows(a.N);
     const int64_t bytes = ps_bytes(a.N, a.K);
     if (bytes >= ((int64_t)1 << 31)) return ICK_EINVAL;
-    if (wide) {
-        if (akm) return launch_ps_cfg<PsCfg<4, 2, 10, true, 3>>(a, np, bytes, tiles_m, tiles_n, kchunk, split, s);
-        return launch_ps_cfg<PsCfg<4, 2, 10, false, 3>>(a, np, bytes, tiles_m, tiles_n, kchunk, split, s);
+    switch (tile) {
+        case 0: return launch_ps_tile<4, 2, 1, 10, 1, 10>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
+        case 1: return launch_ps_tile<8, 1, 1, 8, 1, 2>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
+        case 2: return launch_ps_tile<8, 1, 1, 10, 2, 10>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
+        case 3: return launch_ps_tile<4, 2, 2, 10, 1, 3>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
+        case 4: return launch_ps_tile<8, 1, 1, 8, 2, 8>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
     }
-    if (akm) return launch_ps_cfg<PsCfg<8, 1, 8, true, 2>>(a, np, bytes, tiles_m, tiles_n, kchunk, split, s);
-    return launch_ps_cfg<PsCfg<8, 1, 8, false, 2>>(a, np, bytes, tiles_m, tiles_n, kchunk, split, s);
+    return ICK_EINVAL;
 }
 
 }  // namespace ick

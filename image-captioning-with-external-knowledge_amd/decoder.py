@@ -119,11 +119,12 @@ class _Conv1Fn(torch.autograd.Function):
     fine-tuned).  Used when gradients are wanted (fine_tune_encoder=True, geo-aware/train.py:93-100,282-294)."""
 
     @staticmethod
-    def forward(ctx, feats, weight, bias):
+    def forward(ctx, feats, weight, bias, w_ps=None):
         B, Cc, Hh, Ww = feats.shape
         P, d = Hh * Ww, weight.shape[0]
         out = torch.empty(B, P, d, device=feats.device, dtype=torch.float32)
-        ops.gemm_raw(feats, weight.detach().view(d, Cc), out, B * P, d, Cc, 1, P, Cc, 1, d, bias=bias, a_grp=P, a_gs=Cc * P)
+        ops.gemm_raw(feats, weight.detach().view(d, Cc), out, B * P, d, Cc, 1, P, Cc, 1, d, bias=bias, a_grp=P, a_gs=Cc * P,
+                     b_ps=w_ps)
         ctx.save_for_backward(feats, weight)
         return out
 
@@ -147,7 +148,7 @@ class _Conv1Fn(torch.autograd.Function):
             w2 = weight.view(d, Cc)
             ops.gemm_raw(dy, w2, dxt, B * P, Cc, d, d, 1, 1, Cc, Cc)           # dX = dY . W  (B k-major)
             dx = dxt.view(B, P, Cc).permute(0, 2, 1).reshape(B, Cc, Hh, Ww)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 class Encoder(nn.Module):
@@ -208,7 +209,7 @@ class Encoder(nn.Module):
         P = Hh * Ww
         d = self.emb_dim
         if torch.is_grad_enabled() and (feats.requires_grad or self.conv1.weight.requires_grad):
-            return _Conv1Fn.apply(feats, self.conv1.weight, self.conv1.bias).permute(0, 2, 1)
+            return _Conv1Fn.apply(feats, self.conv1.weight, self.conv1.bias, self.conv1_presplit()).permute(0, 2, 1)
         out = torch.empty(B, P, d, device=feats.device, dtype=torch.float32)
         w = self.conv1.weight.detach().view(d, Cc)
         ops.gemm_raw(feats, w, out, B * P, d, Cc, 1, P, Cc, 1, d, bias=self.conv1.bias.detach(),

@@ -168,7 +168,13 @@ def wgrad_split(rows, n_out, k_in, grouped=False):
     return max(1, min(cap, rows // 256, (1600 + tiles // 2) // tiles))
 
 
-CONV1_TILE = (128, 64)   # workgroup tile ick_gemm picks for Encoder.conv1 at bench size (asserted by the parity tests)
+CONV1_TILE = (128, 64)   # workgroup tile ick_gemm picks for Encoder.conv1 at bench size on the exact fp32 MFMA
+
+
+def conv1_tile():
+    """The workgroup tile Encoder.conv1 runs on at bench size in the library's current product mode (asserted by the
+    parity tests): 128 x 160 of the pre-split kernel (csrc/gemm_ps.hip) with split products, else CONV1_TILE."""
+    return (128, 160) if gemm_split_mode() >= 1 else CONV1_TILE
 
 # test hook: a list that receives (M, N, K, plan dict) of every single-problem ick_gemm launch while it is set
 PLAN_LOG = None

@@ -13,6 +13,11 @@ from . import lib as L
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_GBS = 8000.0             # HBM3E spec
+# Kernels that form their fp32 products as six bf16 partial products (csrc/gemm.hip SPL, csrc/gemm_ps.hip) run on the bf16
+# matrix pipe: its dense peak (~2.5 PFLOP/s, MI355X_MICROARCH.md) divided by the six MFMAs per product block is the
+# fp32-equivalent ceiling of such a kernel -- a fraction against the 157.3 TF of the exact fp32 MFMA could exceed 1.
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+PEAK_SPLIT_FP32_EQ_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
 
 def _struct(arg):
@@ -25,13 +30,24 @@ def _gemm_label(a):
     return "%dx%dx%d (%s%s)" % (a.M, a.N, a.K, lay, ", split-K %d" % a.split_k if a.split_k > 1 else "")
 
 
+def _split_plan(a):
+    """Does ick_gemm form this problem's products on the bf16 pipe (plan query; nothing is launched)?"""
+    info = L.GemmPlanInfo()
+    if L.load_raw().ick_gemm_plan(C.byref(a), C.byref(info)) != 0:
+        return False, False
+    return bool(info.split_bf16), bool(info.presplit)
+
+
 def classify(name, args):
-    """-> (class label, work per launch, 'flop' | 'byte' | None)."""
+    """-> (class label, work per launch, 'flop' | 'byte' | 'flop_split' | None).  'flop_split': fp32-equivalent FLOP of a
+    kernel that runs on the bf16 matrix pipe (priced against PEAK_SPLIT_FP32_EQ_TFLOPS)."""
     if name == "ick_gemm":
         a = _struct(args[0])
         fl = 2.0 * a.M * a.N * a.K
+        spl, ps = _split_plan(a)
         if fl >= 2e9:
-            return "GEMM " + _gemm_label(a), fl, "flop"
+            tag = " [split-bf16 products, B pre-split]" if ps else (" [split-bf16 products]" if spl else "")
+            return "GEMM " + _gemm_label(a) + tag, fl, "flop_split" if spl else "flop"
         return "chain GEMMs (< 2 GFLOP each: projections, FFN, their data gradients)", fl, "flop"
     if name == "ick_gemm_grouped":
         arr, n = args[0], args[1]
@@ -124,10 +140,13 @@ def summarise(records, steps):
     for r in rows.values():
         n = r["launches"]
         row = {"name": r["name"], "launches_per_step": n / steps, "avg_us": r["us"] / n, "us_per_step": r["us"] / steps}
-        if r["unit"] == "flop" and r["us"] > 0:
+        if r["unit"] in ("flop", "flop_split") and r["us"] > 0:
             ach = r["work"] / (r["us"] * 1e-6) / 1e12
-            row.update(work_per_launch=r["work"] / n, unit="TFLOP/s", achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS,
-                       frac=ach / PEAK_FP32_MFMA_TFLOPS, bound="mfma")
+            peak = PEAK_SPLIT_FP32_EQ_TFLOPS if r["unit"] == "flop_split" else PEAK_FP32_MFMA_TFLOPS
+            row.update(work_per_launch=r["work"] / n, unit="TFLOP/s", achieved=ach, peak=peak, frac=ach / peak, bound="mfma",
+                       pipe="bf16 MFMA x 6 partial products (fp32-equivalent FLOP)" if r["unit"] == "flop_split"
+                       else "fp32 MFMA",
+                       frac_of_fp32_mfma_peak=ach / PEAK_FP32_MFMA_TFLOPS)
         elif r["unit"] == "byte" and r["us"] > 0:
             ach = r["work"] / (r["us"] * 1e-6) / 1e9
             row.update(work_per_launch=r["work"] / n, unit="GB/s", achieved=ach, peak=PEAK_HBM_GBS,

@@ -274,21 +274,14 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         # first), the decoder layers' after Encoder.conv1 has been enqueued, the transposed copies of the backward
         # chains on the side stream once the context chain is done (it idles until the backward pass).
         pk = dec._chain_pack(fresh=fresh_pack, subset=first if staged else None, copies=copies) if chain else None
-        # pre-split copies (three bf16 planes) of the weights the large GEMMs multiply with: the all-layer cross K/V
-        # weight, fc_vocab, and fc_vocab transposed for its data gradient (ick_gemm's b_ps, csrc/gemm_ps.hip)
+        # pre-split copy (three bf16 planes) of the all-layer cross K/V weight for the image rows' projection (ick_gemm's
+        # b_ps, csrc/gemm_ps.hip); fc_vocab's copy is made on the side stream behind the context chain (vocab_presplit)
         if ops.gemm_split_mode() >= 1 and not ops.is_deterministic():
-            vw = _p(dec.fc_vocab.weight)
             if fresh_pack:
                 m["wkv_ps"] = ops.presplit_buffer(nseg * d, d, dev)
-                m["vocab_ps"] = ops.presplit_buffer(V, d, dev)
-                m["vocab_t_ps"] = ops.presplit_buffer(d, V, dev)
-                ops.presplit_weights([(wkv, m["wkv_ps"]), (vw, m["vocab_ps"]), (vw.t(), m["vocab_t_ps"])])
+                ops.presplit_weights([(wkv, m["wkv_ps"])])
             else:
                 m["wkv_ps"] = dec._cross_kv_presplit(wkv)
-                m["vocab_ps"] = dec._vocab_presplit()
-                w_ = dec.fc_vocab.weight
-                m["vocab_t_ps"] = ops.presplit_cached(dec, "vocab_t", vw.t(), (w_._version, w_.data_ptr(),
-                                                                              dec.__dict__.get("_param_epoch", 0)))
         return ee, fe, wkv, bkv, pk
 
     if head_on_side:
@@ -299,6 +292,15 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         ee, fe, wkv, bkv, pk = head()
     # the context chains run beside Encoder.conv1 and the image K/V projection: 8-wave workgroups find room there
     slim_ctx = overlap and not os.environ.get("ICK_NO_SLIM")
+
+    def vocab_presplit():
+        # fc_vocab's pre-split copy: nothing needs it before the score head, so it is made where the side stream idles
+        if ops.gemm_split_mode() >= 1 and not ops.is_deterministic() and B * L >= 256:
+            if fresh_pack:
+                m["vocab_ps"] = ops.presplit_buffer(V, d, dev)
+                ops.presplit_weights([(_p(dec.fc_vocab.weight), m["vocab_ps"])])
+            else:
+                m["vocab_ps"] = dec._vocab_presplit()
 
     def entity_chain():
         ops.stamp("side: context chain starts")
@@ -311,6 +313,7 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         ops.stamp("side: context chain done")
         if staged and dec.chain_bwd_supported():
             m["pkb"] = dec._chain_pack(fresh=True, bwd=True, extra=[(("kv", "T"), wkv.t())])
+        vocab_presplit()
         if side is not None and side_tail is not None:
             side_tail()
 

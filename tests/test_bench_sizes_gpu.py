@@ -56,7 +56,7 @@ def test_conv1_at_bench_batch(plan_log, gemm_split):
     pl = plans_of(plan_log, B * 196, 300, 2048)
     assert len(pl) == 1
     # the long-K narrow-N instantiation (a dispatch change must update this line AND keep the parity above)
-    assert pl[0]["vec"] == 1 and pl[0]["a_kmajor"] == 1 and (pl[0]["tile_m"], pl[0]["tile_n"]) == ick_amd.ops.CONV1_TILE
+    assert pl[0]["vec"] == 1 and pl[0]["a_kmajor"] == 1 and (pl[0]["tile_m"], pl[0]["tile_n"]) == ick_amd.ops.conv1_tile()
     assert pl[0]["split_bf16"] == (1 if gemm_split else 0)
 
 
@@ -165,6 +165,8 @@ def test_cfg2_train_step_vs_oracle(plan_log, gemm_split):
     assert vocab_dgrad[0]["split_k"] >= 2                                  # long reduction split over workgroups
     assert vocab_fwd[0]["split_bf16"] == (1 if gemm_split else 0)          # the product mode under test really ran
     assert vocab_dgrad[0]["split_bf16"] == (1 if gemm_split == 2 else 0)   # k-major B operand: only in mode 2
+    if gemm_split:      # the forward GEMMs multiply with the pre-split weight copies (csrc/gemm_ps.hip)
+        assert vocab_fwd[0]["presplit"] == 1 and (vocab_fwd[0]["tile_m"], vocab_fwd[0]["tile_n"]) == (128, 128)
     kv = plans_of(log, B * 196, 1800, 300)
     assert kv and kv[0]["tile_m"] >= 64
     assert (V + K) % 4 == 0 and V + K <= 10240      # => packed CE keeps these rows in registers (score_head.hip)

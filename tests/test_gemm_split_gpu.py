@@ -226,14 +226,14 @@ def test_presplit_copy_is_the_exact_three_way_split(ops, N, K, transposed):
 
 
 @pytest.mark.parametrize("M,N,K,akm,grp,split_k,tile", [
-    (12544, 300, 2048, True, 196, 1, (64, 320)),      # Encoder.conv1: k-major NCHW map, 196 positions per sample
-    (1280, 300, 10000, False, 0, 12, (64, 320)),      # vocabulary data gradient: split K, atomics
+    (12544, 300, 2048, True, 196, 1, (128, 160)),      # Encoder.conv1: k-major NCHW map, 196 positions per sample
+    (1280, 300, 10000, False, 0, 12, (128, 160)),      # vocabulary data gradient: split K, atomics
     (1280, 10000, 300, False, 0, 1, (128, 128)),      # vocabulary projection (K tail of 12)
     (12544, 1800, 300, False, 0, 1, (128, 128)),      # cross K/V projection of the image rows
-    (2052, 132, 516, False, 0, 1, (64, 320)),         # ragged: M tail, N < 320 (pieces beyond the padded rows), K tail of 4
+    (4100, 132, 1028, False, 0, 1, (128, 160)),        # ragged: M tail, N < 320 (pieces beyond the padded rows), K tail of 4
     (2052, 1028, 516, False, 0, 1, (128, 128)),       # ragged edges of the square tile
     (2052, 1028, 516, True, 0, 1, (128, 128)),        # k-major A on the square tile
-    (2052, 260, 100, True, 0, 1, (64, 320)),          # k-major A, K tail of 4 k lines
+    (4100, 260, 516, True, 0, 1, (128, 160)),          # k-major A, K tail of 4 k lines
 ])
 def test_presplit_gemm_error_not_above_exact_path(ops, M, N, K, akm, grp, split_k, tile):
     if grp:
@@ -275,8 +275,9 @@ def test_presplit_gemm_error_not_above_exact_path(ops, M, N, K, akm, grp, split_
     smax, srms = errs(split, ref)
     assert srms <= 1.05 * erms, (srms, erms)
     assert smax <= 1.5 * emax, (smax, emax)
+    # in absolute terms: a few roundings of an fp32 sum of K products of this size (the maximum over up to 12 M outputs)
     unit = 2.0 ** -24 * math.sqrt(K) * 0.1
-    assert smax < 200 * unit and (split - exact).abs().max().item() < 250 * unit
+    assert smax < 300 * unit and (split - exact).abs().max().item() < 500 * unit
 
 
 def test_presplit_gemm_epilogues(ops):

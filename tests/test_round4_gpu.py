@@ -40,7 +40,7 @@ def test_cfg2_b64_from_features_vs_reference_digest(plan_log, gemm_split):
     kv = plans_of(plan_log, B * 196, 1800, 300)
     vocab = plans_of(plan_log, B * 20, 10000, 300)
     assert conv and kv and vocab
-    assert (conv[0]["tile_m"], conv[0]["tile_n"]) == ops.CONV1_TILE and conv[0]["a_kmajor"] == 1
+    assert (conv[0]["tile_m"], conv[0]["tile_n"]) == ops.conv1_tile() and conv[0]["a_kmajor"] == 1
     assert kv[0]["tile_m"] >= 64 and vocab[0]["tile_m"] >= 64
     for pl in (conv[0], kv[0], vocab[0]):
         assert pl["vec"] == 1 and pl["split_bf16"] == (1 if gemm_split else 0)
