@@ -40,7 +40,11 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_TABLE = os.path.join(ROOT, "profiles", "r03_traffic.json")   # PMC bytes per launch, see its "_source"
+TRAFFIC_TABLE = os.path.join(ROOT, "profiles", "r04_traffic.json")   # PMC bytes per launch, see its "_source"
+# kernel time per class INSIDE the captured step (rocprofv3 kernel trace of the same command; tools/in_step_table.py):
+# the eager single-stream pass below times every kernel alone, the captured step runs two streams beside each other
+IN_STEP_TABLE = {"train": os.path.join(ROOT, "profiles", "r04_in_step_train.json"),
+                 "forward": os.path.join(ROOT, "profiles", "r04_in_step_forward.json")}
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_GBS = 8000.0
 BEAM = 5
@@ -420,6 +424,17 @@ def main():
             # HBM bytes per launch from the PMC counters (valid for the workload they were collected on: cfg2 / cfg5)
             if r["name"] in traffic and cfgname in ("cfg2", "cfg5") and args.mode != "beam":
                 r["traffic"] = traffic[r["name"]]
+        in_step = {}
+        if cfgname == "cfg2" and _gemm_mode() == 1 and os.path.exists(IN_STEP_TABLE.get(args.mode, "")):
+            in_step = json.load(open(IN_STEP_TABLE[args.mode]))
+        for r in by_kernel:
+            t = in_step.get(r["name"])
+            if t and r.get("peak") and r.get("work_per_launch"):
+                # the same algorithmic work over the class's kernel time inside the captured step
+                r["in_step_us_per_step"] = t["us_per_step"]
+                ach = r["work_per_launch"] * r["launches_per_step"] / (t["us_per_step"] * 1e-6) / (1e12 if r["unit"] == "TFLOP/s" else 1e9)
+                r["achieved_in_step"] = ach
+                r["frac_in_step"] = ach / r["peak"]
         if by_kernel:
             dom = by_kernel[0]
             roof = {"bound": dom.get("bound", "latency"), "achieved": dom.get("achieved"), "peak": dom.get("peak"),
@@ -427,6 +442,9 @@ def main():
                     "kernel_avg_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
                     "share_of_kernel_time": dom["us_per_step"] / max(1e-9, sum(r["us_per_step"] for r in by_kernel)),
                     "traffic": dom.get("traffic"),
+                    # frac: the class timed alone (eager, one stream); frac_in_step: inside the captured step, beside the
+                    # other stream's kernels (profiles/r04_in_step_*.json, rocprofv3 of this command)
+                    "frac_in_step": dom.get("frac_in_step"), "in_step_source": in_step.get("_source"),
                     "sum_kernel_us_per_step": sum(r["us_per_step"] for r in by_kernel),
                     "by_kernel": by_kernel,
                     "how": "HIP events on the launch stream around every C-ABI launch of %d eager single-stream steps "
@@ -495,7 +513,11 @@ def main():
             if rf.get("kernel"):
                 entry["dominant_kernel"] = {"name": rf["kernel"], "avg_us": rf["kernel_avg_us"],
                                             "launches_per_step": rf["launches_per_step"], "frac": rf.get("frac"),
-                                            "bound": rf.get("bound"), "share_of_kernel_time": rf["share_of_kernel_time"]}
+                                            "bound": rf.get("bound"), "share_of_kernel_time": rf["share_of_kernel_time"],
+                                            "frac_in_step": rf.get("frac_in_step"),
+                                            # PMC bytes per launch (decode step: per token); null where no counter run
+                                            # of that workload is committed (profiles/r04_traffic.json)
+                                            "traffic": rf.get("traffic")}
             modes[name] = entry
         out["modes"] = modes
 

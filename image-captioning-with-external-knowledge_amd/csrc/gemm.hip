@@ -726,7 +726,9 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
             // the vocabulary data gradient) read their A operand once on 128 x 160 (121 us against 139-187).  Larger tiles
             // and deeper rings bought nothing: every variant settles near 120-135 TFLOP/s fp32-equivalent, ~60 % of what
             // the bf16 pipe holds on random data at the clock the chip keeps under MFMA load (MI355X_MICROARCH.md).
-            int best = a.N <= 320 ? 2 : 1;
+            // (split-K problems -- the cross K/V weight gradient, 600 x 300 over 13 824 rows -- also run best on 128 x 128:
+            // 62-67 us against 70-77 on 128 x 160 and 87-93 on the exact 64 x 64 tile, profiles/r04_i_gemm_ps_kv_wgrad.txt)
+            int best = (a.N <= 320 && split_req == 1) ? 2 : 1;
             if (ps_tile_env >= 0 && ps_tile_env < gemm_ps_tile_count()) best = ps_tile_env;
             int bm, bn, wpc; gemm_ps_tile_dims(best, &bm, &bn, &wpc);
             pl.ps = true; pl.ps_tile = best;

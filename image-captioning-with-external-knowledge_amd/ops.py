@@ -120,15 +120,15 @@ def presplit_cached(holder, name, w2d, key):
     return ent[1]
 
 
-def colsum_problem(a2d, out):
+def colsum_problem(a2d, out, split_k=1):
     """ick_gemm_args of a pure column sum out[n] += sum_m a2d[m, n] (ICK_GEMM_COLSUM_ONLY): no kernel of its own,
-    it rides in a grouped launch (gemm_grouped) with the weight-gradient GEMMs."""
+    it rides in a grouped launch (gemm_grouped) with the weight-gradient GEMMs.  split_k: row slices (float atomics)."""
     rows, cols = a2d.shape
     a = L.GemmArgs()
     a.A, a.colsum_a = _p(a2d), _p(out)
     a.M, a.N, a.K = cols, 1, rows
     a.a_rs, a.a_ks = 1, a2d.stride(0)
-    a.flags, a.split_k, a.alpha = L.GEMM_COLSUM_ONLY, 1, 1.0
+    a.flags, a.split_k, a.alpha = L.GEMM_COLSUM_ONLY | (L.GEMM_ATOMIC if split_k > 1 else 0), split_k, 1.0
     a.a_extent = _extent(a2d)
     return a
 

@@ -533,7 +533,7 @@ def _context_encoder_bwd(dec, stack, tapes, dx, grads, pkb=None, tag="e", g_firs
     return dx
 
 
-def _decoder_layer_bwd_chain(dec, li, layer, t, state, dkv_rows, kv, S, grads, pkb, mem2=None):
+def _decoder_layer_bwd_chain(dec, li, layer, t, state, dkv_rows, kv, S, grads, pkb, mem2=None, mem_t_ps=None):
     """Backward of decoder layer li as two ops.rowchain_bwd launches around the cross-attention backward + the
     self-attention backward.  state = (dz, g0, w0p): the residual-path gradient of this layer's output, and -- from the
     layer above -- the in_proj gradient whose data gradient rides on this layer's first launch.  Returns the state
@@ -574,7 +574,7 @@ def _decoder_layer_bwd_chain(dec, li, layer, t, state, dkv_rows, kv, S, grads, p
     if sub >= 1:
         ops.SIDE.flush()
     if mem2 is not None:
-        _kv_proj_param_grads(layer, li, dkv_rows, mem2, grads, d)
+        _kv_proj_param_grads(layer, li, dkv_rows, mem2, grads, d, mem_t_ps)
     if sub >= 2:
         ops.SIDE.flush_group()      # the K/V-projection weight gradient (the heavy one) starts right behind its operand
     n1 = _norm_args(t, 1, t["x"], layer.norm1, grads, M, d, dev)
@@ -605,7 +605,7 @@ def _decoder_layer_bwd_chain(dec, li, layer, t, state, dkv_rows, kv, S, grads, p
     return out
 
 
-def _decoder_layer_bwd(dec, li, layer, t, dx, dkv_rows, kv, S, grads, mem2=None):
+def _decoder_layer_bwd(dec, li, layer, t, dx, dkv_rows, kv, S, grads, mem2=None, mem_t_ps=None):
     H, d = dec.num_heads, dec.emb_dim
     dh = d // H
     B, T, _ = t["x"].shape
@@ -627,7 +627,7 @@ def _decoder_layer_bwd(dec, li, layer, t, dx, dkv_rows, kv, S, grads, mem2=None)
     if mem2 is not None:
         # this layer's columns of the K/V-projection gradient are complete: its weight (and bias) gradient over
         # all B * S memory rows joins this layer's group instead of waiting for the whole decoder stack
-        _kv_proj_param_grads(layer, li, dkv_rows, mem2, grads, d)
+        _kv_proj_param_grads(layer, li, dkv_rows, mem2, grads, d, mem_t_ps)
     dx1 = _lin_bwd(grads, dq.view(M, d), t["x1"].view(M, d), layer.multihead_attn.in_proj_weight,
                    layer.multihead_attn.in_proj_bias, w_rows=slice(0, d), dx=dz.view(M, d), acc=True)
     dz, do1 = ops.layernorm_bwd(dx1.view(B, T, d), t["o1"], t["x"], _p(layer.norm1.weight), t["m1"], t["r1"],
@@ -645,21 +645,52 @@ def _decoder_layer_bwd(dec, li, layer, t, dx, dkv_rows, kv, S, grads, mem2=None)
     return dx0
 
 
-def _kv_proj_param_grads(layer, li, dkv_rows, mem2, grads, d):
-    """dW[d:3d] += dkv[:, layer columns].T @ memory, db[d:3d] += column sums (fused), for one decoder layer."""
+def _kv_proj_param_grads(layer, li, dkv_rows, mem2, grads, d, mem_t_ps=None):
+    """dW[d:3d] += dkv[:, layer columns].T @ memory, db[d:3d] += column sums (fused), for one decoder layer.
+    mem_t_ps: the pre-split copy of memory^T (d x rows; made once per backward pass on the side stream): the product then
+    runs on the LDS-DMA kernel of csrc/gemm_ps.hip (600 x 300 outputs over 13 824 rows: 75-88 -> ~50 us per layer) and the
+    bias gradient becomes a plain column sum in the same side-stream group."""
     gw, gb = _g(grads, layer.multihead_attn.in_proj_weight), _g(grads, layer.multihead_attn.in_proj_bias)
     rows = mem2.shape[0]
     sl = dkv_rows.view(rows, -1)[:, 2 * li * d:(2 * li + 2) * d]
     if gw is not None:
-        wg = ops.gemm_args(sl, mem2, gw[d:], 2 * d, d, rows, 1, sl.stride(0), 1, d, d, atomic=True,
-                           split_k=1 if ops.is_deterministic() else int(os.environ.get("ICK_KV_WGRAD_SPLIT", "16")),
-                           colsum_a=None if gb is None else gb[d:])
-        if ops.SIDE is not None:
-            ops.SIDE.add_problem(wg, dkv_rows, mem2)
+        if mem_t_ps is not None:
+            # 5 x 2 tiles of 128 x 160: K slices so that ~240 workgroups exist (one per CU)
+            split = max(1, min(32, 240 // (((2 * d + 127) // 128) * ((d + 159) // 160)), rows // 256))
+            wg = ops.gemm_args(sl, mem2, gw[d:], 2 * d, d, rows, 1, sl.stride(0), 1, d, d, atomic=True,
+                               split_k=int(os.environ.get("ICK_KV_WGRAD_SPLIT", split)), b_ps=mem_t_ps)
+            extra = [] if gb is None else [ops.colsum_problem(sl, gb[d:], split_k=max(1, min(16, rows // 512)))]
         else:
-            ops.gemm_grouped([wg])
+            wg = ops.gemm_args(sl, mem2, gw[d:], 2 * d, d, rows, 1, sl.stride(0), 1, d, d, atomic=True,
+                               split_k=1 if ops.is_deterministic() else int(os.environ.get("ICK_KV_WGRAD_SPLIT", "16")),
+                               colsum_a=None if gb is None else gb[d:])
+            extra = []
+        if ops.SIDE is not None:
+            ops.SIDE.add_problem(wg, dkv_rows, mem2, mem_t_ps)
+            for e in extra:
+                ops.SIDE.add_problem(e, dkv_rows)
+        else:
+            ops.gemm_grouped([wg] + extra)
     elif gb is not None:
         ops.colsum(sl, gb[d:])
+
+
+def _memory_t_presplit(m, B, S, d):
+    """Pre-split copy of memory^T (csrc/gemm_ps.hip's B operand for the cross K/V weight gradients), made where the side
+    stream starts its backward work; None in the exact / deterministic modes."""
+    if ops.gemm_split_mode() < 1 or ops.is_deterministic() or os.environ.get("ICK_NO_KV_WGRAD_PS") or B * S < 2048:
+        return None
+    mem2 = m["mem"].view(B * S, d)
+    buf = ops.presplit_buffer(d, B * S, mem2.device)
+
+    def make():
+        ops.presplit_weights([(mem2.t(), buf)])
+
+    if ops.SIDE is not None:
+        ops.SIDE.submit(make, mem2, buf)
+    else:
+        make()
+    return buf
 
 
 def backward_from_tape(dec, tape, dscores, grads, overlap=True, want_image_grad=False):
@@ -698,7 +729,10 @@ class BackwardPass:
     embeddings.  The two phases may be captured into two hipGraphs."""
 
     def __init__(self, dec, tape, dscores, grads, overlap=True, want_image_grad=False):
-        self.side = ops.SideStream() if overlap else None
+        # ICK_BWD_SIDE_PRIO (experiment): priority of the stream that carries the bulk weight-gradient GEMMs beside the
+        # latency-bound data-gradient chain (torch: larger number = lower priority)
+        self.side_prio = int(os.environ.get("ICK_BWD_SIDE_PRIO", "0"))
+        self.side = ops.SideStream(priority=self.side_prio) if overlap else None
         self.gen = _backward_phases(dec, tape, dscores, grads, want_image_grad)
 
     def _run(self, join):
@@ -719,7 +753,7 @@ class BackwardPass:
             # the two phases may be captured into two graphs: each graph gets a side stream of its own (one stream
             # object forked into two captures made every kernel of both graphs run ~2.5x slower on ROCm 7.2)
             self.retired = self.side          # keeps the tensors the first phase's side work read alive
-            self.side = ops.SideStream()
+            self.side = ops.SideStream(priority=self.side_prio)
         self._run(True)
 
 
@@ -782,17 +816,18 @@ def _backward_phases(dec, tape, dscores, grads, want_image_grad=False):
     dx = dh
     ops.stamp("bwd: head done")
     pkb = m.get("pkb")
+    mem_t_ps = _memory_t_presplit(m, B, S, d)
     if pkb is not None:
         state = (dh.view(M, d), None, None)
         for li in reversed(range(len(layers))):
             state = _decoder_layer_bwd_chain(dec, li, layers[li], tape.dec_layers[li], state, dkv_rows, m["kv"], S,
-                                             grads, pkb, mem2=m["mem"].view(B * S, d))
+                                             grads, pkb, mem2=m["mem"].view(B * S, d), mem_t_ps=mem_t_ps)
             ops.stamp("bwd: decoder layer %d done" % li)
         dx = state[0]
     else:
         for li in reversed(range(len(layers))):
             dx = _decoder_layer_bwd(dec, li, layers[li], tape.dec_layers[li], dx, dkv_rows, m["kv"], S, grads,
-                                    mem2=m["mem"].view(B * S, d))
+                                    mem2=m["mem"].view(B * S, d), mem_t_ps=mem_t_ps)
             ops.stamp("bwd: decoder layer %d done" % li)
     yield    # ---- end of the early phase: every gradient of early_parameters() has been enqueued
     # ---- cross K/V projection: the weight gradients went out with the decoder layers; data gradient for the

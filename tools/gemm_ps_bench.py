@@ -15,6 +15,8 @@ SHAPES = {  # name: (M, N, K, a_layout, split_k)
     "vocab_dgrad": (1280, 300, 10000, "rows", 0),
     "cross_kv": (12544, 1800, 300, "rows", 1),
     "vocab_fwd": (1280, 10000, 300, "rows", 1),
+    "kv_wgrad": (600, 300, 13824, "kmaj1800", 24),      # dW_kv of one layer: A = a 600-column slice of the (13824, 1800) K/V gradient
+    "kv_wgrad_s16": (600, 300, 13824, "kmaj1800", 16),
     "cross_kv_cfg4": (12544, 1800, 300, "rows", 1),
     "vocab_fwd_cfg4": (1280, 50000, 300, "rows", 1),
 }
@@ -31,6 +33,11 @@ def child(name):
         A = torch.randn(M // 196, K, 196, device="cuda", generator=g)
         aargs = (1, 196)
         akw = dict(a_grp=196, a_gs=K * 196)
+    elif lay.startswith("kmaj"):
+        ld = int(lay[4:])
+        A = torch.randn(K, ld, device="cuda", generator=g)[:, :M]     # element (m, k) at A[k, m]
+        aargs = (1, ld)
+        akw = {}
     else:
         A = torch.randn(M, K, device="cuda", generator=g)
         aargs = (K, 1)
