@@ -719,7 +719,11 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
             e = getenv("ICK_PS_NT"); ps_nt_env = e ? atoi(e) : -1;
         }
         const double flop = 2.0 * a.M * a.N * a.K;
-        if (ps_on && flop >= 1.0e9 && a.M >= 256 && a.N >= 128) {
+        // a one-column-tile problem (N <= 320, no K split) needs ~180 row tiles of 128 to fill the chip with the pre-split
+        // kernel's one-workgroup-per-CU tile (Encoder.conv1 at batch 32 -- 98 workgroups -- took as long as at batch 64);
+        // below that the stager-split kernel's 128 x 64 tiles (five per row panel) are the better fit
+        const bool narrow_underfilled = a.N <= 320 && split_req == 1 && ceil_div(a.M, 128) * ceil_div(a.N, 160) < 180;
+        if (ps_on && flop >= 1.0e9 && a.M >= 256 && a.N >= 128 && (!narrow_underfilled || ps_tile_env >= 0)) {
             // Tile choice, measured (tools/gemm_ps_bench.py, profiles/r04_e_gemm_ps_tiles.txt: every tile x every shape):
             // 128 x 128 with two workgroups per CU wins wherever the output is wider than 320 columns (cross K/V 100 us
             // against 129-143 on the other tiles, vocabulary 65 against 80-88); outputs at most 320 wide (Encoder.conv1,
@@ -728,7 +732,9 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
             // the bf16 pipe holds on random data at the clock the chip keeps under MFMA load (MI355X_MICROARCH.md).
             // (split-K problems -- the cross K/V weight gradient, 600 x 300 over 13 824 rows -- also run best on 128 x 128:
             // 62-67 us against 70-77 on 128 x 160 and 87-93 on the exact 64 x 64 tile, profiles/r04_i_gemm_ps_kv_wgrad.txt)
-            int best = (a.N <= 320 && split_req == 1) ? 2 : 1;
+            static int narrow_tile = -1;
+            if (narrow_tile < 0) { const char* e = getenv("ICK_PS_NARROW_TILE"); narrow_tile = e ? atoi(e) : 2; }
+            int best = (a.N <= 320 && split_req == 1) ? narrow_tile : 1;
             if (ps_tile_env >= 0 && ps_tile_env < gemm_ps_tile_count()) best = ps_tile_env;
             int bm, bn, wpc; gemm_ps_tile_dims(best, &bm, &bn, &wpc);
             pl.ps = true; pl.ps_tile = best;

@@ -358,9 +358,11 @@ int launch_ps_tile(const ick_gemm_args& a, bool akm, int np, int64_t bytes, int 
 //   3: 128 x 320  4 x 2 waves of 32 x 160, D 1, 152 KB
 //   4: 128 x 128  8 x 1 waves of 16 x 128, D 2, 120 KB: one workgroup per CU, the LDS-DMA latency (~1.1 us from issue to
 //                 landing, longer than a slice's MFMA phase) hidden by the deeper ring instead
-constexpr int kPsTiles = 5;
+//   5: 128 x 160  as 2 with D 1, 92 KB: leaves 68 KB of a CU's LDS to a workgroup of the latency-bound chain kernels that
+//                 run beside Encoder.conv1 on the other stream
+constexpr int kPsTiles = 6;
 void gemm_ps_tile_dims(int tile, int* bm, int* bn, int* wgs_per_cu) {
-    static const int dims[kPsTiles][3] = {{64, 320, 1}, {128, 128, 2}, {128, 160, 1}, {128, 320, 1}, {128, 128, 1}};
+    static const int dims[kPsTiles][3] = {{64, 320, 1}, {128, 128, 2}, {128, 160, 1}, {128, 320, 1}, {128, 128, 1}, {128, 160, 1}};
     *bm = dims[tile][0]; *bn = dims[tile][1]; *wgs_per_cu = dims[tile][2];
 }
 int gemm_ps_tile_count() { return kPsTiles; }
@@ -376,6 +378,7 @@ int launch_gemm_ps(const ick_gemm_args& a, bool akm, int tile, int tiles_m, int 
         case 2: return launch_ps_tile<8, 1, 1, 10, 2, 10>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
         case 3: return launch_ps_tile<4, 2, 2, 10, 1, 3>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
         case 4: return launch_ps_tile<8, 1, 1, 8, 2, 8>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
+        case 5: return launch_ps_tile<8, 1, 1, 10, 1, 10>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
     }
     return ICK_EINVAL;
 }

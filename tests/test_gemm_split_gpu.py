@@ -230,10 +230,10 @@ def test_presplit_copy_is_the_exact_three_way_split(ops, N, K, transposed):
     (1280, 300, 10000, False, 0, 12, (128, 128)),      # vocabulary data gradient: split K, atomics
     (1280, 10000, 300, False, 0, 1, (128, 128)),      # vocabulary projection (K tail of 12)
     (12544, 1800, 300, False, 0, 1, (128, 128)),      # cross K/V projection of the image rows
-    (4100, 132, 1028, False, 0, 1, (128, 160)),        # ragged: M tail, N < 320 (pieces beyond the padded rows), K tail of 4
+    (23044, 132, 516, False, 0, 1, (128, 160)),        # ragged: M tail, N < 320 (pieces beyond the padded rows), K tail of 4
     (2052, 1028, 516, False, 0, 1, (128, 128)),       # ragged edges of the square tile
     (2052, 1028, 516, True, 0, 1, (128, 128)),        # k-major A on the square tile
-    (4100, 260, 516, True, 0, 1, (128, 160)),          # k-major A, K tail of 4 k lines
+    (23044, 260, 516, True, 0, 1, (128, 160)),         # k-major A, K tail of 4 k lines
 ])
 def test_presplit_gemm_error_not_above_exact_path(ops, M, N, K, akm, grp, split_k, tile):
     if grp:
@@ -278,6 +278,22 @@ def test_presplit_gemm_error_not_above_exact_path(ops, M, N, K, akm, grp, split_
     # in absolute terms: a few roundings of an fp32 sum of K products of this size (the maximum over up to 12 M outputs)
     unit = 2.0 ** -24 * math.sqrt(K) * 0.1
     assert smax < 300 * unit and (split - exact).abs().max().item() < 500 * unit
+
+
+def test_underfilled_narrow_problem_keeps_the_stager_split_kernel(ops):
+    """Encoder.conv1 at batch 32 (6 272 rows: 98 workgroups of the pre-split kernel's 128 x 160 tile) stays on the
+    tiles of csrc/gemm.hip; at batch 64 it takes the pre-split kernel."""
+    before = ops.gemm_split_mode()
+    ops.set_gemm_split(1)
+    try:
+        for Bn, want in ((32, 0), (64, 1)):
+            M, N, K = Bn * 196, 300, 2048
+            A, W, out = torch.empty(Bn, K, 196, device="cuda"), torch.empty(N, K, device="cuda"), torch.empty(M, N, device="cuda")
+            ps = ops.presplit_buffer(N, K, "cuda")
+            info = plan_of(ops, ops.gemm_args(A, W, out, M, N, K, 1, 196, K, 1, N, a_grp=196, a_gs=K * 196, b_ps=ps))
+            assert info.presplit == want and (info.tile_m, info.tile_n) == ((128, 160) if want else (info.tile_m, info.tile_n)), (Bn, info.presplit)
+    finally:
+        ops.set_gemm_split(before)
 
 
 def test_presplit_gemm_epilogues(ops):
