@@ -128,6 +128,17 @@ def run_train_step_vs_oracle(variant, B, L, K, V, Fn, seed, plan_log):
         err = d.max().item() / scale
         assert err < 2e-3, ("gradient", k, err)
     assert len(flipped) <= 2, flipped
+    # The optimizer itself, on EVERY element: from the gradient the bucket held, Adam's first
+    # step is w - lr * g / (|g| + eps) exactly (bias-corrected moments of a single step are g and g^2), so the post-step
+    # weights are checked against that closed form with no conditioning allowance -- the comparison with the oracle's
+    # weights below then only has to allow for what the (separately checked) gradient difference does to them.
+    for k, p0 in P.items():
+        if k.startswith("fact_encoder.") or k not in named:
+            continue
+        g = ts.grads[id(named[k])].detach().cpu().double()
+        expect = p0.double() - 4e-4 * g / (g.abs() + 1e-8)
+        err = (named[k].detach().cpu().double() - expect).abs().max().item()
+        assert err < 2e-7 + 1e-6 * p0.abs().max().item(), ("Adam closed form", k, err)
     for k, pr in P_after.items():
         if k.startswith("fact_encoder."):
             continue
