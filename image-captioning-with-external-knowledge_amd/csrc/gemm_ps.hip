@@ -112,7 +112,7 @@ struct PsCfg {
     static constexpr int LDS = ST * (A_STAGE + B_STAGE) + SCRATCH;
     static constexpr int IN_FLIGHT = (D - 1) * (PA_W + PB_W);   // pieces of the younger slices at the end of an iteration
     static_assert(NPA % NW == 0 && PA_W >= 1, "every wave issues the same number of A pieces (counted vmcnt)");
-    static_assert(D == 1 || D == 2, "ring depth");
+    static_assert(D >= 1 && D <= 3, "ring depth");
     static_assert(LDS <= 160 * 1024, "tile exceeds the LDS of a CU");
 };
 
@@ -269,9 +269,15 @@ __attribute__((amdgpu_waves_per_eu(1, (PsCfg<WM_, WN_, TM_, TN_, AKM_, D_, PF_>:
             for (int pl = 0; pl < 3; ++pl)
                 f[pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(ptr + pl * C::B_PLANE));
         };
-        bf16x8_t bf[TN][3];
+        // The TN column blocks are processed in groups of GB = PF blocks: the next group's fragments are requested while
+        // this group's MFMAs issue, and inside a group the six partial products are the OUTER loop -- consecutive MFMAs
+        // then go to different accumulators.  (Six MFMAs in a row into one accumulator ran at half rate: every tile shape
+        // settled at 32 cycles per v_mfma_f32_16x16x32_bf16, profiles/r04_*_gemm_ps_tiles.txt.)  The order of the six
+        // products per accumulator is unchanged (smallest first), so the sums are bit-identical.
+        constexpr int GB = C::PF, NG = (TN + GB - 1) / GB;
+        bf16x8_t bf[2][GB][3];
 #pragma unroll
-        for (int b = 0; b < C::PF; ++b) read_b(b, bf[b]);
+        for (int j = 0; j < GB; ++j) read_b(j, bf[0][j]);
         // the wave's A fragments (TM x 16 rows x 32 k): raw fp32 -> three bf16 planes each (the split's ~44 VALU
         // instructions per fragment run while the B fragments are on their way)
         bf16x8_t af[TM][3];
@@ -299,20 +305,24 @@ __attribute__((amdgpu_waves_per_eu(1, (PsCfg<WM_, WN_, TM_, TN_, AKM_, D_, PF_>:
         }
         // the scheduler must not sink the fragment requests back to their uses (it would, to save registers)
         __builtin_amdgcn_sched_barrier(0);
+        constexpr int pa[6] = {0, 2, 1, 0, 1, 0}, pb[6] = {2, 0, 1, 1, 0, 0};     // (A plane, B plane), smallest products first
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            if (b + C::PF < TN) read_b(b + C::PF, bf[b + C::PF]);
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) {
 #pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                f32x4 c = acc[a][b];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[b][2], c, 0, 0, 0);     // smallest products first
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][2], bf[b][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][1], bf[b][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[b][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][1], bf[b][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][0], bf[b][0], c, 0, 0, 0);
-                acc[a][b] = c;
+                for (int j = 0; j < GB; ++j)
+                    if ((g + 1) * GB + j < TN) read_b((g + 1) * GB + j, bf[(g + 1) & 1][j]);
             }
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int j = 0; j < GB; ++j)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+                        const int b = g * GB + j;
+                        if (b < TN)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][pa[q]], bf[g & 1][j][pb[q]], acc[a][b], 0, 0, 0);
+                    }
         }
         // slice it + 1 has landed (in-order completion: only the pieces of the D - 1 younger slices may remain)
         ICK_WAIT_VMCNT(C::IN_FLIGHT);
@@ -360,9 +370,18 @@ int launch_ps_tile(const ick_gemm_args& a, bool akm, int np, int64_t bytes, int 
 //                 landing, longer than a slice's MFMA phase) hidden by the deeper ring instead
 //   5: 128 x 160  as 2 with D 1, 92 KB: leaves 68 KB of a CU's LDS to a workgroup of the latency-bound chain kernels that
 //                 run beside Encoder.conv1 on the other stream
-constexpr int kPsTiles = 6;
+//   6, 7: 128 x 96 with D 2 / D 3 (102 / 136 KB) -- a probe of how the slice time depends on the ring depth alone
+//   8: 128 x 128  4 x 2 waves of 32 x 64 (TM 2, TN 4), D 1, 80 KB, two workgroups per CU
+//   9: 128 x 160  4 x 2 waves of 32 x 80 (TM 2, TN 5), D 2, 139 KB
+//      The kernel turned out to be bound by LDS bandwidth (every tile's slice time = its LDS bytes / ~150 KB per us,
+//      profiles/r04_*_gemm_ps_tiles.txt): a wave reads 128 B per row (raw A) + 192 B per column (B planes) of its tile per
+//      slice, so 32-row wave tiles read 1.5 x less than the 16-row ones of shapes 1 and 2 for the same products.
+//  10: 64 x 64    2 x 2 waves of 32 x 32, D 1, 40 KB: four independent workgroups per CU (probe: do more workgroups that
+//                 are not coupled by a barrier overlap their LDS / split phases with each other's MFMAs?)
+//  11: 64 x 128   2 x 2 waves of 32 x 64, D 1, 64 KB: two per CU
+constexpr int kPsTiles = 12;
 void gemm_ps_tile_dims(int tile, int* bm, int* bn, int* wgs_per_cu) {
-    static const int dims[kPsTiles][3] = {{64, 320, 1}, {128, 128, 2}, {128, 160, 1}, {128, 320, 1}, {128, 128, 1}, {128, 160, 1}};
+    static const int dims[kPsTiles][3] = {{64, 320, 1}, {128, 128, 2}, {128, 160, 1}, {128, 320, 1}, {128, 128, 1}, {128, 160, 1}, {128, 96, 1}, {128, 96, 1}, {128, 128, 2}, {128, 160, 1}, {64, 64, 4}, {64, 128, 2}};
     *bm = dims[tile][0]; *bn = dims[tile][1]; *wgs_per_cu = dims[tile][2];
 }
 int gemm_ps_tile_count() { return kPsTiles; }
@@ -379,6 +398,12 @@ int launch_gemm_ps(const ick_gemm_args& a, bool akm, int tile, int tiles_m, int 
         case 3: return launch_ps_tile<4, 2, 2, 10, 1, 3>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
         case 4: return launch_ps_tile<8, 1, 1, 8, 2, 8>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
         case 5: return launch_ps_tile<8, 1, 1, 10, 1, 10>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
+        case 6: return launch_ps_tile<8, 1, 1, 6, 2, 6>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
+        case 7: return launch_ps_tile<8, 1, 1, 6, 3, 6>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
+        case 8: return launch_ps_tile<4, 2, 2, 4, 1, 2>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
+        case 9: return launch_ps_tile<4, 2, 2, 5, 2, 5>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
+        case 10: return launch_ps_tile<2, 2, 2, 2, 1, 2>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
+        case 11: return launch_ps_tile<2, 2, 2, 4, 1, 2>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
     }
     return ICK_EINVAL;
 }
