@@ -732,9 +732,7 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
             // the bf16 pipe holds on random data at the clock the chip keeps under MFMA load (MI355X_MICROARCH.md).
             // (split-K problems -- the cross K/V weight gradient, 600 x 300 over 13 824 rows -- also run best on 128 x 128:
             // 62-67 us against 70-77 on 128 x 160 and 87-93 on the exact 64 x 64 tile, profiles/r04_i_gemm_ps_kv_wgrad.txt)
-            static int narrow_tile = -1;
-            if (narrow_tile < 0) { const char* e = getenv("ICK_PS_NARROW_TILE"); narrow_tile = e ? atoi(e) : 2; }
-            int best = (a.N <= 320 && split_req == 1) ? narrow_tile : 1;
+            int best = (a.N <= 320 && split_req == 1) ? 2 : 1;
             if (ps_tile_env >= 0 && ps_tile_env < gemm_ps_tile_count()) best = ps_tile_env;
             int bm, bn, wpc; gemm_ps_tile_dims(best, &bm, &bn, &wpc);
             pl.ps = true; pl.ps_tile = best;

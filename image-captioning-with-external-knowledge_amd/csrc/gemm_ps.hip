@@ -31,6 +31,23 @@
 
 #include "gemm_common.h"
 
+// Diagnostic build (-DICK_PS_STAMPS, tools/debug/gemm_ps_stamps.py): wave 0 of one workgroup in the middle of the grid sums
+// the shader-clock ticks it spends in each phase of a slice.  Compiled out of the product library.
+#ifdef ICK_PS_STAMPS
+__device__ unsigned long long ick_ps_stamps[8];
+#define ICK_PSTAMP(var)                                   \
+    do {                                                  \
+        __builtin_amdgcn_sched_barrier(0);                \
+        var = __builtin_amdgcn_s_memtime();               \
+        __builtin_amdgcn_sched_barrier(0);                \
+    } while (0)
+extern "C" int ick_debug_read_ps_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ick_ps_stamps), sizeof(ick_ps_stamps));
+}
+#else
+#define ICK_PSTAMP(var)
+#endif
+
 namespace ick {
 namespace {
 
@@ -112,7 +129,7 @@ struct PsCfg {
     static constexpr int LDS = ST * (A_STAGE + B_STAGE) + SCRATCH;
     static constexpr int IN_FLIGHT = (D - 1) * (PA_W + PB_W);   // pieces of the younger slices at the end of an iteration
     static_assert(NPA % NW == 0 && PA_W >= 1, "every wave issues the same number of A pieces (counted vmcnt)");
-    static_assert(D >= 1 && D <= 3, "ring depth");
+    static_assert(D == 1 || D == 2, "ring depth");
     static_assert(LDS <= 160 * 1024, "tile exceeds the LDS of a CU");
 };
 
@@ -143,7 +160,7 @@ __device__ __forceinline__ void ps_dma_b(const __amdgpu_buffer_rsrc_t& rsrc, cha
 // weight planes, which every workgroup of the XCD re-reads, from that XCD's L2
 template <class C>
 __device__ __forceinline__ void ps_dma_a(const __amdgpu_buffer_rsrc_t& rsrc, char* As, int buf, int wave,
-                                         const uint32_t (&avoff)[C::PA_W], const int (&akl)[C::PA_W], int k0, int kend,
+                                         const uint32_t* avoff, const int* akl, int k0, int kend,
                                          uint32_t soff, bool nt) {
 #pragma unroll
     for (int j = 0; j < C::PA_W; ++j) {
@@ -152,6 +169,34 @@ __device__ __forceinline__ void ps_dma_a(const __amdgpu_buffer_rsrc_t& rsrc, cha
         lds_void_ptr dst = (lds_void_ptr)(As + buf * C::A_STAGE + g * 1024);
         if (nt) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, in ? avoff[j] : kOobOffset, soff, 0, 2);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, in ? avoff[j] : kOobOffset, soff, 0, 0);
+    }
+}
+
+// Piece `idx` of this wave's share of a slice (B pieces first, then A pieces): the kernel issues them one at a time BETWEEN
+// its MFMAs.  (All eight waves issuing their pieces together right behind the barrier stalled every wave for ~700 cycles
+// per slice: a CU's address unit takes one 1 KiB wave request per 16 cycles -- tools/debug/gemm_ps_stamps.py.)
+template <class C>
+__device__ __forceinline__ void ps_dma_piece(int idx, const __amdgpu_buffer_rsrc_t& rsrc_a, const __amdgpu_buffer_rsrc_t& rsrc_b,
+                                             char* As, char* Bs, char* scratch, int buf, int wave, uint32_t bvoff,
+                                             const uint32_t* avoff, const int* akl, int slice, bool valid,
+                                             int n0, int np_rows, int k0, int kend, uint32_t soff_a) {
+    if (idx < C::PB_W) {
+        const int g = wave + C::NW * idx;
+        if (g < C::NPB) {               // wave-uniform
+            const int plane = g / (C::BN / 16), rblk = g % (C::BN / 16);
+            const bool in = valid && (n0 + rblk * 16 < np_rows);
+            const uint32_t soff = (uint32_t)((((int64_t)slice * 3 + plane) * np_rows + rblk * 16) * 64);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void_ptr)(Bs + buf * C::B_STAGE + plane * C::B_PLANE + rblk * 1024),
+                                                     16, in ? bvoff : kOobOffset, in ? soff : 0u, 0, 0);
+        } else if (C::UNIFORM) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void_ptr)scratch, 16, kOobOffset, 0u, 0, 0);
+        }
+    } else {
+        const int j = idx - C::PB_W;
+        const int g = wave + C::NW * j;
+        const bool in = k0 + akl[j] < kend;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void_ptr)(As + buf * C::A_STAGE + g * 1024), 16,
+                                                 in ? avoff[j] : kOobOffset, soff_a, 0, 0);
     }
 }
 
@@ -248,17 +293,25 @@ __attribute__((amdgpu_waves_per_eu(1, (PsCfg<WM_, WN_, TM_, TN_, AKM_, D_, PF_>:
     ICK_WAIT_VMCNT(C::IN_FLIGHT);
     ICK_LDS_BARRIER();
 
+#ifdef ICK_PS_STAMPS
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, ta = 0, tb = 0, tc = 0, td = 0, te = 0, tf = 0;
+#endif
     int buf = 0;                             // ring buffer holding slice `it`
     for (int it = 0; it < nk; ++it) {
-        // requests first: slice it + D into the buffer that was read in iteration it - 1 (slices beyond the range are zero
-        // fills that touch no memory: the piece counts stay constant, so the waits below are immediates)
-        {
-            int nb = buf + D;
-            if (nb >= ST) nb -= ST;
-            dma_b(it + D, nb);
-            dma_a(it + D, nb);
-        }
+        ICK_PSTAMP(ta);
+        // slice it + D goes into the buffer that was read in iteration it - 1 (slices beyond the range are zero fills that
+        // touch no memory: the piece counts stay constant, so the waits below are immediates); its pieces are issued one
+        // by one between the MFMAs below
+        int nb = buf + D;
+        if (nb >= ST) nb -= ST;
+        const int k0_nx = kbeg + 32 * (it + D);
+        const uint32_t soff_nx = it + D < nk ? (uint32_t)(AKM ? (int64_t)k0_nx * p.a_ks * 4 : (int64_t)k0_nx * 4) : 0u;
+        auto piece = [&](int idx) {
+            ps_dma_piece<C>(idx, rsrc_a, rsrc_b, As, Bs, scratch, nb, wave, bvoff, avoff, akl, s0 + it + D, it + D < nk, n0,
+                            np_rows, k0_nx, kend, soff_nx);
+        };
         const int abuf = buf, bbuf = buf;
+        ICK_PSTAMP(tb);
         // B fragments PF blocks ahead of their MFMAs (PF = TN: the whole slice is requested first, so the LDS latency is
         // paid once per slice and the 6 x TM x TN MFMAs then issue back to back; the ds_reads return in order)
         const char* bt = Bs + bbuf * C::B_STAGE;
@@ -305,6 +358,7 @@ __attribute__((amdgpu_waves_per_eu(1, (PsCfg<WM_, WN_, TM_, TN_, AKM_, D_, PF_>:
         }
         // the scheduler must not sink the fragment requests back to their uses (it would, to save registers)
         __builtin_amdgcn_sched_barrier(0);
+        ICK_PSTAMP(tc);
         constexpr int pa[6] = {0, 2, 1, 0, 1, 0}, pb[6] = {2, 0, 1, 1, 0, 0};     // (A plane, B plane), smallest products first
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -314,7 +368,7 @@ __attribute__((amdgpu_waves_per_eu(1, (PsCfg<WM_, WN_, TM_, TN_, AKM_, D_, PF_>:
                     if ((g + 1) * GB + j < TN) read_b((g + 1) * GB + j, bf[(g + 1) & 1][j]);
             }
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
+            for (int q = 0; q < 6; ++q) {
 #pragma unroll
                 for (int j = 0; j < GB; ++j)
 #pragma unroll
@@ -323,12 +377,35 @@ __attribute__((amdgpu_waves_per_eu(1, (PsCfg<WM_, WN_, TM_, TN_, AKM_, D_, PF_>:
                         if (b < TN)
                             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][pa[q]], bf[g & 1][j][pb[q]], acc[a][b], 0, 0, 0);
                     }
+                // one DMA piece of slice it + D per slot; with D = 1 the pieces go out in the first half of the slots (they
+                // must have landed by the end of this iteration), with D >= 2 over all of them
+                constexpr int NS = NG * 6, NP = C::PB_W + C::PA_W;
+                constexpr int SPAN = D >= 2 ? NS : (NS + 1) / 2;
+                constexpr int STRIDE = SPAN / NP > 0 ? SPAN / NP : 1;
+                const int slot = g * 6 + q;
+                if (slot % STRIDE == 0 && slot / STRIDE < NP) piece(slot / STRIDE);
+                if (slot == NS - 1) {            // whatever did not fit the slots
+#pragma unroll
+                    for (int r = (NS - 1) / STRIDE + 1; r < NP; ++r) piece(r);
+                }
+            }
         }
+        ICK_PSTAMP(td);
         // slice it + 1 has landed (in-order completion: only the pieces of the D - 1 younger slices may remain)
         ICK_WAIT_VMCNT(C::IN_FLIGHT);
+        ICK_PSTAMP(te);
         ICK_LDS_BARRIER();
+        ICK_PSTAMP(tf);
+#ifdef ICK_PS_STAMPS
+        ph[0] += tb - ta; ph[1] += tc - tb; ph[2] += td - tc; ph[3] += te - td; ph[4] += tf - te; ph[5] += 1;
+#endif
         if (++buf == ST) buf = 0;
     }
+#ifdef ICK_PS_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == (gridDim.x >> 1) && blockIdx.z == 0) {
+        for (int i = 0; i < 6; ++i) ick_ps_stamps[i] = ph[i];
+    }
+#endif
     ICK_WAIT_VMCNT(0);       // the zero fills of the last iterations write LDS too: none may outlive the workgroup
     gemm_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, fi, fq, zid);
 }
@@ -360,28 +437,22 @@ int launch_ps_tile(const ick_gemm_args& a, bool akm, int np, int64_t bytes, int 
 
 }  // namespace
 
-// Tile shapes of the pre-split kernel (ick_gemm's plan picks one; bm x bn, waves as WM x WN, wave tile TM x TN blocks,
-// D slices in flight):
+// Tile shapes of the pre-split kernel (ick_gemm's plan picks 1 or 2; the others stay selectable with ICK_PS_TILE so that the
+// sweep tables under profiles/r04_*_gemm_ps_* can be reproduced): bm x bn, waves as WM x WN, wave tile TM x TN blocks, D
+// slices in flight, PF = B fragment blocks requested ahead of their MFMAs.
 //   0: 64 x 320   4 x 2 waves of 16 x 160, D 1, 136 KB of LDS
-//   1: 128 x 128  8 x 1 waves of 16 x 128, D 1,  80 KB: two workgroups per CU cover each other's waits
-//   2: 128 x 160  8 x 1 waves of 16 x 160, D 2, 139 KB
+//   1: 128 x 128  8 x 1 waves of 16 x 128, D 1,  80 KB: two workgroups per CU            <- outputs wider than 320 columns, split K
+//   2: 128 x 160  8 x 1 waves of 16 x 160, D 2, 139 KB                                   <- Encoder.conv1 (N = 300, one column pair)
 //   3: 128 x 320  4 x 2 waves of 32 x 160, D 1, 152 KB
-//   4: 128 x 128  8 x 1 waves of 16 x 128, D 2, 120 KB: one workgroup per CU, the LDS-DMA latency (~1.1 us from issue to
-//                 landing, longer than a slice's MFMA phase) hidden by the deeper ring instead
-//   5: 128 x 160  as 2 with D 1, 92 KB: leaves 68 KB of a CU's LDS to a workgroup of the latency-bound chain kernels that
-//                 run beside Encoder.conv1 on the other stream
-//   6, 7: 128 x 96 with D 2 / D 3 (102 / 136 KB) -- a probe of how the slice time depends on the ring depth alone
-//   8: 128 x 128  4 x 2 waves of 32 x 64 (TM 2, TN 4), D 1, 80 KB, two workgroups per CU
-//   9: 128 x 160  4 x 2 waves of 32 x 80 (TM 2, TN 5), D 2, 139 KB
-//      The kernel turned out to be bound by LDS bandwidth (every tile's slice time = its LDS bytes / ~150 KB per us,
-//      profiles/r04_*_gemm_ps_tiles.txt): a wave reads 128 B per row (raw A) + 192 B per column (B planes) of its tile per
-//      slice, so 32-row wave tiles read 1.5 x less than the 16-row ones of shapes 1 and 2 for the same products.
-//  10: 64 x 64    2 x 2 waves of 32 x 32, D 1, 40 KB: four independent workgroups per CU (probe: do more workgroups that
-//                 are not coupled by a barrier overlap their LDS / split phases with each other's MFMAs?)
-//  11: 64 x 128   2 x 2 waves of 32 x 64, D 1, 64 KB: two per CU
-constexpr int kPsTiles = 12;
+//   4: 128 x 128  as 1 with D 2, 120 KB: one workgroup per CU
+//   5: 128 x 128  4 x 2 waves of 32 x 64 (32-row wave tiles read 1.5 x less LDS per product), D 1, two workgroups per CU
+//   6: 128 x 160  4 x 2 waves of 32 x 80, D 2
+// What was measured on them, and on variants that are no longer compiled (ring depth 3, 64 x 64 / 64 x 128 tiles at four
+// workgroups per CU, a ping-pong schedule of two wave groups half a slice apart): DESIGN.md section 3.1c.
+constexpr int kPsTiles = 7;
 void gemm_ps_tile_dims(int tile, int* bm, int* bn, int* wgs_per_cu) {
-    static const int dims[kPsTiles][3] = {{64, 320, 1}, {128, 128, 2}, {128, 160, 1}, {128, 320, 1}, {128, 128, 1}, {128, 160, 1}, {128, 96, 1}, {128, 96, 1}, {128, 128, 2}, {128, 160, 1}, {64, 64, 4}, {64, 128, 2}};
+    static const int dims[kPsTiles][3] = {{64, 320, 1}, {128, 128, 2}, {128, 160, 1}, {128, 320, 1}, {128, 128, 1},
+                                          {128, 128, 2}, {128, 160, 1}};
     *bm = dims[tile][0]; *bn = dims[tile][1]; *wgs_per_cu = dims[tile][2];
 }
 int gemm_ps_tile_count() { return kPsTiles; }
@@ -397,13 +468,8 @@ int launch_gemm_ps(const ick_gemm_args& a, bool akm, int tile, int tiles_m, int 
         case 2: return launch_ps_tile<8, 1, 1, 10, 2, 10>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
         case 3: return launch_ps_tile<4, 2, 2, 10, 1, 3>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
         case 4: return launch_ps_tile<8, 1, 1, 8, 2, 8>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
-        case 5: return launch_ps_tile<8, 1, 1, 10, 1, 10>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
-        case 6: return launch_ps_tile<8, 1, 1, 6, 2, 6>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
-        case 7: return launch_ps_tile<8, 1, 1, 6, 3, 6>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
-        case 8: return launch_ps_tile<4, 2, 2, 4, 1, 2>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
-        case 9: return launch_ps_tile<4, 2, 2, 5, 2, 5>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
-        case 10: return launch_ps_tile<2, 2, 2, 2, 1, 2>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
-        case 11: return launch_ps_tile<2, 2, 2, 4, 1, 2>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
+        case 5: return launch_ps_tile<4, 2, 2, 4, 1, 2>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
+        case 6: return launch_ps_tile<4, 2, 2, 5, 2, 5>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
     }
     return ICK_EINVAL;
 }

@@ -85,7 +85,7 @@ if __name__ == "__main__":
     for name in SHAPES:
         if not name.startswith(want):
             continue
-        for tile in (os.environ.get("TILES", "off,,0,1,2,3,4").split(",")):
+        for tile in (os.environ.get("TILES", "off,,0,1,2,3,4,5,6").split(",")):
             for nt in (("", "0", "1") if os.environ.get("SWEEP_NT") else ("",)):
                 if tile == "" and nt != "":
                     continue
