@@ -34,7 +34,7 @@
 // Diagnostic build (-DICK_PS_STAMPS, tools/debug/gemm_ps_stamps.py): wave 0 of one workgroup in the middle of the grid sums
 // the shader-clock ticks it spends in each phase of a slice.  Compiled out of the product library.
 #ifdef ICK_PS_STAMPS
-__device__ unsigned long long ick_ps_stamps[8];
+__device__ unsigned long long ick_ps_stamps[10];
 #define ICK_PSTAMP(var)                                   \
     do {                                                  \
         __builtin_amdgcn_sched_barrier(0);                \
@@ -204,12 +204,17 @@ __device__ __forceinline__ void ps_dma_piece(int idx, const __amdgpu_buffer_rsrc
 // (8 waves on 4 SIMDs: 256 VGPRs each, enough to hold a whole slice's B fragments), 4 for the two-workgroup tile
 template <int WM_, int WN_, int TM_, int TN_, bool AKM_, int D_, int PF_>
 __global__ __launch_bounds__(WM_ * WN_ * 64)
-__attribute__((amdgpu_waves_per_eu(1, (PsCfg<WM_, WN_, TM_, TN_, AKM_, D_, PF_>::LDS > 80 * 1024 ? 2 : 4)))) void gemm_ps_kernel(ick_gemm_args p, int np_rows, int64_t bps_bytes, int tiles_m,
+__attribute__((amdgpu_waves_per_eu(1, (PsCfg<WM_, WN_, TM_, TN_, AKM_, D_, PF_>::LDS > 80 * 1024 || WM_ * WN_ <= 4 ? 2 : 4)))) void gemm_ps_kernel(ick_gemm_args p, int np_rows, int64_t bps_bytes, int tiles_m,
                                                                  int tiles_n, int kchunk, int a_nt) {
     using C = PsCfg<WM_, WN_, TM_, TN_, AKM_, D_, PF_>;
     constexpr int BM = C::BM, BN = C::BN, TM = C::TM, TN = C::TN, NW = C::NW, D = C::D, ST = C::ST;
     constexpr bool AKM = C::AKM;
     extern __shared__ __attribute__((aligned(1024))) char smem_ps[];
+#ifdef ICK_PS_STAMPS
+    unsigned long long t_start = 0, t_loop = 0, t_end = 0;
+    ICK_PSTAMP(t_start);
+    const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();      // 100 MHz: the shader clock this workgroup saw
+#endif
     char* const As = smem_ps;
     char* const Bs = smem_ps + ST * C::A_STAGE;
     char* const scratch = Bs + ST * C::B_STAGE;
@@ -295,6 +300,7 @@ __attribute__((amdgpu_waves_per_eu(1, (PsCfg<WM_, WN_, TM_, TN_, AKM_, D_, PF_>:
 
 #ifdef ICK_PS_STAMPS
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, ta = 0, tb = 0, tc = 0, td = 0, te = 0, tf = 0;
+    ICK_PSTAMP(t_loop);
 #endif
     int buf = 0;                             // ring buffer holding slice `it`
     for (int it = 0; it < nk; ++it) {
@@ -402,12 +408,22 @@ __attribute__((amdgpu_waves_per_eu(1, (PsCfg<WM_, WN_, TM_, TN_, AKM_, D_, PF_>:
         if (++buf == ST) buf = 0;
     }
 #ifdef ICK_PS_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x == (gridDim.x >> 1) && blockIdx.z == 0) {
-        for (int i = 0; i < 6; ++i) ick_ps_stamps[i] = ph[i];
-    }
+    ICK_PSTAMP(t_end);
+    const unsigned long long t_loop_end = t_end;
 #endif
     ICK_WAIT_VMCNT(0);       // the zero fills of the last iterations write LDS too: none may outlive the workgroup
     gemm_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, fi, fq, zid);
+#ifdef ICK_PS_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores of the epilogue have been acknowledged
+    ICK_PSTAMP(t_end);
+    if (threadIdx.x == 0 && blockIdx.x == (gridDim.x >> 1) && blockIdx.z == 0) {
+        for (int i = 0; i < 6; ++i) ick_ps_stamps[i] = ph[i];
+        ick_ps_stamps[6] = t_loop - t_start;          // set-up + first slices requested and landed
+        ick_ps_stamps[7] = t_end - t_loop_end;        // epilogue incl. its stores
+        ick_ps_stamps[8] = t_end - t_start;
+        ick_ps_stamps[9] = __builtin_amdgcn_s_memrealtime() - rt_start;
+    }
+#endif
 }
 
 
@@ -449,10 +465,15 @@ int launch_ps_tile(const ick_gemm_args& a, bool akm, int np, int64_t bytes, int 
 //   6: 128 x 160  4 x 2 waves of 32 x 80, D 2
 // What was measured on them, and on variants that are no longer compiled (ring depth 3, 64 x 64 / 64 x 128 tiles at four
 // workgroups per CU, a ping-pong schedule of two wave groups half a slice apart): DESIGN.md section 3.1c.
-constexpr int kPsTiles = 7;
+//   7: 128 x 128  FOUR waves (4 x 1) of 32 x 128, D 1, 80 KB: two workgroups per CU, one wave of each per SIMD -- the two
+//                 workgroups are not coupled by a barrier, so one's fragment phase can run under the other's MFMAs
+//   8: 64 x 160   four waves (2 x 2) of 32 x 80, D 1, 76 KB: two per CU
+//   9: 128 x 80   8 x 1 waves of 16 x 80, D 1, 62 KB: two workgroups per CU (Encoder.conv1 as 98 x 4 tiles: the two
+//                 workgroups of a CU are not barrier-coupled, so their fragment and MFMA phases overlap)
+constexpr int kPsTiles = 10;
 void gemm_ps_tile_dims(int tile, int* bm, int* bn, int* wgs_per_cu) {
     static const int dims[kPsTiles][3] = {{64, 320, 1}, {128, 128, 2}, {128, 160, 1}, {128, 320, 1}, {128, 128, 1},
-                                          {128, 128, 2}, {128, 160, 1}};
+                                          {128, 128, 2}, {128, 160, 1}, {128, 128, 2}, {64, 160, 2}, {128, 80, 2}};
     *bm = dims[tile][0]; *bn = dims[tile][1]; *wgs_per_cu = dims[tile][2];
 }
 int gemm_ps_tile_count() { return kPsTiles; }
@@ -470,6 +491,9 @@ int launch_gemm_ps(const ick_gemm_args& a, bool akm, int tile, int tiles_m, int 
         case 4: return launch_ps_tile<8, 1, 1, 8, 2, 8>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
         case 5: return launch_ps_tile<4, 2, 2, 4, 1, 2>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
         case 6: return launch_ps_tile<4, 2, 2, 5, 2, 5>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
+        case 7: return launch_ps_tile<4, 1, 2, 8, 1, 2>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
+        case 8: return launch_ps_tile<2, 2, 2, 5, 1, 5>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
+        case 9: return launch_ps_tile<8, 1, 1, 5, 1, 2>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
     }
     return ICK_EINVAL;
 }

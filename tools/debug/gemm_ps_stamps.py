@@ -37,19 +37,21 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     torch.cuda.synchronize()
     info = L.GemmPlanInfo()
     L.check(L.load().ick_gemm_plan(ops.gemm_args(A, W, out, M, N, K, *aargs, K, 1, N, b_ps=ps, **akw), info), "plan")
-    buf = (ctypes.c_ulonglong * 8)()
+    buf = (ctypes.c_ulonglong * 10)()
     assert ctypes.CDLL(dbg).ick_debug_read_ps_stamps(buf) == 0
     n = max(1, buf[5])
     names = ["DMA issue", "B requests + A read + split", "MFMA issue", "wait next slice's DMA", "barrier"]
     tot = sum(buf[i] for i in range(5)) / n
     print("%-10s tile %3dx%-3d: %5.0f ticks per slice = " % (name, info.tile_m, info.tile_n, tot) +
-          " | ".join("%s %4.0f" % (nm, buf[i] / n) for i, nm in enumerate(names)), flush=True)
+          " | ".join("%s %4.0f" % (nm, buf[i] / n) for i, nm in enumerate(names)) +
+          "  ||  per tile: prologue %d, %d slices = %d, epilogue %d ticks; in-kernel clock %.2f GHz (%d ticks in %.2f us)"
+          % (buf[6], n, tot * n, buf[7], buf[8] / max(1, buf[9]) * 0.1, buf[8], buf[9] / 100.0), flush=True)
     sys.exit(0)
 
 import ick_amd.build as b  # noqa: E402
 dbg = os.path.join(ROOT, "gpurun_out", "libick_amd_psstamps.so")
 os.makedirs(os.path.dirname(dbg), exist_ok=True)
-subprocess.check_call([b.HIPCC] + b.FLAGS + ["-DICK_PS_STAMPS", "-shared", "-o", dbg] + b.sources())
+subprocess.check_call([b.HIPCC] + b.FLAGS + ["-DICK_PS_STAMPS", "-w", "-shared", "-o", dbg] + b.sources())
 shape = sys.argv[2] if len(sys.argv) > 2 and sys.argv[1] == "--shape" else (sys.argv[1] if len(sys.argv) > 1 else "conv1")
 tiles = sys.argv[2:] if len(sys.argv) > 2 else ["2", "0", "6"]
 for t in tiles:
