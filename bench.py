@@ -209,6 +209,8 @@ class Workload:
             from ick_amd.training import TrainStep
             # encoder=: the step takes the feature map itself; Encoder.conv1 runs inside the captured step and writes
             # the image rows straight into the decoder's memory buffer.  All-reduces its bucket when world > 1.
+            if use_graph:
+                os.environ.setdefault("ICK_ALLREDUCE_PROBE", "1")     # several ranks: time one all-reduce of the bucket
             ts = TrainStep(dec, lr=4e-4, grad_clip=5.0, seed=self.rank, use_graph=use_graph, encoder=enc)
             if use_graph:
                 self.train_step = ts
@@ -412,6 +414,10 @@ def main():
                                          2: "split: 6 bf16 MFMA partial products of the exact 3-way bf16 split, fp32 "
                                             "accumulate (all large tiles)"}[_gemm_mode()],
                        "collective_backend": backend if args.mode == "train" else "none",
+                       # several ranks: milliseconds one all-reduce of the flat gradient bucket took at construction (median
+                       # of 3, max over ranks) and whether the step overlaps half of it with the backward pass
+                       "allreduce_probe_ms": getattr(wl.train_step, "allreduce_probe_ms", None),
+                       "split_allreduce": bool(getattr(wl.train_step, "split", False)),
                        "parallelism": ("dp%d (one flat-bucket all-reduce per step)" if args.mode == "train"
                                        else "dp%d (independent shards)") % world},
         }

@@ -423,6 +423,7 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     assert d["config"]["graph"] is True and d["repeats"] >= 1 and d["steps"] == 3 and "modes" not in d
     assert "pass_frac" not in d["roofline"] and d["roofline"]["pass_frac_executed"] > 0
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
+    assert d["config"]["allreduce_probe_ms"] > 0 and d["config"]["split_allreduce"] is False
 
 
 def test_train_step_from_features_and_in_place_input_buffers():
