@@ -14,6 +14,7 @@ import os
 import time
 from dataclasses import dataclass
 
+import numpy as np
 import torch
 from torch import nn
 from torch.nn.utils.rnn import pack_padded_sequence
@@ -79,13 +80,38 @@ class ThreadedBatches:
     def __init__(self, dataset, batch_sampler, threads, depth=None):
         self.dataset, self.batch_sampler, self.threads = dataset, batch_sampler, threads
         self.depth = depth or threads + 1
+        # Pinned feature blocks, recycled: a batch's 26-51 MB are copied ONCE, out of the memory map straight into pinned
+        # memory (round 3 copied them into a fresh numpy block and then again into a freshly allocated pinned tensor).  A
+        # block is free again when the host-to-device copy that read it is done (RELEASE: event per block, set by the
+        # Prefetcher); the ring is deep enough that this wait never triggers in steady state.
+        self.ring, self.ring_at = [], 0
+        self.ring_size = self.depth + 4
 
     def __len__(self):
         return len(self.batch_sampler)
 
-    def _fetch(self, idx):
-        batch = self.dataset.fetch_batch(idx)
-        return tuple(t.pin_memory() for t in batch)
+    def _block(self, n):
+        spec = getattr(self.dataset, "batch_block_spec", lambda n_: None)(n)
+        if spec is None or not torch.cuda.is_available():
+            return None
+        shape, dt = spec
+        tdt = torch.float16 if dt == np.float16 else torch.float32
+        if len(self.ring) < self.ring_size:
+            blk = torch.empty(shape, dtype=tdt).pin_memory()
+            self.ring.append(blk)
+            return blk
+        blk = self.ring[self.ring_at % self.ring_size]
+        self.ring_at += 1
+        if tuple(blk.shape) != tuple(shape):          # the epoch's last, smaller batch: a block of its own
+            return None
+        ev = RELEASE.pop(blk.data_ptr(), None)
+        if ev is not None:
+            ev.synchronize()
+        return blk
+
+    def _fetch(self, idx, blk):
+        batch = self.dataset.fetch_batch(idx, img_out=blk) if blk is not None else self.dataset.fetch_batch(idx)
+        return tuple(t if t.is_pinned() else t.pin_memory() for t in batch)
 
     def __iter__(self):
         from collections import deque
@@ -95,7 +121,8 @@ class ThreadedBatches:
             pending = deque()
             it = iter(self.batch_sampler)
             for idx in it:
-                pending.append(pool.submit(self._fetch, list(idx)))
+                idx = list(idx)
+                pending.append(pool.submit(self._fetch, idx, self._block(len(idx))))
                 if len(pending) >= self.depth:
                     yield pending.popleft().result()
             while pending:
@@ -104,6 +131,7 @@ class ThreadedBatches:
             pool.shutdown(wait=False, cancel_futures=True)
 
 
+RELEASE = {}   # data_ptr of a pinned feature block -> event after which the loader may overwrite it (ThreadedBatches)
 STATS = {}     # "last_epoch_steps_per_s": optimizer steps per second of the last pipelined training epoch (tools/train_rate.py)
 
 
@@ -144,6 +172,8 @@ class Prefetcher:
             facts = batch[6].to(self.device, non_blocking=True) if self.has_facts else None
             ev = torch.cuda.Event()
             ev.record(self.stream)
+        if batch[0].is_pinned():
+            RELEASE[batch[0].data_ptr()] = ev          # the loader's ring may reuse this block once the copy has run
         self.next = ((imgs, caps, caplens, capmasks, ent, facts), n_tok, ev, batch)   # batch: keeps the pinned source alive
 
     def __iter__(self):

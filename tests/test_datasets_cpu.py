@@ -32,7 +32,7 @@ def test_batched_fetch_equals_per_sample_collate(tmp_path, variant, keep_half):
     # threads of this process hand the same batches out, pinned when a GPU is there, in sampler order
     from ick_amd.train import ThreadedBatches
     tb = ThreadedBatches(ds, bs, threads=3)
-    tb._fetch = lambda idx: ds.fetch_batch(idx)          # no pinning on a CPU-only box
+    tb._fetch = lambda idx, blk=None: ds.fetch_batch(idx)          # no pinning on a CPU-only box
     got = list(tb)
     assert len(got) == len(tb) == 3
     for a, b in zip(got, loader):
