@@ -111,6 +111,10 @@ class ThreadedBatches:
 
     def _fetch(self, idx, blk):
         batch = self.dataset.fetch_batch(idx, img_out=blk) if blk is not None else self.dataset.fetch_batch(idx)
+        # the feature block is the ring's pinned memory; the small fields (a few KB each) travel pageable: pinning them
+        # would be a page-locking allocation per tensor and batch
+        if blk is not None:
+            return batch
         return tuple(t if t.is_pinned() else t.pin_memory() for t in batch)
 
     def __iter__(self):
