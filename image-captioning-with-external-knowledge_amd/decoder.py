@@ -113,6 +113,17 @@ class CaptionEmbedder(nn.Module):
         self.vocab_size = vocab_size
 
 
+# Device-side caches a module keeps in its __dict__ (captured graphs, packed / pre-split weight copies, pinned staging):
+# never part of a pickle (checkpoints pickle whole modules, geo-aware/utils.py:32-46) or of a deep copy -- they are rebuilt
+# on first use.
+_CACHE_KEYS = ("_graphs", "_kv_pack", "_pred_wt_cache", "_len_pin", "_idx_pin", "_plist", "_pin_ev", "_dec_pack",
+               "_chain_cache", "_chain_cache_bwd", "_chain_ok", "_chain_bwd_ok", "_ps_cache")
+
+
+def _state_without_caches(module):
+    return {k: v for k, v in module.__dict__.items() if k not in _CACHE_KEYS}
+
+
 class _Conv1Fn(torch.autograd.Function):
     """Encoder.conv1 (1x1 convolution = GEMM over the NCHW map) with its backward on the same HIP GEMM:
     dW = dY^T . X, db = column sums of dY (riding on that GEMM), dX = dY . W (only when the trunk is being
@@ -216,6 +227,9 @@ class Encoder(nn.Module):
                      a_grp=P, a_gs=Cc * P, b_ps=self.conv1_presplit())
         return out.permute(0, 2, 1)
 
+    def __getstate__(self):
+        return _state_without_caches(self)
+
     def conv1_presplit(self):
         """The pre-split copy of conv1's (emb_dim, encoder_dim) weight for ick_gemm's b_ps (refreshed in place when the
         weight changes; None in the exact-fp32 product mode)."""
@@ -315,6 +329,9 @@ class DecoderTransformer(nn.Module):
 
     def _wants_grad(self):
         return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+    def __getstate__(self):
+        return _state_without_caches(self)
 
     def invalidate_caches(self):
         """Call after parameters were modified outside torch's version tracking (the fused Adam kernel

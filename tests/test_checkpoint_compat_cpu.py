@@ -116,3 +116,29 @@ def test_row_chain_weight_items_cover_every_launch():
         first = lambda k: k[0] != "d" or (k[1] == 0 and k[2] in ("so", "cq"))
         assert {k for k in items if first(k)} | {k for k in items if not first(k)} == set(items)
         assert all(k[0] in ("e", "f") or k[1] == 0 for k in items if first(k))
+
+
+def test_device_caches_never_reach_a_pickle_or_a_deep_copy():
+    """Captured graphs, packed and pre-split weight copies live in the modules' __dict__; whole-object checkpoints
+    (geo-aware/utils.py:32-46) and deep copies must not carry them, and the live module must keep them (captured graphs
+    read those buffers by address)."""
+    import copy
+    import io
+    import ick_amd
+    import ick_amd.synth as synth
+    m = ick_amd.load_models("knowledge")
+    dec = m.DecoderTransformer(synth.make_word_map(60), 300, 512, 512, 10, 3)
+    enc = m.Encoder(emb_dim=300)
+    for mod in (dec, enc):
+        mod.__dict__["_ps_cache"] = {"w": [("key",), torch.zeros(8, dtype=torch.uint8)]}
+        mod.__dict__["_graphs"] = {"shape": object()}
+    buf = io.BytesIO()
+    torch.save({"decoder": dec, "encoder": enc}, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    for live, loaded in ((dec, back["decoder"]), (enc, back["encoder"])):
+        assert "_ps_cache" in live.__dict__ and "_graphs" in live.__dict__
+        assert "_ps_cache" not in loaded.__dict__ and "_graphs" not in loaded.__dict__
+        assert list(live.state_dict()) == list(loaded.state_dict())
+        assert all(torch.equal(a, b) for a, b in zip(live.state_dict().values(), loaded.state_dict().values()))
+    assert "_ps_cache" not in copy.deepcopy(dec).__dict__
