@@ -723,7 +723,9 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
         // kernel's one-workgroup-per-CU tile (Encoder.conv1 at batch 32 -- 98 workgroups -- took as long as at batch 64);
         // below that the stager-split kernel's 128 x 64 tiles (five per row panel) are the better fit
         const bool narrow_underfilled = a.N <= 320 && split_req == 1 && ceil_div(a.M, 128) * ceil_div(a.N, 160) < 180;
-        if (ps_on && flop >= 1.0e9 && a.M >= 256 && a.N >= 128 && (!narrow_underfilled || ps_tile_env >= 0)) {
+        // the pre-split copy is addressed through one buffer descriptor: it must stay below 2 GiB
+        const bool ps_fits = (int64_t)ceil_div(a.K, 32) * 3 * ceil_div(a.N, 64) * 64 * 64 < ((int64_t)1 << 31);
+        if (ps_on && ps_fits && flop >= 1.0e9 && a.M >= 256 && a.N >= 128 && (!narrow_underfilled || ps_tile_env >= 0)) {
             // Tile choice, measured (tools/gemm_ps_bench.py, profiles/r04_e_gemm_ps_tiles.txt: every tile x every shape):
             // 128 x 128 with two workgroups per CU wins wherever the output is wider than 320 columns (cross K/V 100 us
             // against 129-143 on the other tiles, vocabulary 65 against 80-88); outputs at most 320 wide (Encoder.conv1,
