@@ -17,16 +17,21 @@ def main(d, steps, out):
     f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
     agg = collections.OrderedDict()
     other = 0.0
+    once = collections.Counter()                     # kernels the step launches exactly once: their count IS the step count
     for r in csv.DictReader(open(f)):
         key = classify(r["Kernel_Name"], r.get("Grid_Size_X") or r.get("Grid_Size"))
         us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        if key in ("adam", "vocab_ps"):
+            once[key] += 1
         if key is None:
             other += us
             continue
         a = agg.setdefault(CLASSES[key], [0, 0.0])
         a[0] += 1
         a[1] += us
-    table = {"_source": "rocprofv3 --kernel-trace of the captured step (%s, %d steps incl. warm-up): kernel durations while "
+    # the trace also holds the eager pass the graph is captured after: divide by the passes actually traced
+    steps = once.get("adam") or once.get("vocab_ps") or steps
+    table = {"_source": "rocprofv3 --kernel-trace of the captured step (%s, %d passes traced incl. warm-up): kernel durations while "
                         "the step's two streams run beside each other; tools/in_step_table.py" % (os.path.basename(d.rstrip("/")), steps),
              "_unclassified_us_per_step": other / steps}
     for k, (n, us) in agg.items():

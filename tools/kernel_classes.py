@@ -54,9 +54,9 @@ def classify(name, grid_x=None):
         return "decode"
     t = _targs(name, "gemm_ps_kernel")
     if t:
-        if t[4] == "true":
-            return "conv1_ps"
         g = int(grid_x) if grid_x else 0
+        if t[4] == "true":                        # A k-major: conv1 (196 tiles of 512 threads) or a split-K weight gradient
+            return "conv1_ps" if g == 100352 else "wgrad"
         return {752640: "kv_ps", 404480: "vocab_ps"}.get(g)
     t = _targs(name, "gemm_kernel")
     if t:

@@ -47,6 +47,8 @@ def main(out, dirs):
             per = (r + w) / n
             if key == "decode":
                 per *= 11            # launches of one token step (3 x (self, cross, ffn) + head + vocabulary)
+            if CLASSES[key] in table:          # a later mode (greedy's prefill) does not overwrite the train step's classes
+                continue
             table[CLASSES[key]] = per
             print("%-100s launches %5d  %9.2f MB per %s" % (CLASSES[key][:100], n, per / 1e6, "token" if key == "decode" else "launch"))
     json.dump(table, open(out, "w"), indent=0)
