@@ -430,6 +430,8 @@ def main():
             # HBM bytes per launch from the PMC counters (valid for the workload they were collected on: cfg2 / cfg5)
             if r["name"] in traffic and cfgname in ("cfg2", "cfg5") and args.mode != "beam":
                 r["traffic"] = traffic[r["name"]]
+                # the decode step's bytes are per token (all of its launches), every other class's per launch
+                r["traffic_per"] = "token" if r["name"].startswith("fused decode step") else "launch"
         in_step = {}
         if cfgname == "cfg2" and _gemm_mode() == 1 and os.path.exists(IN_STEP_TABLE.get(args.mode, "")):
             in_step = json.load(open(IN_STEP_TABLE[args.mode]))
@@ -447,7 +449,7 @@ def main():
                     "unit": dom.get("unit"), "frac": dom.get("frac"), "kernel": dom["name"],
                     "kernel_avg_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
                     "share_of_kernel_time": dom["us_per_step"] / max(1e-9, sum(r["us_per_step"] for r in by_kernel)),
-                    "traffic": dom.get("traffic"),
+                    "traffic": dom.get("traffic"), "traffic_per": dom.get("traffic_per"),
                     # frac: the class timed alone (eager, one stream); frac_in_step: inside the captured step, beside the
                     # other stream's kernels (profiles/r04_in_step_*.json, rocprofv3 of this command)
                     "frac_in_step": dom.get("frac_in_step"), "in_step_source": in_step.get("_source"),
@@ -523,7 +525,7 @@ def main():
                                             "frac_in_step": rf.get("frac_in_step"),
                                             # PMC bytes per launch (decode step: per token); null where no counter run
                                             # of that workload is committed (profiles/r04_traffic.json)
-                                            "traffic": rf.get("traffic")}
+                                            "traffic": rf.get("traffic"), "traffic_per": rf.get("traffic_per")}
             modes[name] = entry
         out["modes"] = modes
 

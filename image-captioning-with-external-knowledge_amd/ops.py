@@ -887,22 +887,35 @@ SIDE = None   # set by training.TrainStep / backward_from_tape for the duration 
 
 
 def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False, group_now=False, gate=None,
-               gate_scale=1.0, wt_ps=None):
+               gate_scale=1.0, wt_ps=None, xt_ps=None):
     """Backward of y = x @ w.T + b for row-major 2-D views dy (M,N), x (M,K), w (N,K):
     dw += dy.T @ x (split-K over M, float atomics), db += colsum(dy), dx = dy @ w.
     With a SideStream installed the two parameter gradients run beside the data gradient.
-    wt_ps: the pre-split copy of w.t() (presplit_weights) -- the data gradient's B operand."""
+    wt_ps: the pre-split copy of w.t() (presplit_weights) -- the data gradient's B operand.
+    xt_ps: the pre-split copy of x.t() -- the weight gradient's B operand: dw then runs on csrc/gemm_ps.hip's kernel (the
+    vocabulary: 10 000 x 300 outputs over 1 280 rows) and db becomes a column-sum problem of the same group."""
     M, N = dy.shape
     K = x.shape[1]
 
     # dw += dy.T @ x with db += colsum(dy) riding on the first tile column of the same kernel
     wg = None
-    if dw is not None:
+    extra = []
+    if dw is not None and xt_ps is not None and gemm_split_mode() >= 1 and not is_deterministic():
+        # 128 x 128 tiles, two workgroups per CU: K slices so that the ~512 slots of the chip are taken once
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        split = max(1, min(8, 480 // tiles, M // 512))
+        wg = gemm_args(dy, x, dw, N, K, M, 1, dy.stride(0), 1, x.stride(0), dw.stride(0), atomic=True,
+                       split_k=int(os.environ.get("ICK_VOCAB_WGRAD_SPLIT", split)), b_ps=xt_ps)
+        if db is not None:
+            extra.append(colsum_problem(dy, db, split_k=max(1, min(16, M // 256))))
+    elif dw is not None:
         wg = gemm_args(dy, x, dw, N, K, M, 1, dy.stride(0), 1, x.stride(0), dw.stride(0), atomic=True,
                        split_k=wgrad_split(M, N, K, grouped=SIDE is not None), colsum_a=db)
 
     def param_grads():
-        if wg is not None:
+        if wg is not None and extra:
+            gemm_grouped([wg] + extra)
+        elif wg is not None:
             _log_plan(wg)
             L.check(L.load().ick_gemm(C.byref(wg), _stream()), "ick_gemm(wgrad)")
         elif db is not None:
@@ -915,7 +928,9 @@ def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False, gro
     overlap = SIDE is not None and (dw is not None or db is not None)
     if overlap:
         if wg is not None:
-            SIDE.add_problem(wg, dy, x)
+            SIDE.add_problem(wg, dy, x, xt_ps)
+            for e in extra:
+                SIDE.add_problem(e, dy)
             if group_now:      # a large problem of its own (the vocabulary): runs beside its data gradient
                 SIDE.flush_group()
         else:

@@ -90,6 +90,14 @@ def classify(name, args):
         kv = 4.0 * c.R * c.layers * 2 * c.H * c.S * 32
         w = 4.0 * (c.layers * (4 * c.d * c.d + 2 * c.d * c.d + 2 * c.d * c.FF) + c.V * c.d)
         return "fused decode step (3 kernels / layer + head + vocabulary)", kv + w, "byte"
+    if name == "ick_decode_layers_part":
+        # the same step in two launches (selection of the previous token + layer 0's self-attention block | the rest):
+        # one class, the step's algorithmic bytes shared out by what each part streams
+        c = _struct(args[0])
+        kv = 4.0 * c.R * c.layers * 2 * c.H * c.S * 32
+        w = 4.0 * (c.layers * (4 * c.d * c.d + 2 * c.d * c.d + 2 * c.d * c.FF) + c.V * c.d)
+        first = 4.0 * 4 * c.d * c.d
+        return ("fused decode step (3 kernels / layer + head + vocabulary)", first if args[2] == 1 else kv + w - first, "byte")
     if name == "ick_decode_select_greedy":
         return "greedy selection + next-token embedding", None, None
     return name[4:].replace("_", " "), None, None

@@ -16,6 +16,7 @@ Dropout: the reference constructs the decoder with dropout 0.5/0.5/0.1; the mask
 counter-based generator (see ick_dropout) and cannot be bit-identical to torch's CPU stream, so
 parity of the training math is pinned with dropout disabled (p = 0 / eval-mode fixtures).
 """
+import functools
 import math
 import os
 
@@ -419,7 +420,7 @@ def _g(grads, param):
 
 
 def _lin_bwd(grads, dy2, x2, lin_w, lin_b, w_rows=None, need_dx=True, dx=None, acc=False, group_now=False,
-             gate=None, gate_scale=1.0, wt_ps=None):
+             gate=None, gate_scale=1.0, wt_ps=None, xt_ps=None):
     """Backward of a Linear whose weight is `lin_w` (optionally the row slice w_rows of it)."""
     gw, gb = _g(grads, lin_w), _g(grads, lin_b)
     w = _p(lin_w)
@@ -428,7 +429,7 @@ def _lin_bwd(grads, dy2, x2, lin_w, lin_b, w_rows=None, need_dx=True, dx=None, a
         gw = gw[w_rows] if gw is not None else None
         gb = gb[w_rows] if gb is not None else None
     return ops.linear_bwd(dy2, x2, w, gw, gb, need_dx=need_dx, dx=dx, accumulate_dx=acc, group_now=group_now,
-                          gate=gate, gate_scale=gate_scale, wt_ps=wt_ps)
+                          gate=gate, gate_scale=gate_scale, wt_ps=wt_ps, xt_ps=xt_ps)
 
 
 def _prezeroed(dec, captions, entities, facts):
@@ -533,7 +534,8 @@ def _context_encoder_bwd(dec, stack, tapes, dx, grads, pkb=None, tag="e", g_firs
     return dx
 
 
-def _decoder_layer_bwd_chain(dec, li, layer, t, state, dkv_rows, kv, S, grads, pkb, mem2=None, mem_t_ps=None):
+def _decoder_layer_bwd_chain(dec, li, layer, t, state, dkv_rows, kv, S, grads, pkb, mem2=None, mem_t_ps=None,
+                             on_done=None):
     """Backward of decoder layer li as two ops.rowchain_bwd launches around the cross-attention backward + the
     self-attention backward.  state = (dz, g0, w0p): the residual-path gradient of this layer's output, and -- from the
     layer above -- the in_proj gradient whose data gradient rides on this layer's first launch.  Returns the state
@@ -601,6 +603,10 @@ def _decoder_layer_bwd_chain(dec, li, layer, t, state, dkv_rows, kv, S, grads, p
                        layer.self_attn.in_proj_bias, dx=dz_b, acc=True).view(B, T, d)
         out = (dx0, None, None)
     if ops.SIDE is not None:
+        if on_done is not None:
+            # behind this layer's last group, in the same side-stream launch: every gradient of the layer is complete
+            # there and nothing of this pass reads the layer's parameters any more (the chains read packed copies)
+            ops.SIDE.submit_with_group(on_done)
         ops.SIDE.flush_group()          # this layer's weight gradients: one grouped launch
     return out
 
@@ -693,14 +699,36 @@ def _memory_t_presplit(m, B, S, d):
     return buf
 
 
-def backward_from_tape(dec, tape, dscores, grads, overlap=True, want_image_grad=False):
+def _rows_t_presplit(x2):
+    """Pre-split copy of x2^T (x2: (rows, d) activations): the B operand of a weight gradient dW = dy^T @ x2 on
+    csrc/gemm_ps.hip's kernel -- the vocabulary's (10 000 x 300 outputs over the 1 280 caption rows), made on the side
+    stream in front of that gradient; None in the exact / deterministic modes and for few rows."""
+    rows, d = x2.shape
+    if ops.gemm_split_mode() < 1 or ops.is_deterministic() or os.environ.get("ICK_NO_VOCAB_WGRAD_PS") or rows < 1024:
+        return None
+    buf = ops.presplit_buffer(d, rows, x2.device)
+
+    def make():
+        ops.presplit_weights([(x2.t(), buf)])
+
+    if ops.SIDE is not None:
+        ops.SIDE.submit(make, x2, buf)
+    else:
+        make()
+    return buf
+
+
+def backward_from_tape(dec, tape, dscores, grads, overlap=True, want_image_grad=False, early_update=None):
     """Accumulate parameter gradients of `dec` into `grads` (dict id(param) -> zero-initialised
     tensor shaped like the parameter; frozen parameters are simply absent).  With `overlap` the weight /
     bias gradients of the Linear layers run on a second HIP stream beside the data-gradient chain.
     want_image_grad: also return the gradient of the (length-sorted) image memory rows (B, P, d) -- what
     fine_tune_encoder=True back-propagates into Encoder.conv1; the default step skips that 13.5 GFLOP GEMM because
-    the reference never uses the result (geo-aware/train.py:93-100,283-284)."""
-    bp = BackwardPass(dec, tape, dscores, grads, overlap, want_image_grad)
+    the reference never uses the result (geo-aware/train.py:93-100,283-284).
+    early_update: {"head": fn, "layer": fn(li)} -- called (with overlap only) on the SIDE stream once every gradient of
+    fc_vocab / of decoder layer li is complete and nothing of this pass reads those parameters any more: TrainStep's
+    optimizer update of that part of the bucket then fills the side stream's idle gaps instead of the step's tail."""
+    bp = BackwardPass(dec, tape, dscores, grads, overlap, want_image_grad, early_update=early_update)
     bp.early(join=False)     # one pass: the side stream is only joined at the very end
     bp.late()
     return tape.misc.get("d_img")
@@ -728,12 +756,12 @@ class BackwardPass:
     early() = score head + decoder stack, with the side stream joined at its end; late() = context encoders and
     embeddings.  The two phases may be captured into two hipGraphs."""
 
-    def __init__(self, dec, tape, dscores, grads, overlap=True, want_image_grad=False):
+    def __init__(self, dec, tape, dscores, grads, overlap=True, want_image_grad=False, early_update=None):
         # ICK_BWD_SIDE_PRIO (experiment): priority of the stream that carries the bulk weight-gradient GEMMs beside the
         # latency-bound data-gradient chain (torch: larger number = lower priority)
         self.side_prio = int(os.environ.get("ICK_BWD_SIDE_PRIO", "0"))
         self.side = ops.SideStream(priority=self.side_prio) if overlap else None
-        self.gen = _backward_phases(dec, tape, dscores, grads, want_image_grad)
+        self.gen = _backward_phases(dec, tape, dscores, grads, want_image_grad, early_update if overlap else None)
 
     def _run(self, join):
         ops.SIDE = self.side
@@ -757,7 +785,7 @@ class BackwardPass:
         self._run(True)
 
 
-def _backward_phases(dec, tape, dscores, grads, want_image_grad=False):
+def _backward_phases(dec, tape, dscores, grads, want_image_grad=False, early_update=None):
     m = tape.misc
     d, V, H = dec.emb_dim, dec.vocab_size, dec.num_heads
     h, ee, fe = m["h"], m["ee"], m["fe"]
@@ -785,13 +813,18 @@ def _backward_phases(dec, tape, dscores, grads, want_image_grad=False):
     hv = m["hv"] if dec.has_facts else h
     # the vocabulary weight gradient is a large problem of its own: it starts beside its data gradient
     dhv0 = pre.get("dhv")
+    hv_t_ps = _rows_t_presplit(hv.view(M, d)) if _g(grads, dec.fc_vocab.weight) is not None else None
     if dhv0 is not None and dhv0.shape == (M, d) and not ops.is_deterministic():
         # split-K partial sums add into the buffer the forward pass's side stream zeroed
         dhv = _lin_bwd(grads, dsc2[:, :V], hv.view(M, d), dec.fc_vocab.weight, dec.fc_vocab.bias, dx=dhv0, acc=True,
-                       group_now=True, wt_ps=m.get("vocab_t_ps")).view(B, L, d)
+                       group_now=True, wt_ps=m.get("vocab_t_ps"), xt_ps=hv_t_ps).view(B, L, d)
     else:
         dhv = _lin_bwd(grads, dsc2[:, :V], hv.view(M, d), dec.fc_vocab.weight, dec.fc_vocab.bias,
-                       group_now=True, wt_ps=m.get("vocab_t_ps")).view(B, L, d)
+                       group_now=True, wt_ps=m.get("vocab_t_ps"), xt_ps=hv_t_ps).view(B, L, d)
+    if early_update is not None and ops.SIDE is not None:
+        # rides behind the NEXT grouped launch of the side stream (no fork point of its own: each costs the main chain
+        # ~4 us), whose dependency point lies behind the data gradient, the last reader of fc_vocab.weight
+        ops.SIDE.submit_with_group(early_update["head"])
     if dec.has_facts:
         dh = ops.mul(dhv, m["gate"])
         dgate = ops.mul(dhv, h)
@@ -820,8 +853,9 @@ def _backward_phases(dec, tape, dscores, grads, want_image_grad=False):
     if pkb is not None:
         state = (dh.view(M, d), None, None)
         for li in reversed(range(len(layers))):
+            done = functools.partial(early_update["layer"], li) if early_update is not None else None
             state = _decoder_layer_bwd_chain(dec, li, layers[li], tape.dec_layers[li], state, dkv_rows, m["kv"], S,
-                                             grads, pkb, mem2=m["mem"].view(B * S, d), mem_t_ps=mem_t_ps)
+                                             grads, pkb, mem2=m["mem"].view(B * S, d), mem_t_ps=mem_t_ps, on_done=done)
             ops.stamp("bwd: decoder layer %d done" % li)
         dx = state[0]
     else:
@@ -953,7 +987,13 @@ class TrainStep:
         # bucket order: the parameters whose gradients are complete first come first, so that with several ranks
         # their part of the bucket can be all-reduced while the rest of the backward pass still runs
         early_ids = {id(p) for p in early_parameters(decoder)}
-        params = [p for p in params if id(p) in early_ids] + [p for p in params if id(p) not in early_ids]
+        # ... and inside the early part fc_vocab, then the decoder layers, come first: with one rank their optimizer
+        # update runs inside the backward pass (see _early_update), over bucket ranges [lo, hi) of their own
+        first = list(decoder.fc_vocab.parameters()) + [q for l in decoder.transformer_decoder.layers for q in l.parameters()]
+        first_ids = {id(p) for p in first if p.requires_grad}
+        params = [p for p in params if id(p) in first_ids] + \
+                 [p for p in params if id(p) in early_ids and id(p) not in first_ids] + \
+                 [p for p in params if id(p) not in early_ids]
         dev = params[0].device
         # every parameter starts at a multiple of 64 floats (256 bytes): the GEMM's 16-byte vector loads need aligned
         # weight rows, and one odd-sized parameter (fc_entity.bias has a single element) would misalign all that follow
@@ -979,6 +1019,23 @@ class TrainStep:
                 off += pad(k)
         self.params = params
         self._graphs = {}
+        # bucket range of a module whose trainable parameters lie next to each other in the bucket (else None)
+        offs = {}
+        off = 0
+        for p in params:
+            offs[id(p)] = (off, off + pad(p.numel()))
+            off += pad(p.numel())
+
+        def span(mod):
+            r = sorted(offs[id(q)] for q in mod.parameters() if id(q) in offs)
+            if not r or any(a[1] != b[0] for a, b in zip(r, r[1:])):
+                return None
+            return r[0][0], r[-1][1]
+
+        self._spans = {"head": span(decoder.fc_vocab)}
+        for li, l in enumerate(decoder.transformer_decoder.layers):
+            self._spans[li] = span(l)
+        self._early_done = []
         # several ranks: every replica starts from rank 0's weights (a freshly built decoder is randomly initialised
         # per process; the reference has a single process, geo-aware/train.py:16-18).  One broadcast of the bucket.
         dp.broadcast_bucket(self.flat_p, self.pg)
@@ -1037,10 +1094,43 @@ class TrainStep:
         _, _, dscores = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True,
                                       out_sum=self.flat_g[self.n:self.n + 1], out_count=self.flat_g[self.n + 1:])
         ops.stamp("CE done")
+        self._early_done = []
         backward_from_tape(dec, tape, dscores, self.grads,
-                           overlap=self._overlap("ICK_NO_BWD_OVERLAP"))
+                           overlap=self._overlap("ICK_NO_BWD_OVERLAP"), early_update=self._early_update())
         ops.stamp("A: end (after join)")
         return self.flat_g
+
+    def _adam(self, lo, hi):
+        # divide by the global token count (device-resident), clamp, Adam with the device step counter
+        ops.adam_clamp(self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi], 1, self.lr,
+                       self.clip, 1.0, self.betas[0], self.betas[1], self.eps, step_tensor=self.counter,
+                       gscale_den=self.flat_g[self.n + 1:])
+
+    def _early_update(self):
+        """ICK_EARLY_ADAM=all | head | layers (opt-in experiment; one rank, overlapped backward pass): clamp + Adam of
+        fc_vocab and / or of each decoder layer run on the side stream as soon as that part's gradients are complete (the
+        side stream idles 30-40 us between its weight-gradient groups; the single update at the step's end is 56-60 us
+        of HBM time on the critical path).  Element-wise clamp (geo-aware/train.py:287-288) and Adam are per-element,
+        the token count is known since the loss kernel, and the step counter moves in part B: the same numbers as the
+        single launch (tests/test_round4_gpu.py).  MEASURED AND LEFT OFF: on one box, interleaved runs, 1.828 ms without,
+        1.838 all, 1.829 head only, 1.841 layers only -- the 3 000-workgroup streaming kernels take the slots the
+        latency-bound main chain is waiting for, which costs what the shorter tail gains.  With several ranks the
+        gradients first meet in the all-reduce between the graphs, so nothing can be updated early anyway."""
+        which = os.environ.get("ICK_EARLY_ADAM", "")
+        if which not in ("all", "head", "layers") or dp.world_size(self.pg) > 1 or self.split or self.deterministic:
+            return None
+
+        def update(key):
+            r = self._spans.get(key)
+            if (which == "head" and key != "head") or (which == "layers" and key == "head"):
+                r = None
+            if r is not None:
+                ops.stamp("side: early update starts")
+                self._adam(*r)
+                ops.stamp("side: early update done")
+                self._early_done.append(r)
+
+        return {"head": functools.partial(update, "head"), "layer": update}
 
     # ---- the same step in two halves (several ranks: the early half's all-reduce overlaps the late half) ----
     def _part_a1(self, captions, caption_masks, entities, facts, enc_in, gmap, lengths):
@@ -1072,9 +1162,11 @@ class TrainStep:
     def _part_b(self):
         # divide by the global token count (device-resident), clamp, Adam with the device step counter
         ops.stamp("B: start")
-        ops.adam_clamp(self.flat_p, self.flat_g, self.flat_m, self.flat_v, 1, self.lr, self.clip, 1.0,
-                       self.betas[0], self.betas[1], self.eps, step_tensor=self.counter,
-                       gscale_den=self.flat_g[self.n + 1:])
+        lo = 0
+        for a, b in sorted(self._early_done) + [(self.n, self.n)]:      # what part A has not updated already
+            if a > lo:
+                self._adam(lo, a)
+            lo = max(lo, b)
         ops.counter_add(self.counter, 1)
         ops.stamp("B: end")
         return self.flat_g
