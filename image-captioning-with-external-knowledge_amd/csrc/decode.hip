@@ -901,15 +901,14 @@ struct HeadArgs {
     const int32_t* n_done; int n_total;
 };
 
-__global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
-    __shared__ __attribute__((aligned(16))) float xs[kDMax];
+// One row of the score head: final LayerNorm -> h (x gate) -> pointer scores.  Written for four waves; in a wider workgroup
+// (the merged head + vocabulary launch) the waves beyond the fourth only keep the barriers company.
+__device__ __forceinline__ void head_row(const HeadArgs& a, const int64_t r, float* xs, float4* psum) {
     const int tid = threadIdx.x;
-    const int64_t r = blockIdx.x;
     const int d = a.d, d4 = d >> 2;
     const int64_t b = r / a.rows_per_sample;
     const int lane = tid & 63, wave = wave_id(), sub = lane >> 4, i = lane & 15;
     const int done = a.n_done != nullptr ? *a.n_done : 0;
-    __shared__ __attribute__((aligned(16))) float4 psum[4 * kD4Max];
     RowGather<1, 4> in;
     in.issue(a.src, r, a.R, d);
     const float* wq[2] = {a.we, a.fe != nullptr && a.F > 0 ? a.wf : a.we};
@@ -933,7 +932,9 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
     __syncthreads();
     in.finish(a.src, r, a.R, d, psum, xs, true);
     __syncthreads();
-    for (int c = tid; c < d; c += 256) a.hv[r * d + c] = a.gate ? xs[c] * a.gate[r * d + c] : xs[c];
+    if (tid < 256)
+        for (int c = tid; c < d; c += 256) a.hv[r * d + c] = a.gate ? xs[c] * a.gate[r * d + c] : xs[c];
+    if (wave >= 4) return;      // no barrier below
     float4 xr[5];
 #pragma unroll
     for (int it = 0; it < 5; ++it) xr[it] = reinterpret_cast<const float4*>(xs)[i + 16 * it];      // zero beyond d
@@ -972,6 +973,12 @@ __global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void dec_head_kernel(HeadArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[kDMax];
+    __shared__ __attribute__((aligned(16))) float4 psum[4 * kD4Max];
+    head_row(a, blockIdx.x, xs, psum);
 }
 
 struct VocabArgs {
@@ -1109,6 +1116,178 @@ __global__ __launch_bounds__(kNT) void dec_vocab_kernel(VocabArgs a) {
         ICK_STAMP(3, 4);
         if (m0 + 32 < a.R) __syncthreads();       // the exchange buffer is reused by the next block of rows
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Score head + vocabulary logits in ONE launch for R <= 32 rows (greedy decoding): the vocabulary
+// workgroups no longer wait for a launch that writes h -- each normalises the R rows itself (LN-on-load into LDS, 16
+// lanes per row, four source rows' loads in flight at once: three L2 round trips, hidden behind the fetch of the
+// workgroup's 58 KB weight slice from HBM), and R more workgroups of the same launch do what dec_head_kernel does
+// (h, h x gate, pointer scores).  No workgroup depends on another.  One dependent launch less per token.
+// The normalised rows are summed source by source in the order res, bias, partial 0, 1, ...: deterministic, the same in
+// every vocabulary workgroup.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kHvSrc = 12;                    // residual + bias + up to 10 partial rows (heads / FFN chunks)
+constexpr int kHvChunk = 4;                   // source rows in flight per lane (x 5 float4)
+constexpr int kHvLd = kDMax + 4;              // LDS row stride of the normalised rows
+__global__ __launch_bounds__(kNT) void dec_headvocab_kernel(HeadArgs ha, VocabArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[kNW][2][kVocabCT][16][17];
+    __shared__ __attribute__((aligned(16))) float xa[32 * kHvLd];
+    __shared__ __attribute__((aligned(16))) float4 psum[4 * kD4Max];
+    if ((int)blockIdx.x >= a.ntiles) {          // head role (uniform per workgroup)
+        head_row(ha, (int64_t)blockIdx.x - a.ntiles, xa, psum);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
+    const int fi = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * kVocabTile;
+    const int d = a.d, d4 = d >> 2;
+    const int done = a.n_done != nullptr ? *a.n_done : 0;
+    // this wave's K slice of the 48 weight rows (HBM: the longest wait of the kernel, requested first)
+    float4 bw[kVocabCT][kVocabKC];
+    uint32_t koff[kVocabKC];
+    bool kok[kVocabKC];
+#pragma unroll
+    for (int t = 0; t < kVocabKC; ++t) {
+        const int k = 16 * (kVocabKC * wave + t) + 4 * fq;
+        kok[t] = k < d;
+        koff[t] = kok[t] ? 4u * (uint32_t)k : 0u;
+    }
+#pragma unroll
+    for (int ct = 0; ct < kVocabCT; ++ct) {
+        const uint32_t rb = (uint32_t)min(n0 + 16 * ct + fi, a.V - 1) * (uint32_t)d * 4u;
+#pragma unroll
+        for (int t = 0; t < kVocabKC; ++t) {
+            bw[ct][t] = ld4o(a.wv, rb + koff[t]);
+            if (!kok[t]) bw[ct][t] = f4zero();
+        }
+    }
+    const int row = tid >> 4, cp = tid & 15;         // LN role and epilogue role: one row per 16 lanes
+    constexpr int kCols = kVocabTile / 16;
+    float biasv[kCols];
+#pragma unroll
+    for (int e = 0; e < kCols; ++e) biasv[e] = a.bv[min(n0 + kCols * cp + e, a.V - 1)];
+    if (done >= a.n_total) return;
+    // ---- x[row] = LayerNorm(res + bias + sum of the partial rows) (x gate): lane cp holds float4 columns cp + 16 it
+    {
+        const RowSrc& s = ha.src;
+        const int64_t r = min(row, a.R - 1);
+        const int nrows = s.nparts > 0 ? s.nparts + 2 : 1;
+        uint32_t col[5];
+#pragma unroll
+        for (int it = 0; it < 5; ++it) col[it] = 16u * (uint32_t)min(cp + 16 * it, d4 - 1);
+        float4 z[5];
+#pragma unroll
+        for (int it = 0; it < 5; ++it) z[it] = f4zero();
+#pragma unroll 1
+        for (int half = 0; half < kHvSrc / kHvChunk; ++half) {
+            float4 v[kHvChunk][5];
+#pragma unroll
+            for (int j = 0; j < kHvChunk; ++j) {
+                const int q = min(half * kHvChunk + j, nrows - 1);
+                const float* src = q == 0 ? s.res + r * d : (q == 1 ? s.bias : s.part + (r * s.nparts + (q - 2)) * d);
+#pragma unroll
+                for (int it = 0; it < 5; ++it) v[j][it] = ld4o(src, col[it]);
+            }
+#pragma unroll
+            for (int j = 0; j < kHvChunk; ++j) {
+                const float f = half * kHvChunk + j < nrows ? 1.f : 0.f;
+#pragma unroll
+                for (int it = 0; it < 5; ++it) {
+                    z[it].x = fmaf(v[j][it].x, f, z[it].x); z[it].y = fmaf(v[j][it].y, f, z[it].y);
+                    z[it].z = fmaf(v[j][it].z, f, z[it].z); z[it].w = fmaf(v[j][it].w, f, z[it].w);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);     // the next chunk's loads stay behind this chunk's sums (registers)
+        }
+        bool ok[5];
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            ok[it] = cp + 16 * it < d4;
+            if (!ok[it]) z[it] = f4zero();
+        }
+        if (s.nparts > 0) {
+            float4 gm[5], bt[5];
+#pragma unroll
+            for (int it = 0; it < 5; ++it) { gm[it] = ld4o(s.gamma, col[it]); bt[it] = ld4o(s.beta, col[it]); }
+            float sum = 0.f;
+#pragma unroll
+            for (int it = 0; it < 5; ++it) sum += (z[it].x + z[it].y) + (z[it].z + z[it].w);
+            const float mean = sum16(sum) / (float)d;
+            float var = 0.f;
+#pragma unroll
+            for (int it = 0; it < 5; ++it)
+                if (ok[it]) {
+                    var = fmaf(z[it].x - mean, z[it].x - mean, var); var = fmaf(z[it].y - mean, z[it].y - mean, var);
+                    var = fmaf(z[it].z - mean, z[it].z - mean, var); var = fmaf(z[it].w - mean, z[it].w - mean, var);
+                }
+            const float rstd = rsqrtf(sum16(var) / (float)d + s.eps);
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                z[it].x = (z[it].x - mean) * rstd * gm[it].x + bt[it].x; z[it].y = (z[it].y - mean) * rstd * gm[it].y + bt[it].y;
+                z[it].z = (z[it].z - mean) * rstd * gm[it].z + bt[it].z; z[it].w = (z[it].w - mean) * rstd * gm[it].w + bt[it].w;
+            }
+        }
+        if (ha.gate != nullptr) {
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const float4 g = ld4o(ha.gate + r * d, col[it]);
+                z[it].x *= g.x; z[it].y *= g.y; z[it].z *= g.z; z[it].w *= g.w;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 5; ++it)
+            reinterpret_cast<float4*>(xa + row * kHvLd)[cp + 16 * it] = ok[it] ? z[it] : f4zero();
+    }
+    __syncthreads();
+    float4 av0[kVocabKC], av1[kVocabKC];
+#pragma unroll
+    for (int t = 0; t < kVocabKC; ++t) {
+        av0[t] = kok[t] ? *reinterpret_cast<const float4*>(xa + fi * kHvLd + (koff[t] >> 2)) : f4zero();
+        av1[t] = kok[t] ? *reinterpret_cast<const float4*>(xa + (16 + fi) * kHvLd + (koff[t] >> 2)) : f4zero();
+    }
+#pragma unroll
+    for (int ct = 0; ct < kVocabCT; ++ct) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < kVocabKC; ++t) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t].x, bw[ct][t].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t].x, bw[ct][t].x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t].y, bw[ct][t].y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t].y, bw[ct][t].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t].z, bw[ct][t].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t].z, bw[ct][t].z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t].w, bw[ct][t].w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t].w, bw[ct][t].w, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            red[wave][0][ct][fq * 4 + rg][fi] = acc0[rg];
+            red[wave][1][ct][fq * 4 + rg][fi] = acc1[rg];
+        }
+    }
+    __syncthreads();
+    // thread (row = tid >> 4, three columns): sum the eight K slices in a fixed order, add the bias
+    Top2 t2{-INFINITY, -INFINITY, kNone, kNone};
+#pragma unroll
+    for (int e = 0; e < kCols; ++e) {
+        const int colv = kCols * cp + e, n = n0 + colv, ct = colv >> 4, cc = colv & 15;
+        float v = red[0][row >> 4][ct][row & 15][cc];
+#pragma unroll
+        for (int w = 1; w < kNW; ++w) v += red[w][row >> 4][ct][row & 15][cc];
+        if (n < a.V) {
+            v += biasv[e];
+            if (a.scores != nullptr && row < a.R) a.scores[(int64_t)row * a.ld + n] = v;
+            top2_push(t2, v, n);
+        }
+    }
+    t2 = top2_merge_dpp<kDppXor1>(t2);
+    t2 = top2_merge_dpp<kDppXor2>(t2);
+    t2 = top2_merge_dpp<kDppHalfMirror>(t2);
+    t2 = top2_merge_dpp<kDppMirror>(t2);
+    if (cp == 0 && row < a.R)
+        a.cand[(int64_t)row * a.ntiles + blockIdx.x] =
+            make_float4(t2.v1, __int_as_float(t2.i1), t2.v2, __int_as_float(t2.i2));
 }
 
 struct SelectArgs {
@@ -1650,11 +1829,18 @@ static int decode_layers_impl(const ick_decode_ctx* c, int32_t pos, void* stream
     ha.fe = c->F > 0 ? c->fe : nullptr; ha.wf = c->wf; ha.bf = c->bf; ha.eib = c->eib; ha.ptr = c->ptr;
     ha.R = R; ha.rows_per_sample = c->rows_per_sample; ha.d = d; ha.K = c->K; ha.F = c->F;
     ha.n_done = c->n_done; ha.n_total = R;
-    if (which & 8u) hipLaunchKernelGGL(dec_head_kernel, dim3(R), dim3(256), 0, s, ha);
     VocabArgs va;
     va.hv = c->hv; va.wv = c->wv; va.bv = c->bv; va.scores = c->scores; va.ld = c->scores_ld;
     va.cand = reinterpret_cast<float4*>(c->cand); va.R = R; va.d = d; va.V = c->V; va.ntiles = ceil_div(c->V, kVocabTile);
     va.n_done = c->n_done; va.n_total = R;
+    // one launch for both when the rows fit one 32-row block and the final LayerNorm's sources fit the merged kernel's
+    // registers (greedy decoding at cfg5); ICK_DECODE_SPLIT_HEAD=1 keeps the two launches (A/B runs, the diagnostic build)
+    static const bool split_head = getenv("ICK_DECODE_SPLIT_HEAD") != nullptr;
+    if ((which & 24u) == 24u && R <= 32 && src.nparts + 2 <= kHvSrc && !split_head) {
+        hipLaunchKernelGGL(dec_headvocab_kernel, dim3(va.ntiles + R), dim3(kNT), 0, s, ha, va);
+        ICK_LAUNCH_RET();
+    }
+    if (which & 8u) hipLaunchKernelGGL(dec_head_kernel, dim3(R), dim3(256), 0, s, ha);
     if (which & 16u) hipLaunchKernelGGL(dec_vocab_kernel, dim3(va.ntiles), dim3(kNT), 0, s, va);
     ICK_LAUNCH_RET();
 }
