@@ -230,20 +230,52 @@ class Workload:
                     # host-to-device copy would put the next batch -- so no per-step device-to-device input copy
                     state["args"] = ts.input_buffers()
                 return out
-        elif mode == "forward":
-            def step():
-                with torch.no_grad():
-                    e = enc(feats)
-                    return dec(batch["captions"], e, batch["caption_masks"], batch["caption_lengths"],
-                               batch["entities"], *extra)
-        elif mode == "greedy":
-            def step():
-                e = enc(feats)
-                return dec.predict(e, L, batch["entities"], *extra)
         else:
-            def step():
-                e = enc(feats)
-                return dec.predict_beam(e, L, batch["entities"], *extra, beam_size=BEAM)
+            # attach_encoder: the calls below take the feature map itself and Encoder.conv1 runs inside the captured
+            # graph beside the context-encoder chain (ICK_BENCH_SEPARATE_ENCODER=1: the stand-alone Encoder launch in
+            # front of the graph, as before round 4).  After the first call the (HBM-resident) batch lives in the graph's
+            # own input buffers -- where a loader's host-to-device copy would put the next batch -- so no step pays a
+            # device-to-device copy of its inputs.
+            legacy = os.environ.get("ICK_BENCH_SEPARATE_ENCODER") == "1" or not use_graph
+            if not legacy:
+                dec.attach_encoder(enc)
+            cur = {"feats": feats, "ent": batch["entities"], "facts": extra[0] if extra else None,
+                   "caps": batch["captions"], "masks": batch["caption_masks"]}
+
+            def adopt():
+                bufs = dec.input_buffers() if use_graph else None
+                if bufs is None or cur.get("adopted"):
+                    return
+                if mode == "forward":
+                    cur["caps"], cur["masks"], cur["ent"], cur["facts"], img = bufs
+                else:
+                    img, cur["ent"], cur["facts"] = bufs
+                if not legacy:
+                    cur["feats"] = img
+                cur["adopted"] = True
+
+            def image():
+                return enc(cur["feats"]) if legacy else cur["feats"]
+
+            def fx():
+                return [cur["facts"]] if extra else []
+
+            if mode == "forward":
+                def step():
+                    with torch.no_grad():
+                        out = dec(cur["caps"], image(), cur["masks"], batch["caption_lengths"], cur["ent"], *fx())
+                    adopt()
+                    return out
+            elif mode == "greedy":
+                def step():
+                    out = dec.predict(image(), L, cur["ent"], *fx())
+                    adopt()
+                    return out
+            else:
+                def step():
+                    out = dec.predict_beam(image(), L, cur["ent"], *fx(), beam_size=BEAM)
+                    adopt()
+                    return out
         return step
 
     def graph_in_use(self):

@@ -117,7 +117,7 @@ class CaptionEmbedder(nn.Module):
 # never part of a pickle (checkpoints pickle whole modules, geo-aware/utils.py:32-46) or of a deep copy -- they are rebuilt
 # on first use.
 _CACHE_KEYS = ("_graphs", "_kv_pack", "_pred_wt_cache", "_len_pin", "_idx_pin", "_plist", "_pin_ev", "_dec_pack",
-               "_chain_cache", "_chain_cache_bwd", "_chain_ok", "_chain_bwd_ok", "_ps_cache")
+               "_chain_cache", "_chain_cache_bwd", "_chain_ok", "_chain_bwd_ok", "_ps_cache", "_last_static", "_enc")
 
 
 def _state_without_caches(module):
@@ -338,7 +338,7 @@ class DecoderTransformer(nn.Module):
         writes the flat bucket directly): drops the packed cross-K/V weights, the transposed predicate
         weights and every captured graph."""
         self.__dict__["_param_epoch"] = self.__dict__.get("_param_epoch", 0) + 1
-        for k in ("_kv_pack", "_pred_wt_cache", "_graphs", "_plist", "_dec_pack"):   # (_chain_cache keeps its buffer:
+        for k in ("_kv_pack", "_pred_wt_cache", "_graphs", "_plist", "_dec_pack", "_last_static"):   # (_chain_cache keeps its buffer:
             # captured training graphs write it; its key holds _param_epoch, so the contents are refreshed)
             self.__dict__.pop(k, None)
 
@@ -348,6 +348,32 @@ class DecoderTransformer(nn.Module):
         if encoder_out.stride() == (P * d, 1, d):
             return encoder_out.permute(0, 2, 1)
         return encoder_out.permute(0, 2, 1).contiguous()
+
+    def attach_encoder(self, encoder):
+        """Let forward() / predict() / predict_beam() take the (B, 2048, 14, 14) feature map in place of encoder_out:
+        Encoder.conv1 then runs INSIDE the captured graph, on the main stream beside the context-encoder chain on the
+        side stream -- instead of a stand-alone launch the graph (and with it the context chain, which never reads the
+        image) has to wait for.  Same kernels, same numbers (tests/test_round4_gpu.py); cfg2 forward 0.76 -> ~0.6 ms,
+        cfg5 greedy 2.15 -> ~1.9 ms.  encoder_out tensors (B, emb_dim, 196) keep working as before.  The encoder is not
+        registered as a submodule (state_dict / parameters() of the decoder stay the reference's)."""
+        self.__dict__["_enc"] = encoder
+        return self
+
+    def _image_input(self, encoder_out):
+        """-> (enc_in, P): the token-major (B, P, d) view of an encoder output, or -- with an attached Encoder and the
+        hipGraph paths on -- the float32 feature map itself (4-D) for _encode_context to project inside the graph."""
+        if encoder_out.dim() == 4:
+            enc = self.__dict__.get("_enc")
+            if enc is None:
+                raise IckError("a 4-D input is a feature map: attach_encoder(encoder) first, or pass encoder(feats)")
+            if self.use_hip_graphs and not self._wants_grad() and not os.environ.get("ICK_NO_FUSED_ENCODER") and \
+                    encoder_out.shape[1] == enc.encoder_dim:
+                feats = encoder_out if encoder_out.dtype == torch.float32 else encoder_out.float()
+                enc.conv1_presplit()       # refreshed in place, outside the captured graph, if conv1's weight changed
+                return feats.contiguous(), feats.shape[2] * feats.shape[3]
+            encoder_out = enc(encoder_out)
+        t = self._token_major(encoder_out)
+        return t, t.shape[1]
 
     def _packed_cross_kv(self):
         """[K_0;V_0;K_1;V_1;...] rows of the decoder layers' cross-attention in_proj, so the memory is
@@ -534,7 +560,15 @@ class DecoderTransformer(nn.Module):
         memory rows [196 image positions ; entity rows ; fact rows]."""
         d = self.emb_dim
         H = self.num_heads
-        B, P, _ = enc_tok.shape
+        feats = None
+        if enc_tok.dim() == 4:
+            # the feature map itself (attach_encoder): Encoder.conv1 runs below, beside the context chain
+            feats, enc = enc_tok, self.__dict__["_enc"]
+            B, Cc = feats.shape[:2]
+            P = feats.shape[2] * feats.shape[3]
+            enc_tok = torch.empty(B, P, d, device=feats.device, dtype=torch.float32)
+        else:
+            B, P, _ = enc_tok.shape
         K = entities.shape[1]
         ee = ops.entity_encode(self.variant, entities, self.entity_encoder.type_embedding.weight.detach(), d,
                                facts=facts if self.has_facts else None,
@@ -568,15 +602,26 @@ class DecoderTransformer(nn.Module):
         # dependency point now, enqueued after the main stream's next kernel: in a captured graph the main chain
         # must be the first child of the fork node (see SideStream)
         side.submit(entity_chain, ee, fe, kv, wkv, bkv)
+
+        def conv1():
+            c1 = enc.conv1
+            ops.gemm_raw(feats, c1.weight.detach().view(d, Cc), enc_tok, B * P, d, Cc, 1, P, Cc, 1, d,
+                         bias=c1.bias.detach(), a_grp=P, a_gs=Cc * P, b_ps=enc.conv1_presplit())
+
         if self.has_facts:
             # the fact chain runs on the main stream beside the entity chain (two chains of small kernels overlap well,
             # a chain beside the large projection does not: cfg4 forward 1.84 -> 1.72 ms), the image rows follow
             fact_chain()
             side.flush()
+            if feats is not None:
+                conv1()
             ops.project_heads(enc_tok, wkv, bkv, nseg, H, S, out=kv, s0=0, grp=P, a_gmap=gmap, a_gs=enc_tok.stride(0),
                               w_ps=wkv_ps)
         else:
             # image rows (gathered through gmap = sort order)
+            if feats is not None:
+                conv1()
+                side.flush()       # the context chain starts beside Encoder.conv1
             ops.project_heads(enc_tok, wkv, bkv, nseg, H, S, out=kv, s0=0, grp=P, a_gmap=gmap, a_gs=enc_tok.stride(0),
                               w_ps=wkv_ps)
             side.flush()
@@ -737,6 +782,21 @@ class DecoderTransformer(nn.Module):
                           fact_context=ctx[1], h=x, kv=kv, eib=eib, gate=gate)
         return scores
 
+    def _enc_key(self, enc_in):
+        """Graph-key part for a feature-map input: the attached encoder's conv1 is read through its device pointers."""
+        if enc_in.dim() != 4:
+            return ()
+        c1 = self.__dict__["_enc"].conv1
+        return (c1.weight.data_ptr(), c1.bias.data_ptr())
+
+    def input_buffers(self):
+        """The static input tensors of the graph the last forward() / predict() / predict_beam() call replayed (None
+        before the first graphed call), in that call's order -- forward: [captions, caption_masks, entities, facts,
+        image input]; predict*: [image input, entities, facts].  A loader that copies the next batch straight into them
+        and passes them back in saves the device-to-device input copy of every call (the feature map is 103 MB at
+        B = 64)."""
+        return self.__dict__.get("_last_static")
+
     def _graphed(self, kind, key, fn, inputs):
         """Replay (capturing on first use) the hipGraph of `fn` for this shape key; parameters are read
         through their device pointers, so in-place weight updates are seen, re-allocation is not
@@ -753,6 +813,7 @@ class DecoderTransformer(nn.Module):
             if len(cache) >= 8:
                 cache.clear()
             g = cache[full] = _GraphedCall(fn, inputs)
+        self.__dict__["_last_static"] = g.static_in
         return g(*inputs)
 
     def forward(self, captions, encoder_out, caption_masks, caption_lengths, entities, facts=None, stages=None):
@@ -760,7 +821,9 @@ class DecoderTransformer(nn.Module):
         dev = encoder_out.device
         captions = captions.to(dev)
         caption_masks = caption_masks.to(dev)
-        enc_tok = self._token_major(encoder_out)
+        if encoder_out.dim() == 4 and not (stages is None and not self._wants_grad() and self.use_hip_graphs):
+            encoder_out = self.__dict__["_enc"](encoder_out) if "_enc" in self.__dict__ else encoder_out
+        enc_tok, _ = self._image_input(encoder_out)
 
         def sorted_inputs(c, m, e, f, sd):
             """Batch permutation into length order (reference: geo-aware/models.py:330-336), on the device."""
@@ -782,7 +845,7 @@ class DecoderTransformer(nn.Module):
                 ev = torch.cuda.Event()
                 ev.record()
             key = (tuple(captions.shape), tuple(enc_tok.shape), tuple(entities.shape),
-                   None if facts is None else tuple(facts.shape))
+                   None if facts is None else tuple(facts.shape)) + self._enc_key(enc_tok)
             scores_raw = self._graphed("fwd", key, lambda c, m, e, f, t: self._forward_device(c, m, e, f, t, None),
                                        [captions, caption_masks, entities, facts, enc_tok])
             if ev is not None:
@@ -995,17 +1058,18 @@ class DecoderTransformer(nn.Module):
             return DecoderTransformer.predict(self, encoder_out, max_pred_len, entities, facts)
         encoder_out, entities, facts = self._prepare_inputs(encoder_out, entities, facts)
         entities = entities.contiguous()
-        enc_tok = self._token_major(encoder_out).contiguous()
+        enc_tok, P = self._image_input(encoder_out)
+        enc_tok = enc_tok.contiguous()
         FF = self.transformer_decoder.layers[0].linear1.out_features
-        S_all = enc_tok.shape[1] + entities.shape[1] + (facts.shape[1] if facts is not None else 0)
-        Vx = self.vocab_size + S_all - enc_tok.shape[1]
+        S_all = P + entities.shape[1] + (facts.shape[1] if facts is not None else 0)
+        Vx = self.vocab_size + S_all - P
         if not (1 < beam_size <= 8) or not ops.decode_supported(self.emb_dim, self.num_heads, FF, S_all, max_pred_len) \
                 or not ops.decode_beam_supported(Vx, beam_size):
             raise IckError("predict_beam needs 1 <= beam_size <= 8, beam_size^2 * ceil((V+K+F)/1024) <= 4096 and sizes "
                            "the fused decode kernels support")
         if self.use_hip_graphs:
             key = (tuple(enc_tok.shape), tuple(entities.shape), None if facts is None else tuple(facts.shape),
-                   max_pred_len, beam_size)
+                   max_pred_len, beam_size) + self._enc_key(enc_tok)
             res = self._graphed("beam", key, lambda t, e, f: self._predict_beam_device(t, e, f, max_pred_len, beam_size),
                                 [enc_tok, entities, facts])
         else:
@@ -1019,7 +1083,8 @@ class DecoderTransformer(nn.Module):
         dev = enc_tok.device
         B = enc_tok.shape[0]
         d, V, K = self.emb_dim, self.vocab_size, entities.shape[1]
-        S_all = enc_tok.shape[1] + K + (facts.shape[1] if facts is not None else 0)
+        P = enc_tok.shape[1] if enc_tok.dim() == 3 else enc_tok.shape[2] * enc_tok.shape[3]
+        S_all = P + K + (facts.shape[1] if facts is not None else 0)
         FF = self.transformer_decoder.layers[0].linear1.out_features
         if self.fused_decode and ops.decode_supported(d, self.num_heads, FF, S_all, max_pred_len):
             return self._predict_fused(enc_tok, entities, facts, max_pred_len)
@@ -1061,10 +1126,10 @@ class DecoderTransformer(nn.Module):
         batch size (B independent captions); returns LongTensor (max_pred_len, B), <pad> after <end>."""
         encoder_out, entities, facts = self._prepare_inputs(encoder_out, entities, facts)
         entities = entities.contiguous()
-        enc_tok = self._token_major(encoder_out).contiguous()
+        enc_tok = self._image_input(encoder_out)[0].contiguous()
         if self.use_hip_graphs:
             key = (tuple(enc_tok.shape), tuple(entities.shape), None if facts is None else tuple(facts.shape),
-                   max_pred_len)
+                   max_pred_len) + self._enc_key(enc_tok)
             output = self._graphed("greedy", key, lambda t, e, f: self._predict_device(t, e, f, max_pred_len),
                                    [enc_tok, entities, facts])
         else:

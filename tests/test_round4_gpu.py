@@ -115,3 +115,40 @@ def test_early_optimizer_update_equals_the_single_update(monkeypatch):
     assert ((ts1.flat_p - ts0.flat_p).abs()[sure]).max().item() < 1e-6
     assert (ts1.flat_p - ts0.flat_p).abs().max().item() <= 2 * 4e-4 + 1e-6
     assert ts1.counter.item() == ts0.counter.item() == 1
+
+
+def test_feature_map_inputs_run_conv1_inside_the_graph(gemm_split):
+    """attach_encoder(): forward() / predict() / predict_beam() on the (B, 2048, 14, 14) feature map give exactly what
+    they give on Encoder(feats) -- the same conv1 GEMM, only launched inside the captured graph beside the context
+    chain -- and passing the graph's own input buffers back in (input_buffers()) changes nothing."""
+    variant, B, L, K, V, seed = "geo", 8, 12, 6, 300, 11
+    P = synth.make_params(variant, V, seed)
+    enc, _, _ = make_encoder(seed)
+    dec = build_decoder(variant, V, P).eval()
+    b = synth.make_batch(variant, B, L, K, V, 0, seed)
+    feats = synth.make_feats(B, seed).cuda()
+    caps, masks, lens, ents = b["captions"].cuda(), b["caption_masks"].cuda(), b["caption_lengths"].cuda(), b["entities"].cuda()
+    with torch.no_grad():
+        e = enc(feats)
+        ref_scores, ref_caps, ref_dl = dec(caps, e, masks, lens, ents)
+        ref_tok = dec.predict(e, L, ents)
+        ref_beam = dec.predict_beam(e, L, ents, beam_size=3)
+        from ick_amd.lib import IckError
+        with pytest.raises(IckError):
+            dec.predict(feats, L, ents)                       # a feature map without an attached encoder
+        dec.attach_encoder(enc)
+        for rep in range(2):
+            scores, caps_s, dl = dec(caps, feats, masks, lens, ents)
+            assert dl == ref_dl and torch.equal(caps_s, ref_caps) and torch.equal(scores, ref_scores)
+        bufs = dec.input_buffers()
+        assert bufs[4].shape == feats.shape and bufs[4].data_ptr() != feats.data_ptr()
+        scores, _, _ = dec(bufs[0], bufs[4], bufs[1], lens, bufs[2])          # the graph's own buffers: no input copy
+        assert torch.equal(scores, ref_scores)
+        assert torch.equal(dec.predict(feats, L, ents), ref_tok)
+        img, ent_buf, _ = dec.input_buffers()
+        assert img.dim() == 4 and torch.equal(dec.predict(img, L, ent_buf), ref_tok)
+        assert torch.equal(dec.predict_beam(feats, L, ents, beam_size=3), ref_beam)
+        # encoder outputs keep working on a decoder with an attached encoder
+        assert torch.equal(dec.predict(e, L, ents), ref_tok)
+    # the attached encoder is not part of the decoder's state
+    assert not any(k.startswith("_enc") for k in dec.state_dict()) and "_enc" not in dec.__getstate__()
