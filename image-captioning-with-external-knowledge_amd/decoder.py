@@ -508,7 +508,7 @@ class DecoderTransformer(nn.Module):
             self.__dict__["_pred_wt_cache"] = cache
         return cache[1]
 
-    def _context_encoder(self, stack, x, tag="e", out=None):
+    def _context_encoder(self, stack, x, tag="e", out=None, slim=False):
         """Post-LN encoder stack on x (B, T, d); `out` (optional (B, T, d) view, e.g. rows of the memory buffer)
         receives the last layer's output."""
         H = self.num_heads
@@ -531,7 +531,7 @@ class DecoderTransformer(nn.Module):
                 f = torch.empty(B, T, layer.linear1.out_features, device=x.device, dtype=torch.float32)
                 ops.rowchain_fwd(sa, pk[(tag, li, "so")], layer.self_attn.out_proj.bias.detach(), x,
                                  layer.norm1.weight.detach(), layer.norm1.bias.detach(), layer.norm1.eps, x1,
-                                 w2p=pk[(tag, li, "l1")], b2=layer.linear1.bias.detach(), y2=f, relu=True)
+                                 w2p=pk[(tag, li, "l1")], b2=layer.linear1.bias.detach(), y2=f, relu=True, slim=slim)
                 x2 = out if (last and out is not None) else torch.empty_like(x)
                 nxt = None if last else stack.layers[li + 1]
                 if nxt is not None:
@@ -540,7 +540,7 @@ class DecoderTransformer(nn.Module):
                                  layer.norm2.bias.detach(), layer.norm2.eps, x2,
                                  w2p=None if nxt is None else pk[(tag, li + 1, "si")],
                                  b2=None if nxt is None else nxt.self_attn.in_proj_bias.detach(), y2=qkv,
-                                 heads=None if nxt is None else (3, H, T, 0, T))
+                                 heads=None if nxt is None else (3, H, T, 0, T), slim=slim)
                 x = x2
                 continue
             o = ops.linear(sa, layer.self_attn.out_proj.weight.detach(), layer.self_attn.out_proj.bias.detach())
@@ -592,8 +592,13 @@ class DecoderTransformer(nn.Module):
         ctx = [None, None]
 
         def entity_chain():
-            ctx[0] = self._context_encoder(self.transformer_encoder_entities, ee)
+            ops.stamp("side: context chain starts")
+            # beside Encoder.conv1 / the image K/V projection: the 8-wave form finds room on a CU that hosts bulk GEMM
+            # workgroups (as in the training step; ICK_SLIM_INFER=0 for A/B)
+            ctx[0] = self._context_encoder(self.transformer_encoder_entities, ee,
+                                           slim=os.environ.get("ICK_SLIM_INFER", "1") != "0")
             ops.project_heads(ctx[0], wkv, bkv, nseg, H, S, out=kv, s0=P, grp=K)
+            ops.stamp("side: context chain done")
 
         def fact_chain():
             ctx[1] = self._context_encoder(self.transformer_encoder_facts, fe, tag="f")
@@ -625,6 +630,7 @@ class DecoderTransformer(nn.Module):
             ops.project_heads(enc_tok, wkv, bkv, nseg, H, S, out=kv, s0=0, grp=P, a_gmap=gmap, a_gs=enc_tok.stride(0),
                               w_ps=wkv_ps)
             side.flush()
+        ops.stamp("main: image K/V projection done")
         ctx_e, ctx_f = ctx
         return ee, fe, kv, (ctx_e, ctx_f), side
 
@@ -763,6 +769,7 @@ class DecoderTransformer(nn.Module):
         """Device-only part of forward() on length-sorted inputs (no host synchronisation inside)."""
         d, V = self.emb_dim, self.vocab_size
         K = entities.shape[1]
+        ops.stamp("forward: start")
         ee, fe, kv, ctx, side = self._encode_context(enc_tok, entities, facts, gmap)
         pe = self.pos_encoder.pe.view(-1, d)
         x, emb = ops.caption_embed(captions, caption_masks, self.word_embedding.weight.detach(), ee, fe, pe, V,
@@ -771,12 +778,14 @@ class DecoderTransformer(nn.Module):
         qkv = None
         for li, layer in enumerate(self.transformer_decoder.layers):
             x, qkv = self._decoder_layer(li, layer, x, kv, S, side=side if li == 0 else None, qkv=qkv, want_next=True)
+            ops.stamp("main: decoder layer %d done" % li)
         side.join()
         eib = gate = None
         if self.has_facts:
             eib, gate = ops.context_indicators(captions, facts, K, V, self._pred_wt(),
                                                self.fc_predicate.bias.detach(), mode=0)
         scores = self._score_head(x, ee, fe, eib, gate)
+        ops.stamp("forward: scores done")
         if stages is not None:
             stages.update(entities_encoded=ee, facts_encoded=fe, embeddings=emb, entity_context=ctx[0],
                           fact_context=ctx[1], h=x, kv=kv, eib=eib, gate=gate)
