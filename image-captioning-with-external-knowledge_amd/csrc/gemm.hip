@@ -734,7 +734,19 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
             // the bf16 pipe holds on random data at the clock the chip keeps under MFMA load (MI355X_MICROARCH.md).
             // (split-K problems -- the cross K/V weight gradient, 600 x 300 over 13 824 rows -- also run best on 128 x 128:
             // 62-67 us against 70-77 on 128 x 160 and 87-93 on the exact 64 x 64 tile, profiles/r04_i_gemm_ps_kv_wgrad.txt)
-            int best = (a.N <= 320 && split_req == 1) ? 2 : 1;
+            static int narrow_env = -2;
+            if (narrow_env == -2) { const char* e = getenv("ICK_PS_TILE_NARROW"); narrow_env = e ? atoi(e) : -1; }
+            static int wide_env = -2;
+            if (wide_env == -2) { const char* e = getenv("ICK_PS_TILE_WIDE"); wide_env = e ? atoi(e) : -1; }
+            // Inside the steps Encoder.conv1 runs beside the context-encoder chain of the other stream, whose 49 KB
+            // workgroups cannot share a CU with a 139 KB tile: on 128 x 80 (62 KB, two per CU; alone 2-8 % slower than
+            // 128 x 160) the cfg2 train step is 1.748 -> 1.722 ms and the forward pass 0.702 -> 0.693
+            // (profiles/r04_y_ab_narrow_tile.txt; ICK_PS_TILE_NARROW / ICK_PS_TILE_WIDE pick others for A/B runs)
+            int best = (a.N <= 320 && split_req == 1) ? (narrow_env >= 0 && narrow_env < gemm_ps_tile_count() ? narrow_env : 9)
+                                                      : (wide_env >= 0 && wide_env < gemm_ps_tile_count() ? wide_env : 1);
+            static int splitk_env = -2;
+            if (splitk_env == -2) { const char* e = getenv("ICK_PS_TILE_SPLITK"); splitk_env = e ? atoi(e) : -1; }
+            if (a.N <= 320 && split_req > 1 && splitk_env >= 0 && splitk_env < gemm_ps_tile_count()) best = splitk_env;
             if (ps_tile_env >= 0 && ps_tile_env < gemm_ps_tile_count()) best = ps_tile_env;
             int bm, bn, wpc; gemm_ps_tile_dims(best, &bm, &bn, &wpc);
             pl.ps = true; pl.ps_tile = best;

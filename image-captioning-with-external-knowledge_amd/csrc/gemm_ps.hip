@@ -470,10 +470,11 @@ int launch_ps_tile(const ick_gemm_args& a, bool akm, int np, int64_t bytes, int 
 //   8: 64 x 160   four waves (2 x 2) of 32 x 80, D 1, 76 KB: two per CU
 //   9: 128 x 80   8 x 1 waves of 16 x 80, D 1, 62 KB: two workgroups per CU (Encoder.conv1 as 98 x 4 tiles: the two
 //                 workgroups of a CU are not barrier-coupled, so their fragment and MFMA phases overlap)
-constexpr int kPsTiles = 10;
+//  10: 128 x 160  as 2 with D 1, 92 KB: leaves room on the CU for a 49 KB row-chain workgroup of the other stream
+constexpr int kPsTiles = 11;
 void gemm_ps_tile_dims(int tile, int* bm, int* bn, int* wgs_per_cu) {
     static const int dims[kPsTiles][3] = {{64, 320, 1}, {128, 128, 2}, {128, 160, 1}, {128, 320, 1}, {128, 128, 1},
-                                          {128, 128, 2}, {128, 160, 1}, {128, 128, 2}, {64, 160, 2}, {128, 80, 2}};
+                                          {128, 128, 2}, {128, 160, 1}, {128, 128, 2}, {64, 160, 2}, {128, 80, 2}, {128, 160, 1}};
     *bm = dims[tile][0]; *bn = dims[tile][1]; *wgs_per_cu = dims[tile][2];
 }
 int gemm_ps_tile_count() { return kPsTiles; }
@@ -494,6 +495,7 @@ int launch_gemm_ps(const ick_gemm_args& a, bool akm, int tile, int tiles_m, int 
         case 7: return launch_ps_tile<4, 1, 2, 8, 1, 2>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
         case 8: return launch_ps_tile<2, 2, 2, 5, 1, 5>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
         case 9: return launch_ps_tile<8, 1, 1, 5, 1, 2>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
+        case 10: return launch_ps_tile<8, 1, 1, 10, 1, 10>(a, akm, np, bytes, tiles_m, tiles_n, kchunk, split, a_nt, s);
     }
     return ICK_EINVAL;
 }

@@ -173,8 +173,9 @@ CONV1_TILE = (128, 64)   # workgroup tile ick_gemm picks for Encoder.conv1 at be
 
 def conv1_tile():
     """The workgroup tile Encoder.conv1 runs on at bench size in the library's current product mode (asserted by the
-    parity tests): 128 x 160 of the pre-split kernel (csrc/gemm_ps.hip) with split products, else CONV1_TILE."""
-    return (128, 160) if gemm_split_mode() >= 1 else CONV1_TILE
+    parity tests): 128 x 80 of the pre-split kernel (csrc/gemm_ps.hip; two workgroups per CU, small enough to share the
+    CU with the other stream's row chains) with split products, else CONV1_TILE."""
+    return (128, 80) if gemm_split_mode() >= 1 else CONV1_TILE
 
 # test hook: a list that receives (M, N, K, plan dict) of every single-problem ick_gemm launch while it is set
 PLAN_LOG = None

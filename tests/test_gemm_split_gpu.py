@@ -226,14 +226,14 @@ def test_presplit_copy_is_the_exact_three_way_split(ops, N, K, transposed):
 
 
 @pytest.mark.parametrize("M,N,K,akm,grp,split_k,tile", [
-    (12544, 300, 2048, True, 196, 1, (128, 160)),      # Encoder.conv1: k-major NCHW map, 196 positions per sample
+    (12544, 300, 2048, True, 196, 1, (128, 80)),      # Encoder.conv1: k-major NCHW map, 196 positions per sample
     (1280, 300, 10000, False, 0, 12, (128, 128)),      # vocabulary data gradient: split K, atomics
     (1280, 10000, 300, False, 0, 1, (128, 128)),      # vocabulary projection (K tail of 12)
     (12544, 1800, 300, False, 0, 1, (128, 128)),      # cross K/V projection of the image rows
-    (23044, 132, 516, False, 0, 1, (128, 160)),        # ragged: M tail, N < 320 (pieces beyond the padded rows), K tail of 4
+    (23044, 132, 516, False, 0, 1, (128, 80)),        # ragged: M tail, N < 320 (pieces beyond the padded rows), K tail of 4
     (2052, 1028, 516, False, 0, 1, (128, 128)),       # ragged edges of the square tile
     (2052, 1028, 516, True, 0, 1, (128, 128)),        # k-major A on the square tile
-    (23044, 260, 516, True, 0, 1, (128, 160)),         # k-major A, K tail of 4 k lines
+    (23044, 260, 516, True, 0, 1, (128, 80)),         # k-major A, K tail of 4 k lines
 ])
 def test_presplit_gemm_error_not_above_exact_path(ops, M, N, K, akm, grp, split_k, tile):
     if grp:
@@ -291,7 +291,7 @@ def test_underfilled_narrow_problem_keeps_the_stager_split_kernel(ops):
             A, W, out = torch.empty(Bn, K, 196, device="cuda"), torch.empty(N, K, device="cuda"), torch.empty(M, N, device="cuda")
             ps = ops.presplit_buffer(N, K, "cuda")
             info = plan_of(ops, ops.gemm_args(A, W, out, M, N, K, 1, 196, K, 1, N, a_grp=196, a_gs=K * 196, b_ps=ps))
-            assert info.presplit == want and (info.tile_m, info.tile_n) == ((128, 160) if want else (info.tile_m, info.tile_n)), (Bn, info.presplit)
+            assert info.presplit == want and (info.tile_m, info.tile_n) == ((128, 80) if want else (info.tile_m, info.tile_n)), (Bn, info.presplit)
     finally:
         ops.set_gemm_split(before)
 
