@@ -746,7 +746,10 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
                                                       : (wide_env >= 0 && wide_env < gemm_ps_tile_count() ? wide_env : 1);
             static int splitk_env = -2;
             if (splitk_env == -2) { const char* e = getenv("ICK_PS_TILE_SPLITK"); splitk_env = e ? atoi(e) : -1; }
-            if (a.N <= 320 && split_req > 1 && splitk_env >= 0 && splitk_env < gemm_ps_tile_count()) best = splitk_env;
+            // split-K problems at most 320 columns wide (the vocabulary's data gradient 1280 x 300 over K = 10 000, the
+            // cross K/V and vocabulary weight gradients): 128 x 80 as well -- the data gradient's 40 x 12 = 480 workgroups
+            // fill the chip's two slots per CU once (train step 1.770 -> 1.741 ms), the weight gradients are unchanged
+            if (a.N <= 320 && split_req > 1) best = splitk_env >= 0 && splitk_env < gemm_ps_tile_count() ? splitk_env : 9;
             if (ps_tile_env >= 0 && ps_tile_env < gemm_ps_tile_count()) best = ps_tile_env;
             int bm, bn, wpc; gemm_ps_tile_dims(best, &bm, &bn, &wpc);
             pl.ps = true; pl.ps_tile = best;

@@ -947,7 +947,7 @@ def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False, gro
             split = max(1, min(8, (N + 150) // 300))
         if wt_ps is not None and split > 1 and gemm_split_mode() >= 1 and K <= 320:
             # the pre-split kernel's 64 x 320 tile covers every output column: ~256 workgroups = row tiles x K slices
-            split = max(1, min(16, N // 512, 256 // ((M + 63) // 64)))
+            split = int(os.environ.get("ICK_VOCAB_DGRAD_SPLIT", max(1, min(16, N // 512, 256 // ((M + 63) // 64)))))
         if split > 1:
             if dx is None:
                 dx = torch.zeros(M, K, device=dy.device, dtype=torch.float32)

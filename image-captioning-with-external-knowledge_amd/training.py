@@ -302,6 +302,12 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
                 ops.presplit_weights([(_p(dec.fc_vocab.weight), m["vocab_ps"])])
             else:
                 m["vocab_ps"] = dec._vocab_presplit()
+            if fresh_pack and os.environ.get("ICK_VOCAB_DGRAD_PS", "1") != "0":
+                # the data gradient dh = dscores @ W on the pre-split kernel takes W^T as its B operand: on the 128 x 80
+                # tile (40 tiles x 12 K slices = 480 workgroups, two per CU) the cfg2 train step is 1.770 -> 1.741 ms
+                # (profiles/r04_y_ab_vocab_dgrad_ps.txt; on the 64 x 320 and 128 x 128 tiles it gained nothing)
+                m["vocab_t_ps"] = ops.presplit_buffer(d, V, dev)
+                ops.presplit_weights([(_p(dec.fc_vocab.weight).t(), m["vocab_t_ps"])])
 
     def entity_chain():
         ops.stamp("side: context chain starts")

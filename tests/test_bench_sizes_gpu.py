@@ -175,9 +175,10 @@ def test_cfg2_train_step_vs_oracle(plan_log, gemm_split):
     assert vocab_fwd[0]["tile_m"] >= 64 and vocab_fwd[0]["vec"] == 1      # large tiles above 512 workgroups
     assert vocab_dgrad[0]["split_k"] >= 2                                  # long reduction split over workgroups
     assert vocab_fwd[0]["split_bf16"] == (1 if gemm_split else 0)          # the product mode under test really ran
-    assert vocab_dgrad[0]["split_bf16"] == (1 if gemm_split == 2 else 0)   # k-major B operand: only in mode 2
-    if gemm_split:      # the forward GEMMs multiply with the pre-split weight copies (csrc/gemm_ps.hip)
+    assert vocab_dgrad[0]["split_bf16"] == (1 if gemm_split else 0)
+    if gemm_split:      # forward and data gradient multiply with pre-split weight copies (csrc/gemm_ps.hip: W, W^T)
         assert vocab_fwd[0]["presplit"] == 1 and (vocab_fwd[0]["tile_m"], vocab_fwd[0]["tile_n"]) == (128, 128)
+        assert vocab_dgrad[0]["presplit"] == 1 and (vocab_dgrad[0]["tile_m"], vocab_dgrad[0]["tile_n"]) == (128, 80)
     kv = plans_of(log, B * 196, 1800, 300)
     assert kv and kv[0]["tile_m"] >= 64
     assert (V + K) % 4 == 0 and V + K <= 10240      # => packed CE keeps these rows in registers (score_head.hip)

@@ -227,7 +227,7 @@ def test_presplit_copy_is_the_exact_three_way_split(ops, N, K, transposed):
 
 @pytest.mark.parametrize("M,N,K,akm,grp,split_k,tile", [
     (12544, 300, 2048, True, 196, 1, (128, 80)),      # Encoder.conv1: k-major NCHW map, 196 positions per sample
-    (1280, 300, 10000, False, 0, 12, (128, 128)),      # vocabulary data gradient: split K, atomics
+    (1280, 300, 10000, False, 0, 12, (128, 80)),      # vocabulary data gradient: split K, atomics
     (1280, 10000, 300, False, 0, 1, (128, 128)),      # vocabulary projection (K tail of 12)
     (12544, 1800, 300, False, 0, 1, (128, 128)),      # cross K/V projection of the image rows
     (23044, 132, 516, False, 0, 1, (128, 80)),        # ragged: M tail, N < 320 (pieces beyond the padded rows), K tail of 4
