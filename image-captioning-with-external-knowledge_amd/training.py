@@ -318,6 +318,17 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         if side is not None:
             side.signal("ctx")      # the first cross-attention waits for this point, not for the packing / zeroing below
         ops.stamp("side: context chain done")
+        if not tail_on_main:
+            bulk_tail()
+
+    # Bulk work nothing waits for before the score head / the backward pass: the transposed packed copies of the backward
+    # chains, fc_vocab's pre-split copies, the zero fills.  ICK_TAIL_ON_MAIN=1 (experiment, measured and left off: train
+    # step 1.764 -> 1.817 ms): on the main stream between Encoder.conv1 and the image K/V projection instead of on the
+    # side stream behind the context chain -- there they delay the K/V projection, and the decoder's first
+    # cross-attention waits for that as much as for the context chain.
+    tail_on_main = side is not None and staged and bool(os.environ.get("ICK_TAIL_ON_MAIN"))
+
+    def bulk_tail():
         if staged and dec.chain_bwd_supported():
             m["pkb"] = dec._chain_pack(fresh=True, bwd=True, extra=[(("kv", "T"), wkv.t())])
         vocab_presplit()
@@ -371,6 +382,8 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         early.flush()
     if staged:
         dec._chain_pack(fresh=True, subset=lambda k: not first(k))
+        if tail_on_main:
+            bulk_tail()
     elif pk is not None and dec.chain_bwd_supported():
         m["pkb"] = dec._chain_pack(fresh=fresh_pack, bwd=True, extra=[(("kv", "T"), wkv.t())])
     if dec.has_facts:
