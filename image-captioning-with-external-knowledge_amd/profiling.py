@@ -51,12 +51,16 @@ def classify(name, args):
         return "chain GEMMs (< 2 GFLOP each: projections, FFN, their data gradients)", fl, "flop"
     if name == "ick_gemm_grouped":
         arr, n = args[0], args[1]
-        fl = 0.0
+        fl = fl_split = 0.0
         for i in range(n):
             a = arr[i]
             if not (a.flags & L.GEMM_COLSUM_ONLY):
-                fl += 2.0 * a.M * a.N * a.K
-        return "grouped weight-gradient GEMMs", fl, "flop"
+                f = 2.0 * a.M * a.N * a.K
+                fl += f
+                if _split_plan(a)[0]:
+                    fl_split += f        # this problem's products run on the bf16 pipe (six MFMAs per product block)
+        # a mixed launch is priced against the time its parts would take at their own pipes' peaks ("flop_mixed")
+        return "grouped weight-gradient GEMMs", fl, "flop_mixed", fl_split
     if name == "ick_attention":
         a = _struct(args[0])
         return "attention forward (T=%d)" % a.T if a.T > 1 else "attention decode step", 4.0 * a.B * a.H * a.T * a.S * a.dh, "flop"
@@ -114,12 +118,12 @@ class _Profiled:
             return fn
 
         def timed(*args):
-            label, work, unit = classify(name, args)
+            label, work, unit, *rest = classify(name, args)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             rc = fn(*args)
             e1.record()
-            L.PROFILE.append((label, work, unit, e0, e1))
+            L.PROFILE.append((label, work, unit, e0, e1, rest[0] if rest else 0.0))
             return rc
         return timed
 
@@ -138,23 +142,30 @@ def stop():
 def summarise(records, steps):
     torch.cuda.synchronize()
     rows = {}
-    for label, work, unit, e0, e1 in records:
-        r = rows.setdefault(label, {"name": label, "launches": 0, "us": 0.0, "work": 0.0, "unit": unit})
+    for label, work, unit, e0, e1, work_split in records:
+        r = rows.setdefault(label, {"name": label, "launches": 0, "us": 0.0, "work": 0.0, "unit": unit, "work_split": 0.0})
         r["launches"] += 1
         r["us"] += e0.elapsed_time(e1) * 1e3
         if work is not None:
             r["work"] += work
+            r["work_split"] += work_split
     out = []
     for r in rows.values():
         n = r["launches"]
         row = {"name": r["name"], "launches_per_step": n / steps, "avg_us": r["us"] / n, "us_per_step": r["us"] / steps}
-        if r["unit"] in ("flop", "flop_split") and r["us"] > 0:
+        if r["unit"] in ("flop", "flop_split", "flop_mixed") and r["us"] > 0 and r["work"] > 0:
             ach = r["work"] / (r["us"] * 1e-6) / 1e12
-            peak = PEAK_SPLIT_FP32_EQ_TFLOPS if r["unit"] == "flop_split" else PEAK_FP32_MFMA_TFLOPS
+            if r["unit"] == "flop_mixed":
+                # problems of both pipes in one launch: the peak is the rate at which the launch's parts would finish
+                # at their own pipes' peaks, one after the other
+                ws = r["work_split"]
+                peak = r["work"] / (ws / PEAK_SPLIT_FP32_EQ_TFLOPS + (r["work"] - ws) / PEAK_FP32_MFMA_TFLOPS)
+                pipe = "%.0f %% of the FLOP on the bf16 MFMA x 6 partial products, the rest on the fp32 MFMA" % (100 * ws / r["work"])
+            else:
+                peak = PEAK_SPLIT_FP32_EQ_TFLOPS if r["unit"] == "flop_split" else PEAK_FP32_MFMA_TFLOPS
+                pipe = "bf16 MFMA x 6 partial products (fp32-equivalent FLOP)" if r["unit"] == "flop_split" else "fp32 MFMA"
             row.update(work_per_launch=r["work"] / n, unit="TFLOP/s", achieved=ach, peak=peak, frac=ach / peak, bound="mfma",
-                       pipe="bf16 MFMA x 6 partial products (fp32-equivalent FLOP)" if r["unit"] == "flop_split"
-                       else "fp32 MFMA",
-                       frac_of_fp32_mfma_peak=ach / PEAK_FP32_MFMA_TFLOPS)
+                       pipe=pipe, frac_of_fp32_mfma_peak=ach / PEAK_FP32_MFMA_TFLOPS)
         elif r["unit"] == "byte" and r["us"] > 0:
             ach = r["work"] / (r["us"] * 1e-6) / 1e9
             row.update(work_per_launch=r["work"] / n, unit="GB/s", achieved=ach, peak=PEAK_HBM_GBS,

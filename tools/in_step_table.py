@@ -19,7 +19,11 @@ def main(d, steps, out):
     other = 0.0
     once = collections.Counter()                     # kernels the step launches exactly once: their count IS the step count
     for r in csv.DictReader(open(f)):
-        key = classify(r["Kernel_Name"], r.get("Grid_Size_X") or r.get("Grid_Size"))
+        if r.get("Grid_Size_X"):
+            grid = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y") or 1) * int(r.get("Grid_Size_Z") or 1)
+        else:
+            grid = r.get("Grid_Size")
+        key = classify(r["Kernel_Name"], grid)
         us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         if key in ("adam", "vocab_ps"):
             once[key] += 1

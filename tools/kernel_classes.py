@@ -21,6 +21,7 @@ CLASSES = {
     "vocab_ps": "GEMM 1280x10000x300 (A row-major, B row-major)" + PS,
     "conv1": "GEMM 12544x300x2048 (A k-major, B row-major)",
     "vocab_dgrad": "GEMM 1280x300x10000 (A row-major, B k-major, split-K 9)",
+    "vocab_dgrad_ps": "GEMM 1280x300x10000 (A row-major, B k-major, split-K 12)" + PS,
     "decode": "fused decode step (3 kernels / layer + head + vocabulary)",
 }
 
@@ -31,7 +32,7 @@ def _targs(name, kernel):
 
 
 def classify(name, grid_x=None):
-    """-> key of CLASSES or None."""
+    """-> key of CLASSES or None.  grid_x: total threads of the launch (x * y * z)."""
     if "gemm_group_kernel" in name:
         return "wgrad"
     if "rowchain_fwd_kernel" in name:
@@ -50,14 +51,16 @@ def classify(name, grid_x=None):
         return "pack"
     if "presplit_kernel" in name:
         return "presplit"
-    if re.search(r"dec_(self|cross|ffn|head|vocab)_kernel", name):
+    if re.search(r"dec_(self|cross|ffn|head|vocab|headvocab)_kernel", name):
         return "decode"
     t = _targs(name, "gemm_ps_kernel")
     if t:
-        g = int(grid_x) if grid_x else 0
-        if t[4] == "true":                        # A k-major: conv1 (196 tiles of 512 threads) or a split-K weight gradient
-            return "conv1_ps" if g == 100352 else "wgrad"
-        return {752640: "kv_ps", 404480: "vocab_ps"}.get(g)
+        g = int(grid_x) if grid_x else 0              # TOTAL threads of the grid (x * y * z)
+        if t[4] == "true":                            # A k-major: Encoder.conv1 (392 tiles of 128 x 80) or a weight gradient
+            return "conv1_ps" if g in (200704, 100352) else "wgrad"
+        # A row-major: K/V projection (98 x 15 tiles of 128 x 128), vocabulary (10 x 79), its data gradient (40 tiles of
+        # 128 x 80 x 12 K slices)
+        return {752640: "kv_ps", 404480: "vocab_ps", 245760: "vocab_dgrad_ps"}.get(g)
     t = _targs(name, "gemm_kernel")
     if t:
         if t[4] == "true" and t[5] == "true":

@@ -32,10 +32,13 @@ def main(out, dirs):
     for i in range(0, len(dirs), 2):
         rd, wr = load(dirs[i], "FETCH_SIZE"), load(dirs[i + 1], "WRITE_SIZE")
         agg = collections.OrderedDict()
+        tokens = 0                                    # decode steps = launches of the vocabulary kernel
         for (k, g, did), v in rd.items():
             key = classify(k, g)
             if key is None:
                 continue
+            if "dec_vocab_kernel" in k or "dec_headvocab_kernel" in k:
+                tokens += 1
             a = agg.setdefault(key, [0, 0.0, 0.0])
             a[0] += 1
             a[1] += 2.0 * v * 1024
@@ -46,7 +49,7 @@ def main(out, dirs):
         for key, (n, r, w) in agg.items():
             per = (r + w) / n
             if key == "decode":
-                per *= 11            # launches of one token step (3 x (self, cross, ffn) + head + vocabulary)
+                per = (r + w) / max(tokens, 1)        # all launches of one token step
             if CLASSES[key] in table:          # a later mode (greedy's prefill) does not overwrite the train step's classes
                 continue
             table[CLASSES[key]] = per
