@@ -78,6 +78,10 @@ def classify(name, args):
     if name == "ick_pack_weights":
         arr, n = args[0], args[1]
         return "packed weight copies", 8.0 * sum(arr[i].N * arr[i].K for i in range(n)), "byte"
+    if name == "ick_presplit_weights":
+        arr, n = args[0], args[1]
+        # 4 bytes read, three bf16 planes (6 bytes) written per element
+        return "presplit weights", 10.0 * sum(arr[i].N * arr[i].K for i in range(n)), "byte"
     if name == "ick_add_layernorm":
         rows, d = args[5], args[6]
         return "residual + LayerNorm", 4.0 * rows * d * 3, "byte"
