@@ -42,11 +42,15 @@ def evaluate(encoder, decoder, loader, word_map, max_caption_len=30, out_csv="ge
     encoder.eval()
     rev = {v: k for k, v in word_map.items()}
     captions, sequences = [], []
+    # precomputed feature maps go to predict() as they are: Encoder.conv1 then runs inside the captured decode graph
+    # beside the context encoders (decoder.attach_encoder); raw images go through the encoder's trunk first
+    decoder.attach_encoder(encoder)
     for batch in loader:                                      # any batch size: captions decode independently
         image, ent, names = batch[0].to(device), batch[4], batch[5]
         has_facts = len(batch) > 6
         extra = (batch[6].to(device),) if has_facts else ()
-        seq = decoder.predict(encoder(image), max_caption_len, ent, *extra)   # (max_len, B)
+        feature_map = image.dim() == 4 and image.shape[1] == encoder.encoder_dim
+        seq = decoder.predict(image if feature_map else encoder(image), max_caption_len, ent, *extra)   # (max_len, B)
         for b in range(seq.shape[1]):
             ids = seq[:, b].tolist()
             sequences.append(ids)
