@@ -13,6 +13,8 @@
 // Same machinery as the forward chain: 8 rows per workgroup, 16 waves, v_mfma_f32_4x4x1 with broadcast A, packed
 // copies of the TRANSPOSED weights streamed straight into the MFMA operand, K-split partials summed in a fixed order
 // through LDS, LayerNorm backward one wave per row with the arithmetic of layernorm_bwd_kernel (backward.hip).
+#include <cstdlib>
+
 #include "rowchain.h"
 
 namespace ick {
@@ -22,7 +24,14 @@ using namespace rowchain;
 
 constexpr int kMaxK0 = 1920;                // widest pre-GEMM input (in_proj gradient: 3 d; all-layer cross K/V gradient:
                                             // 2 * layers * d = 1800)
-constexpr int kLdA = kMaxK0 + 4;            // LDS row stride of the wide input buffer
+// LDS row stride of the wide input buffer XA, sized by the launch (round 4: a fixed 1924-float stride made every launch
+// declare 136 KB, so a workgroup of this latency-bound kernel only found room on a CU that held nothing of the other
+// stream's weight-gradient kernels): the widest row it holds -- K0 padded to 16, or the FFN's hidden width padded to
+// 64-column slabs -- rounded up to 32 floats, + 4 (the same bank offset between rows as before).
+__host__ __device__ __forceinline__ int lda_for(int K0, int N1) {
+    const int w = max(max((K0 + 15) & ~15, ((N1 + 63) / 64) * 64), 64);
+    return ((w + 31) & ~31) + 4;
+}
 constexpr int kLdB = kMaxD + 4;             // ... of the d-wide buffers
 constexpr int kMaxN1 = 512;                 // dim_feedforward
 
@@ -78,6 +87,7 @@ __device__ __forceinline__ void ln_bwd_row(const LnIn& q, const float (&dx)[5], 
 __global__ __launch_bounds__(kThreads) void rowchain_bwd_kernel(ick_rowchain_bwd_args p) {
     chain_priority_bwd();
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int kLdA = lda_for(p.g0 != nullptr ? p.K0 : 0, p.w1p != nullptr ? p.N1 : 0);      // uniform
     float* XA = smem;                          // [8][kLdA]  wide GEMM input: g0 rows, later t
     float* XB = XA + kRows * kLdA;             // [8][kLdB]  d-wide GEMM input: do1 / do2
     float* DZ = XB + kRows * kLdB;             // [8][kLdB]  residual-path gradient between the two norms
@@ -313,7 +323,10 @@ __global__ __launch_bounds__(kThreads) void rowchain_bwd_kernel(ick_rowchain_bwd
         if (row0 + i < M) p.out3[(int64_t)(row0 + i) * d + col] = y[i];
 }
 
-constexpr size_t kBwdSmem = (size_t)(kRows * kLdA + 2 * kRows * kLdB + kRows * 2 * kLdB + kPartFloats) * sizeof(float);
+constexpr size_t kBwdSmemMax = (size_t)(kRows * (kMaxK0 + 4) + 2 * kRows * kLdB + kRows * 2 * kLdB + kPartFloats) * sizeof(float);
+inline size_t bwd_smem(int lda) {
+    return (size_t)(kRows * lda + 2 * kRows * kLdB + kRows * 2 * kLdB + kPartFloats) * sizeof(float);
+}
 
 }  // namespace
 }  // namespace ick
@@ -339,10 +352,12 @@ extern "C" int ick_rowchain_bwd(const ick_rowchain_bwd_args* in, void* stream) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowchain_bwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdSmem);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdSmemMax);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(rowchain_bwd_kernel, dim3(ceil_div(a.M, kRows)), dim3(kThreads), kBwdSmem, (hipStream_t)stream, a);
+    static const bool declare_max = getenv("ICK_CHAIN_BWD_LDS_MAX") != nullptr;     // A/B: the 136 KB of rounds 2-3
+    const size_t smem = declare_max ? kBwdSmemMax : bwd_smem(lda_for(a.g0 != nullptr ? a.K0 : 0, a.w1p != nullptr ? a.N1 : 0));
+    hipLaunchKernelGGL(rowchain_bwd_kernel, dim3(ceil_div(a.M, kRows)), dim3(kThreads), smem, (hipStream_t)stream, a);
     ICK_LAUNCH_RET();
 }
