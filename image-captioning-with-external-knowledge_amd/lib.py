@@ -68,7 +68,7 @@ class RowChainBwdArgs(C.Structure):
         ("o2", vp), ("res2", vp), ("mean2", vp), ("rstd2", vp), ("gamma2", vp),
         ("drop2_p", f32), ("drop2_site", u32),
         ("do2", vp), ("part2", vp),
-        ("w3p", vp), ("out3", vp), ("dz_out", vp),
+        ("w3p", vp), ("out3", vp), ("dz_out", vp), ("flags", i32),
     ]
 
 

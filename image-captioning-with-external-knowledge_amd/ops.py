@@ -359,14 +359,21 @@ def ln_partials(rows, d, device):
     return torch.empty((rows + rpb - 1) // rpb, 2 * d, device=device, dtype=torch.float32)
 
 
-def rowchain_bwd(M, d, norm1, w3p, out3, dz_out, g0=None, w0p=None, dzin=None, ffn=None, norm2=None):
+def rowchain_bwd(M, d, norm1, w3p, out3, dz_out, g0=None, w0p=None, dzin=None, ffn=None, norm2=None, slim=None):
     """One launch for the data-gradient path between two attention-backward kernels (include/ick_amd.h,
     ick_rowchain_bwd).  norm1 / norm2 = dict(o, res, mean, rstd, gamma, drop, do, part): saved forward tensors of an
     add & norm, its dropout triple, and the outputs do (M, d) / part (ln_partials).  ffn = dict(w1p, w2p, act,
     gate_scale, t_out) with packed linear2.weight.T / linear1.weight.T.  g0 (M, K0) @ W0 (packed W0.T = w0p) and dzin
-    (M, d) are the two addends of the incoming gradient."""
+    (M, d) are the two addends of the incoming gradient.  slim: the 8-wave form (ICK_CHAIN_SLIM, same bits; default off,
+    ICK_SLIM_BWD=1 turns it on).  Built in round 4 on the observation that the 16-wave kernel takes 480 of a SIMD's 512
+    registers, so its workgroups only start on CUs that hold nothing of the other stream -- and measured slower inside the
+    step all the same: 1.746 against 1.700 ms (profiles/r04_y_ab_slim_bwd.txt); two units per wave, every partial tile
+    through LDS, cost more than the earlier start gains."""
     a = L.RowChainBwdArgs()
     a.M, a.d = M, d
+    if slim is None:
+        slim = os.environ.get("ICK_SLIM_BWD", "0") not in ("", "0")
+    a.flags = 256 if slim else 0
     seeds = []
 
     def norm(prefix, n):

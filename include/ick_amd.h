@@ -208,6 +208,7 @@ typedef struct {
     float* do2; float* part2;
     const float* w3p; float* out3;
     float* dz_out;
+    int32_t flags;                     /* ICK_CHAIN_SLIM: the 8-wave form (same bits), for launches beside another stream's kernels */
 } ick_rowchain_bwd_args;
 int ick_rowchain_bwd_supported(int32_t K0, int32_t d, int32_t N1);
 int ick_rowchain_bwd(const ick_rowchain_bwd_args* args, void* stream);
