@@ -277,13 +277,21 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         pk = dec._chain_pack(fresh=fresh_pack, subset=first if staged else None, copies=copies) if chain else None
         # pre-split copy (three bf16 planes) of the all-layer cross K/V weight for the image rows' projection (ick_gemm's
         # b_ps, csrc/gemm_ps.hip); fc_vocab's copy is made on the side stream behind the context chain (vocab_presplit)
+        if not late_kv_presplit:
+            kv_presplit(wkv)
+        return ee, fe, wkv, bkv, pk
+
+    # with a side stream the context chain (the longest dependency of the first phase) forks behind head(): the K/V
+    # weight's pre-split copy, which only the main stream's projection reads, is made behind the fork (5 us earlier start)
+    late_kv_presplit = side is not None and not head_on_side and not os.environ.get("ICK_EARLY_KV_PRESPLIT")
+
+    def kv_presplit(wkv):
         if ops.gemm_split_mode() >= 1 and not ops.is_deterministic():
             if fresh_pack:
                 m["wkv_ps"] = ops.presplit_buffer(nseg * d, d, dev)
                 ops.presplit_weights([(wkv, m["wkv_ps"])])
             else:
                 m["wkv_ps"] = dec._cross_kv_presplit(wkv)
-        return ee, fe, wkv, bkv, pk
 
     if head_on_side:
         with side.fork(after=ev0):
@@ -376,6 +384,8 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         mem[:, :P].copy_(img)
     if side is not None:
         side.flush()     # enqueued after the main stream's next kernel (see SideStream)
+    if late_kv_presplit:
+        kv_presplit(wkv)
     if head_on_side:
         side.wait("head")    # the main stream needs the packed K/V weight, the entity rows and the first copies from here on
     if early is not None:
