@@ -398,6 +398,14 @@ class DecoderTransformer(nn.Module):
             wkv.data_ptr(), self.__dict__.get("_param_epoch", 0))
         return ops.presplit_cached(self, "wkv", wkv, key)
 
+    def _cross_kv_presplit_parts(self, wkv):
+        """The same in two copies: layer 0's rows and the later layers' (ICK_KV_SPLIT_LAYERS: two projections)."""
+        d = self.emb_dim
+        layers = self.transformer_decoder.layers
+        key = tuple(l.multihead_attn.in_proj_weight._version for l in layers) + (
+            wkv.data_ptr(), self.__dict__.get("_param_epoch", 0))
+        return (ops.presplit_cached(self, "wkv_l0", wkv[:2 * d], key), ops.presplit_cached(self, "wkv_rest", wkv[2 * d:], key))
+
     def _vocab_presplit(self):
         w = self.fc_vocab.weight
         return ops.presplit_cached(self, "vocab", w.detach(), (w._version, w.data_ptr(), self.__dict__.get("_param_epoch", 0)))
@@ -590,6 +598,14 @@ class DecoderTransformer(nn.Module):
         # side stream before the first cross-attention (`side.join()`).
         side = ops.SideStream(priority=-1)
         ctx = [None, None]
+        # ICK_KV_SPLIT_LAYERS=1 (experiment, measured and left off: cfg2 forward 0.695 -> 0.826 ms): only layer 0's K/V of
+        # the image rows is projected in front of the decoder; the later layers' (two thirds of the GEMM) follow on the
+        # side stream behind the context chain, beside layer 0.  Same scores (tools/debug/kvsplit_check.py), but with a
+        # second fork / join pair in the captured graph the runtime starts the context chain only after conv1 and the
+        # first projection (device stamps: 222 us instead of 18) -- the hipGraph executor serialises the branches
+        split_kv = bool(os.environ.get("ICK_KV_SPLIT_LAYERS")) and nseg > 2 and not self.has_facts and gmap is None
+        side.split_kv = split_kv
+        wkv_parts = self._cross_kv_presplit_parts(wkv) if split_kv else None
 
         def entity_chain():
             ops.stamp("side: context chain starts")
@@ -598,6 +614,7 @@ class DecoderTransformer(nn.Module):
             ctx[0] = self._context_encoder(self.transformer_encoder_entities, ee,
                                            slim=os.environ.get("ICK_SLIM_INFER", "1") != "0")
             ops.project_heads(ctx[0], wkv, bkv, nseg, H, S, out=kv, s0=P, grp=K)
+            side.signal("ctx")
             ops.stamp("side: context chain done")
 
         def fact_chain():
@@ -627,8 +644,18 @@ class DecoderTransformer(nn.Module):
             if feats is not None:
                 conv1()
                 side.flush()       # the context chain starts beside Encoder.conv1
-            ops.project_heads(enc_tok, wkv, bkv, nseg, H, S, out=kv, s0=0, grp=P, a_gmap=gmap, a_gs=enc_tok.stride(0),
-                              w_ps=wkv_ps)
+            if split_kv:
+                ops.project_heads(enc_tok, wkv[:2 * d], bkv[:2 * d], 2, H, S, out=kv[:, :2], s0=0, grp=P, w_ps=wkv_parts[0])
+
+                def later_layers():
+                    ops.project_heads(enc_tok, wkv[2 * d:], bkv[2 * d:], nseg - 2, H, S, out=kv[:, 2:], s0=0, grp=P,
+                                      w_ps=wkv_parts[1])
+                    ops.stamp("side: K/V of the later layers done")
+
+                side.submit(later_layers, enc_tok, kv, wkv, bkv)
+            else:
+                ops.project_heads(enc_tok, wkv, bkv, nseg, H, S, out=kv, s0=0, grp=P, a_gmap=gmap, a_gs=enc_tok.stride(0),
+                                  w_ps=wkv_ps)
             side.flush()
         ops.stamp("main: image K/V projection done")
         ctx_e, ctx_f = ctx
@@ -663,7 +690,12 @@ class DecoderTransformer(nn.Module):
                              heads=(1, H, T, 0, T))
             ca = torch.empty_like(x)
             if side is not None:
-                side.join()    # entity / fact rows of kv come from the side stream
+                # entity / fact rows of kv come from the side stream (split K/V: layer 0 waits for the context chain only,
+                # layer 1 for the later layers' image rows)
+                if getattr(side, "split_kv", False) and li == 0:
+                    side.wait_or_join("ctx")
+                else:
+                    side.join()
             ops.attention_heads(q, kv, ca, H, dh, T, S, q_seg=0, k_seg=2 * li, v_seg=2 * li + 1)
             x2 = torch.empty_like(x)
             f = torch.empty(B, T, layer.linear1.out_features, device=x.device, dtype=torch.float32)
@@ -777,7 +809,8 @@ class DecoderTransformer(nn.Module):
         S = kv.shape[3]
         qkv = None
         for li, layer in enumerate(self.transformer_decoder.layers):
-            x, qkv = self._decoder_layer(li, layer, x, kv, S, side=side if li == 0 else None, qkv=qkv, want_next=True)
+            x, qkv = self._decoder_layer(li, layer, x, kv, S, qkv=qkv, want_next=True,
+                                         side=side if (li == 0 or (li == 1 and getattr(side, "split_kv", False))) else None)
             ops.stamp("main: decoder layer %d done" % li)
         side.join()
         eib = gate = None
