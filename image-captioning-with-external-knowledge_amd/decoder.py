@@ -561,11 +561,12 @@ class DecoderTransformer(nn.Module):
                 x = out
         return x
 
-    def _encode_context(self, enc_tok, entities, facts, gmap):
+    def _encode_context(self, enc_tok, entities, facts, gmap, side_first=None):
         """Entity / fact encoders, context transformers and the all-layer cross K/V projection.
         Returns (entities_encoded, facts_encoded, kv, contexts); kv is head-major
         (B, 2*layers, H, S, 32): segment 2i = keys of decoder layer i, 2i+1 = its values, over the
-        memory rows [196 image positions ; entity rows ; fact rows]."""
+        memory rows [196 image positions ; entity rows ; fact rows].
+        side_first(ee, fe, side): optional work for the head of the side stream, in front of the context chain."""
         d = self.emb_dim
         H = self.num_heads
         feats = None
@@ -608,6 +609,8 @@ class DecoderTransformer(nn.Module):
         wkv_parts = self._cross_kv_presplit_parts(wkv) if split_kv else None
 
         def entity_chain():
+            if side_first is not None:
+                side_first(ee, fe, side)
             ops.stamp("side: context chain starts")
             # beside Encoder.conv1 / the image K/V projection: the 8-wave form finds room on a CU that hosts bulk GEMM
             # workgroups (as in the training step; ICK_SLIM_INFER=0 for A/B)
@@ -802,12 +805,37 @@ class DecoderTransformer(nn.Module):
         d, V = self.emb_dim, self.vocab_size
         K = entities.shape[1]
         ops.stamp("forward: start")
-        ee, fe, kv, ctx, side = self._encode_context(enc_tok, entities, facts, gmap)
         pe = self.pos_encoder.pe.view(-1, d)
-        x, emb = ops.caption_embed(captions, caption_masks, self.word_embedding.weight.detach(), ee, fe, pe, V,
-                                   self.word_map["<pad>"], math.sqrt(d), want_emb=True)
+        head = {}
+
+        def embed(ee, fe):
+            return ops.caption_embed(captions, caption_masks, self.word_embedding.weight.detach(), ee, fe, pe, V,
+                                     self.word_map["<pad>"], math.sqrt(d), want_emb=True)
+
+        def first_in_proj(ee, fe, side):
+            # ICK_EARLY_IN_PROJ=1 (experiment, measured and left off: cfg2 forward 0.694 -> 0.715 ms).  Decoder layer 0's
+            # caption embedding and self-attention in_proj read neither the image nor the context rows; at the head of the
+            # SIDE stream they were meant to balance the two branches of the first phase.  They delay the context chain by
+            # 40 us instead (its 340 us beside the bulk GEMMs do not shrink), and that chain is what the first
+            # cross-attention waits for.
+            l0 = self.transformer_decoder.layers[0]
+            head["x"], head["emb"] = embed(ee, fe)
+            head["qkv"] = ops.project_heads(head["x"], l0.self_attn.in_proj_weight.detach(),
+                                            l0.self_attn.in_proj_bias.detach(), 3, self.num_heads, captions.shape[1])
+            side.signal("qkv0")
+
+        # (captured graphs only: there every tensor lives in the graph's own pool, whichever stream allocated it)
+        early = self.chain_supported() and gmap is None and not self.has_facts and stages is None and \
+            torch.cuda.is_current_stream_capturing() and bool(os.environ.get("ICK_EARLY_IN_PROJ"))
+        ee, fe, kv, ctx, side = self._encode_context(enc_tok, entities, facts, gmap,
+                                                     side_first=first_in_proj if early else None)
+        if early:
+            side.wait("qkv0")
+            x, emb, qkv = head["x"], head["emb"], head["qkv"]
+        else:
+            x, emb = embed(ee, fe)
+            qkv = None
         S = kv.shape[3]
-        qkv = None
         for li, layer in enumerate(self.transformer_decoder.layers):
             x, qkv = self._decoder_layer(li, layer, x, kv, S, qkv=qkv, want_next=True,
                                          side=side if (li == 0 or (li == 1 and getattr(side, "split_kv", False))) else None)
