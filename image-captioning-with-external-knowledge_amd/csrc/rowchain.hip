@@ -65,8 +65,12 @@ __global__ __launch_bounds__(NW * 64) void rowchain_fwd_kernel(ick_rowchain_args
     // every thread costs 16 cycles of the CU, a 32-bit division ~40 of them.
     ICK_CSTAMP(0);
     const uint32_t seed = p.drop_epoch ? p.drop_seed + *p.drop_epoch : p.drop_seed;
+    // ICK_CHAIN_PROJ: projection only -- y2 = act(A W2^T + b2) with A (M, d) as the rows GEMM 2 multiplies: the first
+    // in_proj of a stack as a 160-workgroup priority launch instead of a 1 160-workgroup generic GEMM that queues behind
+    // the bulk kernels of the other stream
+    const bool proj = (p.flags & ICK_CHAIN_PROJ) != 0;       // uniform
     // ---- the residual row, gamma / beta / bias of the LayerNorm wave: issued first, consumed after GEMM 1
-    const bool ln_wave = wave < kRows;
+    const bool ln_wave = wave < kRows && !proj;
     const int lrow = row0 + wave;
     const bool lrow_ok = ln_wave && lrow < M;
     float rres[5], rg[5], rb[5], rbias[5];
@@ -82,9 +86,9 @@ __global__ __launch_bounds__(NW * 64) void rowchain_fwd_kernel(ick_rowchain_args
     ICK_CSTAMP(1);
     const int K1 = p.K1, K1p = (K1 + 15) & ~15;
     const GemmPlan g1 = plan_for(d, K1);
-    const int units1 = g1.nslab * g1.splits;
+    const int units1 = proj ? 0 : g1.nslab * g1.splits;
     RowGemm mm;
-    mm.begin(K1, p.w1p, g1, unit_of(g1, wave));       // weights of GEMM 1 start streaming before the rows arrive
+    if (!proj) mm.begin(K1, p.w1p, g1, unit_of(g1, wave));       // weights of GEMM 1 start streaming before the rows arrive
     // ---- A rows -> LDS (zero beyond K1 up to the next multiple of 16, zero rows beyond M): wave = (row, part)
     {
         const int r = wave & (kRows - 1), part = wave >> 3;
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(NW * 64) void rowchain_fwd_kernel(ick_rowchain_args
         for (int k = lane + 64 * part; k < K1p; k += 8 * NW) Xs[r * kLdx + k] = (gr < M && k < K1) ? arow[k] : 0.f;
     }
     ICK_CSTAMP(2);
-    __syncthreads();
+    if (!proj) __syncthreads();      // (projection only: the barrier in front of GEMM 2 below covers the rows)
     ICK_CSTAMP(3);
     for (int u = wave; u < units1; u += NW) {
         const Slab w = unit_of(g1, u);
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(NW * 64) void rowchain_fwd_kernel(ick_rowchain_args
         }
     }
     ICK_CSTAMP(4);
-    __syncthreads();
+    if (!proj) __syncthreads();
     ICK_CSTAMP(5);
     const int N2 = p.N2;
     const GemmPlan g2 = plan_for(max(N2, 1), d);
@@ -329,7 +333,8 @@ extern "C" int ick_rowchain_fwd(const ick_rowchain_args* in, void* stream) {
     using namespace ick;
     if (!in) return ICK_EINVAL;
     const ick_rowchain_args& a = *in;
-    ICK_CHECK_ARG(a.A && a.w1p && a.gamma && a.beta && a.x);
+    if (a.flags & ICK_CHAIN_PROJ) ICK_CHECK_ARG(a.A && a.w2p && a.y2 && a.K1 == a.d);
+    else ICK_CHECK_ARG(a.A && a.w1p && a.gamma && a.beta && a.x);
     ICK_CHECK_ARG(a.M > 0 && ick_rowchain_supported(a.K1, a.d, a.w2p ? a.N2 : 0));
     ICK_CHECK_ARG((a.mean == nullptr) == (a.rstd == nullptr));
     if (a.w2p) {

@@ -421,8 +421,8 @@ class DecoderTransformer(nn.Module):
             items += [(("d", li, "so"), layer.self_attn.out_proj.weight), (("d", li, "cq"), layer.multihead_attn.in_proj_weight[:d]),
                       (("d", li, "co"), layer.multihead_attn.out_proj.weight), (("d", li, "l1"), layer.linear1.weight),
                       (("d", li, "l2"), layer.linear2.weight)]
-            if li > 0:
-                items.append((("d", li, "si"), layer.self_attn.in_proj_weight))
+            if li > 0 or ops.chain_proj_on():
+                items.append((("d", li, "si"), layer.self_attn.in_proj_weight))     # layer 0: ops.chain_project_heads
         stacks = [("e", self.transformer_encoder_entities)]
         if self.has_facts:
             stacks.append(("f", self.transformer_encoder_facts))
@@ -430,7 +430,7 @@ class DecoderTransformer(nn.Module):
             for li, layer in enumerate(stack.layers):
                 items += [((tag, li, "so"), layer.self_attn.out_proj.weight), ((tag, li, "l1"), layer.linear1.weight),
                           ((tag, li, "l2"), layer.linear2.weight)]
-                if li > 0:
+                if li > 0 or ops.chain_proj_on():
                     items.append(((tag, li, "si"), layer.self_attn.in_proj_weight))
         return items
 
@@ -527,7 +527,9 @@ class DecoderTransformer(nn.Module):
         n = len(stack.layers)
         qkv = None
         for li, layer in enumerate(stack.layers):
-            if qkv is None:
+            if qkv is None and chain and ops.chain_proj_on():
+                qkv = ops.chain_project_heads(x, pk[(tag, li, "si")], layer.self_attn.in_proj_bias.detach(), 3, H, T, slim=slim)
+            elif qkv is None:
                 qkv = ops.project_heads(x, layer.self_attn.in_proj_weight.detach(), layer.self_attn.in_proj_bias.detach(),
                                         3, H, T)
             sa = torch.empty_like(x)
@@ -676,7 +678,9 @@ class DecoderTransformer(nn.Module):
         sa = torch.empty_like(x)
         chain = qkv_buf is None and self.chain_supported()
         if qkv_buf is None:
-            if qkv is None:
+            if qkv is None and chain and ops.chain_proj_on():
+                qkv = ops.chain_project_heads(x, self._chain_pack()[("d", li, "si")], sa_b, 3, H, T)
+            elif qkv is None:
                 qkv = ops.project_heads(x, sa_w, sa_b, 3, H, T)
             ops.attention_heads(qkv, qkv, sa, H, dh, T, T, q_seg=0, k_seg=1, v_seg=2, causal=True)
         else:

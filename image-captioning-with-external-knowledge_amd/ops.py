@@ -349,6 +349,34 @@ def rowchain_fwd(a, w1p, b1, res, gamma, beta, eps, x_out, drop1=None, o_out=Non
     return (mean, rstd) if save_stats else None
 
 
+def chain_proj_on():
+    """ICK_CHAIN_PROJ=1 (experiment, measured and left off: cfg2 forward 0.728 -> 0.745 ms, train 1.747 -> 1.755): the first
+    in_proj of a stack on the row-chain kernel's projection-only form instead of the generic GEMM -- 160 priority
+    workgroups that stream the whole 900 x 300 weight each are slower than 1 200 small tiles even behind a bulk kernel."""
+    return bool(os.environ.get("ICK_CHAIN_PROJ"))
+
+
+def chain_project_heads(x, w2p, bias, nseg, H, S, out=None, slim=False):
+    """project_heads(x, W, bias, nseg, H, S) for x (B, T, d) on the row-chain kernel's projection-only form
+    (ICK_CHAIN_PROJ; w2p = pack_weights copy of the (nseg * d, d) weight): 8 rows per workgroup, raised wave priority --
+    for the first in_proj of a stack, which as a generic GEMM of ~1 200 small workgroups queues behind the bulk kernels of
+    the other stream (14 us alone, 32-48 us inside the steps)."""
+    B, T, d = x.shape
+    N2 = bias.shape[0]
+    if out is None:
+        out = torch.empty(B, nseg, H, S, DHP, device=x.device, dtype=torch.float32)
+    x2 = x.reshape(-1, d)
+    g = L.RowChainArgs()
+    g.A, g.a_rs, g.a_grp, g.a_gs = _p(x2), x2.stride(0), 0, 0
+    g.M, g.K1, g.d = x2.shape[0], d, d
+    g.w2p, g.b2, g.N2, g.y2 = _p(w2p), _p(bias), N2, _p(out)
+    g.y2_rs, g.y2_grp, g.y2_gs = 0, T, out.stride(0)
+    g.hs_dh, g.hs_dhp, g.hs_H, g.hs_S, g.hs_s0 = (N2 // nseg) // H, DHP, H, S, 0
+    g.flags = 512 | (256 if slim else 0)
+    L.check(L.load().ick_rowchain_fwd(C.byref(g), _stream()), "ick_rowchain_fwd(proj)")
+    return out
+
+
 def rowchain_bwd_supported(K0, d, N1=0):
     return bool(L.load_raw().ick_rowchain_bwd_supported(int(K0), int(d), int(N1)))
 

@@ -70,8 +70,12 @@ def _context_encoder_fwd(dec, stack, x, tape_list, ds, pk=None, tag="e", out=Non
         last = li == n - 1
         t = {"x": x, "d_att": ds.site(layer.self_attn.dropout), "d1": ds.site(layer.dropout1.p), "d_ff": ds.site(p),
              "d2": ds.site(layer.dropout2.p)}
-        t["qkv"] = qkv if qkv is not None else ops.project_heads(x, _p(layer.self_attn.in_proj_weight),
-                                                                 _p(layer.self_attn.in_proj_bias), 3, H, T)
+        if qkv is not None:
+            t["qkv"] = qkv
+        elif pk is not None and ops.chain_proj_on():
+            t["qkv"] = ops.chain_project_heads(x, pk[(tag, li, "si")], _p(layer.self_attn.in_proj_bias), 3, H, T, slim=slim)
+        else:
+            t["qkv"] = ops.project_heads(x, _p(layer.self_attn.in_proj_weight), _p(layer.self_attn.in_proj_bias), 3, H, T)
         qkv = None
         t["sa"] = torch.empty_like(x)
         t["lse"] = torch.empty(B * H * T, device=x.device, dtype=torch.float32)
@@ -120,8 +124,12 @@ def _decoder_self_block(dec, li, layer, x, ds, pk=None, qkv=None):
     t = {"x": x, "d_sa": ds.site(layer.self_attn.dropout), "d1": ds.site(layer.dropout1.p),
          "d_ca": ds.site(layer.multihead_attn.dropout), "d2": ds.site(layer.dropout2.p),
          "d_ff": ds.site(layer.dropout.p), "d3": ds.site(layer.dropout3.p)}
-    t["qkv"] = qkv if qkv is not None else ops.project_heads(x, _p(layer.self_attn.in_proj_weight),
-                                                             _p(layer.self_attn.in_proj_bias), 3, H, T)
+    if qkv is not None:
+        t["qkv"] = qkv
+    elif pk is not None and ops.chain_proj_on():
+        t["qkv"] = ops.chain_project_heads(x, pk[("d", li, "si")], _p(layer.self_attn.in_proj_bias), 3, H, T)
+    else:
+        t["qkv"] = ops.project_heads(x, _p(layer.self_attn.in_proj_weight), _p(layer.self_attn.in_proj_bias), 3, H, T)
     t["sa"] = torch.empty_like(x)
     t["lse_s"] = torch.empty(B * H * T, device=x.device, dtype=torch.float32)
     ops.attention_heads(t["qkv"], t["qkv"], t["sa"], H, dh, T, T, 0, 1, 2, causal=True, lse=t["lse_s"],
@@ -246,7 +254,7 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
 
     chain = dec.chain_supported()
     staged = chain and fresh_pack and overlap
-    first = lambda k: k[0] != "d" or (k[1] == 0 and k[2] in ("so", "cq"))     # context encoders + layer 0's self block
+    first = lambda k: k[0] != "d" or (k[1] == 0 and k[2] in ("so", "cq", "si"))     # context encoders + layer 0's self block
 
     def head():
         ee = ops.entity_encode(dec.variant, entities, _p(dec.entity_encoder.type_embedding.weight), d,

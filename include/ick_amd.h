@@ -172,6 +172,7 @@ typedef struct {
 } ick_rowchain_args;
 #define ICK_CHAIN_SLIM 256   /* 8-wave workgroups: for chains that run beside bulk GEMMs on another stream (they find
                                 room on a busy CU where the 16-wave form waits for the bulk kernel to drain) */
+#define ICK_CHAIN_PROJ 512   /* ick_rowchain_fwd: projection only, y2 = act(A W2^T + b2) with A (M, d); w1p / norm arguments unused */
 int ick_rowchain_supported(int32_t K1, int32_t d, int32_t N2);
 int ick_rowchain_fwd(const ick_rowchain_args* args, void* stream);
 
