@@ -842,7 +842,9 @@ extern "C" int ick_gemm_grouped(const ick_gemm_args* problems, int32_t count, vo
         for (int i = 0; i < count; ++i)
             if (plans[i].vec && !plans[i].big && plans[i].akm && plans[i].bkm && !(plans[i].a.flags & ICK_GEMM_COLSUM_ONLY))
                 total += (int64_t)ceil_div(plans[i].a.M, 64) * ceil_div(plans[i].a.N, 64) * plans[i].split;
-        if (total >= 512)
+        static int big_min = -1;      // ICK_GROUP_BIG_MIN: 64 x 64-tile count from which a group takes the large tiles (A/B runs)
+        if (big_min < 0) { const char* e = getenv("ICK_GROUP_BIG_MIN"); big_min = e ? atoi(e) : 512; }
+        if (total >= big_min)
             for (int i = 0; i < count; ++i)
                 if (plans[i].vec && !plans[i].big && plans[i].akm && plans[i].bkm && !(plans[i].a.flags & ICK_GEMM_COLSUM_ONLY))
                     if (int rc = make_plan(problems + i, plans[i], 1)) return rc;
