@@ -722,7 +722,9 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
         // a one-column-tile problem (N <= 320, no K split) needs ~180 row tiles of 128 to fill the chip with the pre-split
         // kernel's one-workgroup-per-CU tile (Encoder.conv1 at batch 32 -- 98 workgroups -- took as long as at batch 64);
         // below that the stager-split kernel's 128 x 64 tiles (five per row panel) are the better fit
-        const bool narrow_underfilled = a.N <= 320 && split_req == 1 && ceil_div(a.M, 128) * ceil_div(a.N, 160) < 180;
+        static int narrow_min = -1;
+        if (narrow_min < 0) { const char* e = getenv("ICK_PS_NARROW_MIN"); narrow_min = e ? atoi(e) : 180; }
+        const bool narrow_underfilled = a.N <= 320 && split_req == 1 && ceil_div(a.M, 128) * ceil_div(a.N, 160) < narrow_min;
         // the pre-split copy is addressed through one buffer descriptor: it must stay below 2 GiB
         const bool ps_fits = (int64_t)ceil_div(a.K, 32) * 3 * ceil_div(a.N, 64) * 64 * 64 < ((int64_t)1 << 31);
         if (ps_on && ps_fits && flop >= 1.0e9 && a.M >= 256 && a.N >= 128 && (!narrow_underfilled || ps_tile_env >= 0)) {
