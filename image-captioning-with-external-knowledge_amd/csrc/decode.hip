@@ -1699,14 +1699,6 @@ static GroupPlan plan_groups(const ick_decode_ctx* c) {
         for (int g : shared)
             if (rps % g == 0) { p.g_cross = g; p.cross_shared = true; break; }
     }
-    if (const char* e = getenv("ICK_DEC_G")) {
-        int a = 0, b = 0, f = 0;
-        if (sscanf(e, "%d,%d,%d", &a, &b, &f) == 3) {
-            if (a == 1 || a == 2 || a == 4 || a == 8) p.g_self = a;
-            if (f == 1 || f == 2 || f == 4 || f == 8) p.g_ffn = f;
-            if (!p.cross_shared && (b == 1 || b == 2 || b == 4 || b == 8)) p.g_cross = b;
-        }
-    }
     return p;
 }
 static void launch_self(int g, bool fsel, dim3 grid, hipStream_t s, const SelfArgs& a) {
@@ -1834,9 +1826,8 @@ static int decode_layers_impl(const ick_decode_ctx* c, int32_t pos, void* stream
     va.cand = reinterpret_cast<float4*>(c->cand); va.R = R; va.d = d; va.V = c->V; va.ntiles = ceil_div(c->V, kVocabTile);
     va.n_done = c->n_done; va.n_total = R;
     // one launch for both when the rows fit one 32-row block and the final LayerNorm's sources fit the merged kernel's
-    // registers (greedy decoding at cfg5); ICK_DECODE_SPLIT_HEAD=1 keeps the two launches (A/B runs, the diagnostic build)
-    static const bool split_head = getenv("ICK_DECODE_SPLIT_HEAD") != nullptr;
-    if ((which & 24u) == 24u && R <= 32 && src.nparts + 2 <= kHvSrc && !split_head) {
+    // registers (greedy decoding at cfg5)
+    if ((which & 24u) == 24u && R <= 32 && src.nparts + 2 <= kHvSrc) {
         hipLaunchKernelGGL(dec_headvocab_kernel, dim3(va.ntiles + R), dim3(kNT), 0, s, ha, va);
         ICK_LAUNCH_RET();
     }

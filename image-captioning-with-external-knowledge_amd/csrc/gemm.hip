@@ -502,26 +502,13 @@ struct Plan {
     int tiles_m, tiles_n, kchunk, split;
 };
 
-// Occupancy cap for the large-tile kernels: a workgroup that declares more LDS than it uses leaves wave slots,
-// registers and LDS of its CU to the latency-bound chain kernels that run beside it on the other stream.
-// ICK_GEMM_LDS_SINGLE / ICK_GEMM_LDS_GROUP: bytes of LDS a 64x64 / 128x64 workgroup declares (<= 160 KB; above 64 KB
-// the launchers raise the kernel's dynamic-LDS limit first).
-inline size_t lds_floor(int which) {
-    static long v[2] = {-1, -1};
-    if (v[which] < 0) {
-        const char* e = getenv(which ? "ICK_GEMM_LDS_GROUP" : "ICK_GEMM_LDS_SINGLE");
-        v[which] = e ? std::min(160l * 1024, std::max(0l, atol(e))) : 0;
-    }
-    return (size_t)v[which];
-}
-
 template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, bool VEC, bool SPL, int LSTG = 2>
 int launch_tile_s(const Plan& pl, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = WM * WN * 64;
     constexpr int STAGE = Stager<BM, AKM, VEC, 32, NT, SPL>::FLOATS + Stager<BN, BKM, VEC, 32, NT, SPL>::FLOATS;
     constexpr size_t smem = LSTG * STAGE * sizeof(float);
     static_assert(smem <= 160 * 1024, "tile exceeds the LDS of a CU");
-    const size_t lds = (TM > 1) ? std::max(smem, lds_floor(0)) : smem;
+    const size_t lds = smem;
     if (lds > 64 * 1024) {
         static bool attr = false;
         if (!attr) {
@@ -548,8 +535,6 @@ template <int TM, int TN, bool AKM, bool BKM, bool VEC>
 int launch_one(const Plan& pl, hipStream_t s) { return launch_tile<2, 2, TM, TN, AKM, BKM, VEC>(pl, s); }
 template <int TM, int TN, bool AKM, bool BKM, bool VEC>
 int launch_wide(const Plan& pl, hipStream_t s) { return launch_tile<4, 2, TM, TN, AKM, BKM, VEC>(pl, s); }   // 8 waves
-template <int TM, int TN, bool AKM, bool BKM, bool VEC>
-int launch_xl(const Plan& pl, hipStream_t s) { return launch_tile_s<4, 2, TM, TN, AKM, BKM, VEC, true>(pl, s); }
 // 128 x 128, four waves of 64 x 64, one LDS buffer: two workgroups per CU
 template <int TM, int TN, bool AKM, bool BKM, bool VEC>
 int launch_xl4(const Plan& pl, hipStream_t s) { return launch_tile_s<2, 2, TM, TN, AKM, BKM, VEC, true, 1>(pl, s); }
@@ -573,7 +558,7 @@ int launch_group_s(const Plan* const* pls, int n, hipStream_t s) {
         ga.wg_end[i] = total; ga.tiles_m[i] = ga.tiles_n[i] = 1; ga.kchunk[i] = 32; ga.split[i] = 0; ga.g[i] = pls[0]->a;
     }
     static_assert(smem <= 160 * 1024, "tile exceeds the LDS of a CU");
-    const size_t lds = (TM > 1) ? std::max(smem, lds_floor(1)) : smem;
+    const size_t lds = smem;
     if (lds > 64 * 1024) {      // split planes of two k-major operands: 72 KB, above the default dynamic-LDS limit
         static bool attr = false;
         if (!attr) {
@@ -681,26 +666,18 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
     const int split_req = a.split_k > 1 ? a.split_k : 1;
     const int64_t wgs64 = (int64_t)ceil_div(a.M, 64) * ceil_div(a.N, 64) * split_req;
     pl.big = !pl.vec || wgs64 >= 512;
-    {   // experiment hook: ICK_GEMM_TILE=2 forces 64x64 tiles, 3 forces 32x32
-        static int forced = -2;
-        if (forced == -2) { const char* e = getenv("ICK_GEMM_TILE"); forced = e ? atoi(e) : -1; }
-        if (forced == 2 || force_big > 0) pl.big = true;
-        if (forced == 3 && pl.vec) pl.big = false;
-        // 128 x 64 tiles, 8 waves: measured +4 % on the feature projection (k-major A, K = 2048, N = 300: 157 -> 151 us),
-        // -3 % on the K = 300 shapes, so it is reserved for long-K, narrow-N problems (or forced with ICK_GEMM_TILE=8)
-        pl.wide = pl.vec && pl.big && a.M >= 128 &&
-                  (forced == 8 || (forced < 0 && akm && !bkm && a.N <= 320 && a.M >= 4096 && a.K >= 1024 && split_req == 1));
-    }
+    if (force_big > 0) pl.big = true;
+    // 128 x 64 tiles, 8 waves: measured +4 % on the feature projection (k-major A, K = 2048, N = 300: 157 -> 151 us),
+    // -3 % on the K = 300 shapes, so it is reserved for long-K, narrow-N problems
+    pl.wide = pl.vec && pl.big && a.M >= 128 && akm && !bkm && a.N <= 320 && a.M >= 4096 && a.K >= 1024 && split_req == 1;
     pl.spl = pl.vec && pl.big && (gemm_split_mode() == 2 || (gemm_split_mode() == 1 && !bkm));
     pl.xl = false;
     if (pl.spl) {
         // 128 x 128 tiles: twice the products per staged (and split) element.  One workgroup per CU (98 KB of LDS), so
         // the problem must bring several rounds of tiles and waste little of its last tile column
-        static int forced = -2;
-        if (forced == -2) { const char* e = getenv("ICK_GEMM_XL"); forced = e ? atoi(e) : -1; }
         const int64_t t128 = (int64_t)ceil_div(a.M, 128) * ceil_div(a.N, 128);
         const bool fits = split_req == 1 && a.M >= 128 && a.N >= 128 && t128 >= 512 && ceil_div(a.N, 128) * 128 <= a.N + a.N / 8;
-        pl.xl = forced < 0 ? fits : (forced > 0 && a.M >= 128 && a.N >= 128);
+        pl.xl = fits;
         if (pl.xl) pl.wide = true;
     }
     const int BMN = pl.big ? 64 : 32;
@@ -712,12 +689,8 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
     pl.ps = false; pl.ps_tile = 0; pl.ps_nt = 0;
     if (a.b_ps != nullptr && gemm_split_mode() >= 1 && avec && aligned16(a.b_ps) && a.a_extent >= 4 &&
         a_need <= a.a_extent + 3 && a.colsum_a == nullptr && !(a.flags & ICK_GEMM_COLSUM_ONLY)) {
-        static int ps_on = -1, ps_tile_env = -2, ps_nt_env = -2;
-        if (ps_on < 0) {
-            const char* e = getenv("ICK_GEMM_PS"); ps_on = e ? atoi(e) : 1;
-            e = getenv("ICK_PS_TILE"); ps_tile_env = e ? atoi(e) : -1;
-            e = getenv("ICK_PS_NT"); ps_nt_env = e ? atoi(e) : -1;
-        }
+        static int ps_tile_env = -2;      // ICK_PS_TILE: one tile shape for every pre-split problem (tools/gemm_ps_bench.py sweeps)
+        if (ps_tile_env == -2) { const char* e = getenv("ICK_PS_TILE"); ps_tile_env = e ? atoi(e) : -1; }
         const double flop = 2.0 * a.M * a.N * a.K;
         // a one-column-tile problem (N <= 320, no K split) needs ~180 row tiles of 128 to fill the chip with the pre-split
         // kernel's one-workgroup-per-CU tile (Encoder.conv1 at batch 32 -- 98 workgroups -- took as long as at batch 64);
@@ -727,7 +700,7 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
         const bool narrow_underfilled = a.N <= 320 && split_req == 1 && ceil_div(a.M, 128) * ceil_div(a.N, 160) < narrow_min;
         // the pre-split copy is addressed through one buffer descriptor: it must stay below 2 GiB
         const bool ps_fits = (int64_t)ceil_div(a.K, 32) * 3 * ceil_div(a.N, 64) * 64 * 64 < ((int64_t)1 << 31);
-        if (ps_on && ps_fits && flop >= 1.0e9 && a.M >= 256 && a.N >= 128 && (!narrow_underfilled || ps_tile_env >= 0)) {
+        if (ps_fits && flop >= 1.0e9 && a.M >= 256 && a.N >= 128 && (!narrow_underfilled || ps_tile_env >= 0)) {
             // Tile choice, measured (tools/gemm_ps_bench.py, profiles/r04_e_gemm_ps_tiles.txt: every tile x every shape):
             // 128 x 128 with two workgroups per CU wins wherever the output is wider than 320 columns (cross K/V 100 us
             // against 129-143 on the other tiles, vocabulary 65 against 80-88); outputs at most 320 wide (Encoder.conv1,
@@ -736,29 +709,22 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
             // the bf16 pipe holds on random data at the clock the chip keeps under MFMA load (MI355X_MICROARCH.md).
             // (split-K problems -- the cross K/V weight gradient, 600 x 300 over 13 824 rows -- also run best on 128 x 128:
             // 62-67 us against 70-77 on 128 x 160 and 87-93 on the exact 64 x 64 tile, profiles/r04_i_gemm_ps_kv_wgrad.txt)
-            static int narrow_env = -2;
-            if (narrow_env == -2) { const char* e = getenv("ICK_PS_TILE_NARROW"); narrow_env = e ? atoi(e) : -1; }
-            static int wide_env = -2;
-            if (wide_env == -2) { const char* e = getenv("ICK_PS_TILE_WIDE"); wide_env = e ? atoi(e) : -1; }
             // Inside the steps Encoder.conv1 runs beside the context-encoder chain of the other stream, whose 49 KB
             // workgroups cannot share a CU with a 139 KB tile: on 128 x 80 (62 KB, two per CU; alone 2-8 % slower than
             // 128 x 160) the cfg2 train step is 1.748 -> 1.722 ms and the forward pass 0.702 -> 0.693
-            // (profiles/r04_y_ab_narrow_tile.txt; ICK_PS_TILE_NARROW / ICK_PS_TILE_WIDE pick others for A/B runs)
-            int best = (a.N <= 320 && split_req == 1) ? (narrow_env >= 0 && narrow_env < gemm_ps_tile_count() ? narrow_env : 9)
-                                                      : (wide_env >= 0 && wide_env < gemm_ps_tile_count() ? wide_env : 1);
-            static int splitk_env = -2;
-            if (splitk_env == -2) { const char* e = getenv("ICK_PS_TILE_SPLITK"); splitk_env = e ? atoi(e) : -1; }
+            // (profiles/r04_y_ab_narrow_tile.txt)
+            int best = (a.N <= 320 && split_req == 1) ? 9 : 1;
             // split-K problems at most 320 columns wide (the vocabulary's data gradient 1280 x 300 over K = 10 000, the
             // cross K/V and vocabulary weight gradients): 128 x 80 as well -- the data gradient's 40 x 12 = 480 workgroups
             // fill the chip's two slots per CU once (train step 1.770 -> 1.741 ms), the weight gradients are unchanged
-            if (a.N <= 320 && split_req > 1) best = splitk_env >= 0 && splitk_env < gemm_ps_tile_count() ? splitk_env : 9;
+            if (a.N <= 320 && split_req > 1) best = 9;
             if (ps_tile_env >= 0 && ps_tile_env < gemm_ps_tile_count()) best = ps_tile_env;
             int bm, bn, wpc; gemm_ps_tile_dims(best, &bm, &bn, &wpc);
             pl.ps = true; pl.ps_tile = best;
             pl.spl = true; pl.big = true; pl.wide = pl.xl = false;
             pl.tiles_m = ceil_div(a.M, bm);
             pl.tiles_n = ceil_div(a.N, bn);
-            pl.ps_nt = ps_nt_env >= 0 ? ps_nt_env : 0;    // non-temporal A loads: measured, no gain (same file)
+            pl.ps_nt = 0;    // non-temporal A loads: measured, no gain (same file)
         }
     }
     return ICK_OK;
@@ -778,12 +744,9 @@ int launch_plan(const Plan& pl, hipStream_t s) {
     if (pl.ps) return launch_gemm_ps(pl.a, pl.akm, pl.ps_tile, pl.tiles_m, pl.tiles_n, pl.kchunk, pl.split, pl.ps_nt, s);
     if (!pl.vec) ICK_BY_LAYOUT(launch_one, 2, 2, ICK_COMMA_FALSE, pl, s);
     if (pl.xl) {
-        // four waves of 64 x 64 and one LDS buffer (two workgroups per CU overlap their phases) unless ICK_GEMM_XL4=0
-        // (eight waves, two buffers, one workgroup per CU): cross K/V 140 -> 128 us, train step 1.867 -> 1.839 ms
-        static int four = -1;
-        if (four < 0) { const char* e = getenv("ICK_GEMM_XL4"); four = e ? atoi(e) : 1; }
-        if (four) ICK_BY_LAYOUT(launch_xl4, 4, 4, ICK_COMMA_TRUE, pl, s);
-        ICK_BY_LAYOUT(launch_xl, 2, 4, ICK_COMMA_TRUE, pl, s);
+        // four waves of 64 x 64 and one LDS buffer: two workgroups per CU overlap their phases (against eight waves, two
+        // buffers, one workgroup per CU: cross K/V 140 -> 128 us, train step 1.867 -> 1.839 ms)
+        ICK_BY_LAYOUT(launch_xl4, 4, 4, ICK_COMMA_TRUE, pl, s);
     }
     if (pl.wide) ICK_BY_LAYOUT(launch_wide, 2, 2, ICK_COMMA_TRUE, pl, s);
     if (pl.big) ICK_BY_LAYOUT(launch_one, 2, 2, ICK_COMMA_TRUE, pl, s);
@@ -836,17 +799,14 @@ extern "C" int ick_gemm_grouped(const ick_gemm_args* problems, int32_t count, vo
     for (int i = 0; i < count; ++i)
         if (int rc = make_plan(problems + i, plans[i])) return rc;
     // weight-gradient problems that are small alone (32x32 tiles) but fill the GPU together take 64x64 tiles: four
-    // independent accumulators per wave instead of one dependent chain (train step 2.49 -> 2.44 ms); ICK_GROUP_BIG=0
-    // keeps the per-problem choice
-    static const bool group_big = !(getenv("ICK_GROUP_BIG") && atoi(getenv("ICK_GROUP_BIG")) == 0);
-    if (group_big) {
+    // independent accumulators per wave instead of one dependent chain (train step 2.49 -> 2.44 ms) -- from 512 such
+    // tiles on (64 x 64 tiles for EVERY grouped weight gradient: train step 1.742 -> 1.79 ms, round 4)
+    {
         int64_t total = 0;
         for (int i = 0; i < count; ++i)
             if (plans[i].vec && !plans[i].big && plans[i].akm && plans[i].bkm && !(plans[i].a.flags & ICK_GEMM_COLSUM_ONLY))
                 total += (int64_t)ceil_div(plans[i].a.M, 64) * ceil_div(plans[i].a.N, 64) * plans[i].split;
-        static int big_min = -1;      // ICK_GROUP_BIG_MIN: 64 x 64-tile count from which a group takes the large tiles (A/B runs)
-        if (big_min < 0) { const char* e = getenv("ICK_GROUP_BIG_MIN"); big_min = e ? atoi(e) : 512; }
-        if (total >= big_min)
+        if (total >= 512)
             for (int i = 0; i < count; ++i)
                 if (plans[i].vec && !plans[i].big && plans[i].akm && plans[i].bkm && !(plans[i].a.flags & ICK_GEMM_COLSUM_ONLY))
                     if (int rc = make_plan(problems + i, plans[i], 1)) return rc;

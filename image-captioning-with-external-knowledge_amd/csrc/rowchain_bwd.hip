@@ -331,235 +331,6 @@ __global__ __launch_bounds__(kThreads) ICK_CHAIN_BWD_ATTR void rowchain_bwd_kern
         if (row0 + i < M) p.out3[(int64_t)(row0 + i) * d + col] = y[i];
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The same chain in EIGHT waves (ICK_CHAIN_SLIM; round 4).  The 16-wave kernel above holds 117 VGPRs x 4 waves = 480 of the
-// 512 registers of every SIMD: its workgroups only start on CUs that hold nothing else, and in the training step every
-// launch of it runs beside the other stream's weight-gradient workgroups, which sit on every CU.  Here a wave owns two
-// (slab, K split) units of each GEMM stage, one after the other: the same matrix work per SIMD with half the wave slots and
-// registers, so a workgroup fits beside resident weight-gradient waves instead of waiting for a CU to drain.  Every unit's
-// partial tile goes through LDS and the splits are added in the order 0, 1, 2 -- the order of the 16-wave kernel, whose
-// split-0 tile merely stays in registers -- so both kernels produce the same bits (tests/test_rowchain_gpu.py).
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr int kSlimWaves = 8;
-__global__ __launch_bounds__(kSlimWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void rowchain_bwd_slim_kernel(ick_rowchain_bwd_args p) {
-    chain_priority_bwd();
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int kLdA = lda_for(p.g0 != nullptr ? p.K0 : 0, p.w1p != nullptr ? p.N1 : 0);      // uniform
-    float* XA = smem;
-    float* XB = XA + kRows * kLdA;
-    float* DZ = XB + kRows * kLdB;
-    float* RG = DZ + kRows * kLdB;
-    float* Ps = RG + kRows * 2 * kLdB;
-    constexpr int NW = kSlimWaves;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = blockIdx.x * kRows;
-    const int d = p.d, M = p.M, dp = (d + 15) & ~15;
-    const uint32_t seed = p.drop_epoch ? p.drop_seed + *p.drop_epoch : p.drop_seed;
-    const bool ffn = p.w1p != nullptr;         // uniform
-    const int lrow = row0 + wave;              // one wave per row: NW == kRows
-    const bool lrow_ok = lrow < M;
-    static_assert(NW == kRows, "the norm stages give every wave one row");
-
-    LnIn q1, q2;
-    float dzin[5];
-    ln_prefetch(q1, p.o1, p.res1, p.gamma1, p.mean1, p.rstd1, lrow, lrow_ok, d, lane);
-    if (ffn) ln_prefetch(q2, p.o2, p.res2, p.gamma2, p.mean2, p.rstd2, lrow, lrow_ok, d, lane);
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int c = lane + 64 * j;
-        dzin[j] = (lrow_ok && c < d && p.dzin) ? p.dzin[(int64_t)lrow * p.dzin_rs + c] : 0.f;
-    }
-    const int N1 = p.N1;
-    const bool pre = p.g0 != nullptr;          // uniform
-    const GemmPlan gF1 = plan_for(ffn ? N1 : 64, d);
-    const GemmPlan g0p = plan_for(d, pre ? p.K0 : 16);
-    const GemmPlan gF2 = plan_for(d, ffn ? N1 : 16);
-    const GemmPlan g3 = plan_for(d, d);
-    // the ReLU gate of linear2's data gradient for the (at most two) K-split-0 units of this wave
-    float act[2][kRows];
-#pragma unroll
-    for (int ui = 0; ui < 2; ++ui) {
-        const int u = wave + NW * ui;
-        const Slab w = unit_of(gF1, u);
-        const int col = w.slab * 64 + lane;
-        const bool mine = ffn && u < gF1.nslab * gF1.splits && w.h == 0 && col < N1;
-#pragma unroll
-        for (int i = 0; i < kRows; ++i) act[ui][i] = (mine && row0 + i < M) ? p.act[(int64_t)(row0 + i) * N1 + col] : 0.f;
-    }
-    RowGemm mm;
-    // one GEMM stage: every unit's 8 x 64 partial tile to Ps[split][row][npad]; the caller follows with a barrier
-    auto stage = [&](const GemmPlan& g, int K, const float* Wp, const float* Xs, int ldx) {
-        const int units = g.nslab * g.splits, npad = g.nslab * 64;
-        for (int u = wave; u < units; u += NW) {
-            const Slab w = unit_of(g, u);
-            if (u != wave) mm.begin(K, Wp, g, w);      // the wave's first unit was begun before the previous stage ended
-            f32x4 acc0, acc1;
-            mm.run(Xs, ldx, acc0, acc1);
-            float* q = Ps + (size_t)w.h * kRows * npad + w.slab * 64 + lane;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                q[i * npad] = acc0[i];
-                q[(4 + i) * npad] = acc1[i];
-            }
-        }
-    };
-
-    // ---- dx = dzin + g0 W0
-    if (pre) {
-        mm.begin(p.K0, p.w0p, g0p, unit_of(g0p, wave));
-        const int K0 = p.K0, K0p = (K0 + 15) & ~15;
-        const int gr = row0 + wave;
-        int64_t goff = (int64_t)gr * p.g0_rs;
-        if (p.g0_grp > 0) { const int g = small_div(gr, p.g0_grp); goff = (int64_t)g * p.g0_gs + (int64_t)(gr - g * p.g0_grp) * p.g0_rs; }
-        const float* grow = p.g0 + goff;
-        for (int k = lane; k < K0p; k += 64) XA[wave * kLdA + k] = (gr < M && k < K0) ? grow[k] : 0.f;
-        __syncthreads();
-        stage(g0p, p.K0, p.w0p, XA, kLdA);
-        __syncthreads();
-    }
-    // ---- norm stage 1
-    if (ffn) mm.begin(d, p.w1p, gF1, unit_of(gF1, wave));
-    else mm.begin(d, p.w3p, g3, unit_of(g3, wave));
-    {
-        float dx[5], dz[5], dod[5], dgam[5], dbet[5];
-        const int npad = g0p.nslab * 64;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int c = lane + 64 * j;
-            float t = dzin[j];
-            if (pre && c < d) {
-                float s = Ps[wave * npad + c];
-                for (int h = 1; h < g0p.splits; ++h) s += Ps[(h * kRows + wave) * npad + c];
-                t += s;
-            }
-            dx[j] = t;
-        }
-        const Dropout drop = make_dropout(p.drop1_p, seed, p.drop1_site);
-        ln_bwd_row(q1, dx, drop, lrow, d, lane, dz, dod, dgam, dbet);
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int c = lane + 64 * j;
-            if (c < dp) {
-                XB[wave * kLdB + c] = (lrow_ok && c < d) ? dod[j] : 0.f;
-                DZ[wave * kLdB + c] = (lrow_ok && c < d) ? dz[j] : 0.f;
-                RG[(wave * 2 + 0) * kLdB + c] = (lrow_ok && c < d) ? dgam[j] : 0.f;
-                RG[(wave * 2 + 1) * kLdB + c] = (lrow_ok && c < d) ? dbet[j] : 0.f;
-                if (lrow_ok && c < d) {
-                    p.do1[(int64_t)lrow * d + c] = dod[j];
-                    if (!ffn) p.dz_out[(int64_t)lrow * d + c] = dz[j];
-                }
-            }
-        }
-    }
-    __syncthreads();
-    auto part_sums = [&](float* part) {      // gamma / beta partial sums of this workgroup's rows, fixed order
-        float* pr = part + (int64_t)blockIdx.x * 2 * d;
-        if (tid < d) {
-#pragma unroll
-            for (int which = 0; which < 2; ++which) {
-                float s = 0.f;
-#pragma unroll
-                for (int r = 0; r < kRows; ++r) s += RG[(r * 2 + which) * kLdB + tid];
-                pr[which * d + tid] = s;
-            }
-        }
-    };
-    part_sums(p.part1);
-    if (ffn) {
-        // ---- t = gate(do1 W2)
-        stage(gF1, d, p.w1p, XB, kLdB);
-        mm.begin(N1, p.w2p, gF2, unit_of(gF2, wave));
-        __syncthreads();
-        {
-            const int npad = gF1.nslab * 64;
-#pragma unroll
-            for (int ui = 0; ui < 2; ++ui) {
-                const int u = wave + NW * ui;
-                const Slab w = unit_of(gF1, u);
-                if (u >= gF1.nslab * gF1.splits || w.h != 0) continue;      // uniform per wave
-                const int col = w.slab * 64 + lane;
-                float y[kRows];
-#pragma unroll
-                for (int i = 0; i < kRows; ++i) y[i] = Ps[i * npad + col];
-                for (int h = 1; h < gF1.splits; ++h) {
-                    const float* q = Ps + (size_t)h * kRows * npad + col;
-#pragma unroll
-                    for (int i = 0; i < kRows; ++i) y[i] += q[i * npad];
-                }
-#pragma unroll
-                for (int i = 0; i < kRows; ++i) {
-                    const float t = act[ui][i] > 0.f ? y[i] * p.gate_scale : 0.f;
-                    XA[i * kLdA + col] = t;
-                    if (col < N1 && row0 + i < M) p.t_out[(int64_t)(row0 + i) * N1 + col] = t;
-                }
-            }
-        }
-        __syncthreads();
-        // ---- dx2 = dz1 + t W1
-        stage(gF2, N1, p.w2p, XA, kLdA);
-        mm.begin(d, p.w3p, g3, unit_of(g3, wave));
-        __syncthreads();
-        // ---- norm stage 2
-        {
-            float dx[5], dz[5], dod[5], dgam[5], dbet[5];
-            const int npad = gF2.nslab * 64;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const int c = lane + 64 * j;
-                float t = 0.f;
-                if (c < d) {
-                    float s = Ps[wave * npad + c];
-                    for (int h = 1; h < gF2.splits; ++h) s += Ps[(h * kRows + wave) * npad + c];
-                    t = DZ[wave * kLdB + c] + s;
-                }
-                dx[j] = t;
-            }
-            const Dropout drop = make_dropout(p.drop2_p, seed, p.drop2_site);
-            ln_bwd_row(q2, dx, drop, lrow, d, lane, dz, dod, dgam, dbet);
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const int c = lane + 64 * j;
-                if (c < dp) {
-                    XB[wave * kLdB + c] = (lrow_ok && c < d) ? dod[j] : 0.f;
-                    RG[(wave * 2 + 0) * kLdB + c] = (lrow_ok && c < d) ? dgam[j] : 0.f;
-                    RG[(wave * 2 + 1) * kLdB + c] = (lrow_ok && c < d) ? dbet[j] : 0.f;
-                    if (lrow_ok && c < d) {
-                        p.do2[(int64_t)lrow * d + c] = dod[j];
-                        p.dz_out[(int64_t)lrow * d + c] = dz[j];
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        part_sums(p.part2);
-    }
-    // ---- out = do W3
-    stage(g3, d, p.w3p, XB, kLdB);
-    __syncthreads();
-    {
-        const int npad = g3.nslab * 64;
-#pragma unroll
-        for (int ui = 0; ui < 2; ++ui) {
-            const int u = wave + NW * ui;
-            const Slab w = unit_of(g3, u);
-            const int col = w.slab * 64 + lane;
-            if (u >= g3.nslab * g3.splits || w.h != 0 || col >= d) continue;
-            float y[kRows];
-#pragma unroll
-            for (int i = 0; i < kRows; ++i) y[i] = Ps[i * npad + col];
-            for (int h = 1; h < g3.splits; ++h) {
-                const float* q = Ps + (size_t)h * kRows * npad + col;
-#pragma unroll
-                for (int i = 0; i < kRows; ++i) y[i] += q[i * npad];
-            }
-#pragma unroll
-            for (int i = 0; i < kRows; ++i)
-                if (row0 + i < M) p.out3[(int64_t)(row0 + i) * d + col] = y[i];
-        }
-    }
-}
-
 constexpr size_t kBwdSmemMax = (size_t)(kRows * (kMaxK0 + 4) + 2 * kRows * kLdB + kRows * 2 * kLdB + kPartFloats) * sizeof(float);
 inline size_t bwd_smem(int lda) {
     return (size_t)(kRows * lda + 2 * kRows * kLdB + kRows * 2 * kLdB + kPartFloats) * sizeof(float);
@@ -593,20 +364,8 @@ extern "C" int ick_rowchain_bwd(const ick_rowchain_bwd_args* in, void* stream) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    static const bool declare_max = getenv("ICK_CHAIN_BWD_LDS_MAX") != nullptr;     // A/B: the 136 KB of rounds 2-3
-    const size_t smem = declare_max ? kBwdSmemMax : bwd_smem(lda_for(a.g0 != nullptr ? a.K0 : 0, a.w1p != nullptr ? a.N1 : 0));
-    if (a.flags & ICK_CHAIN_SLIM) {
-        static bool attr_slim = false;
-        if (!attr_slim) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowchain_bwd_slim_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdSmemMax);
-            if (e != hipSuccess) return (int)e;
-            attr_slim = true;
-        }
-        hipLaunchKernelGGL(rowchain_bwd_slim_kernel, dim3(ceil_div(a.M, kRows)), dim3(kSlimWaves * 64), smem,
-                           (hipStream_t)stream, a);
-        ICK_LAUNCH_RET();
-    }
+    // the launch declares the LDS its own stage widths need (85-104 KB; 136 only with the 1 800-wide K/V gradient input)
+    const size_t smem = bwd_smem(lda_for(a.g0 != nullptr ? a.K0 : 0, a.w1p != nullptr ? a.N1 : 0));
     hipLaunchKernelGGL(rowchain_bwd_kernel, dim3(ceil_div(a.M, kRows)), dim3(kThreads), smem, (hipStream_t)stream, a);
     ICK_LAUNCH_RET();
 }

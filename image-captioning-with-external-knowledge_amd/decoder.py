@@ -398,14 +398,6 @@ class DecoderTransformer(nn.Module):
             wkv.data_ptr(), self.__dict__.get("_param_epoch", 0))
         return ops.presplit_cached(self, "wkv", wkv, key)
 
-    def _cross_kv_presplit_parts(self, wkv):
-        """The same in two copies: layer 0's rows and the later layers' (ICK_KV_SPLIT_LAYERS: two projections)."""
-        d = self.emb_dim
-        layers = self.transformer_decoder.layers
-        key = tuple(l.multihead_attn.in_proj_weight._version for l in layers) + (
-            wkv.data_ptr(), self.__dict__.get("_param_epoch", 0))
-        return (ops.presplit_cached(self, "wkv_l0", wkv[:2 * d], key), ops.presplit_cached(self, "wkv_rest", wkv[2 * d:], key))
-
     def _vocab_presplit(self):
         w = self.fc_vocab.weight
         return ops.presplit_cached(self, "vocab", w.detach(), (w._version, w.data_ptr(), self.__dict__.get("_param_epoch", 0)))
@@ -421,8 +413,8 @@ class DecoderTransformer(nn.Module):
             items += [(("d", li, "so"), layer.self_attn.out_proj.weight), (("d", li, "cq"), layer.multihead_attn.in_proj_weight[:d]),
                       (("d", li, "co"), layer.multihead_attn.out_proj.weight), (("d", li, "l1"), layer.linear1.weight),
                       (("d", li, "l2"), layer.linear2.weight)]
-            if li > 0 or ops.chain_proj_on():
-                items.append((("d", li, "si"), layer.self_attn.in_proj_weight))     # layer 0: ops.chain_project_heads
+            if li > 0:
+                items.append((("d", li, "si"), layer.self_attn.in_proj_weight))     # layer 0's in_proj is a plain GEMM
         stacks = [("e", self.transformer_encoder_entities)]
         if self.has_facts:
             stacks.append(("f", self.transformer_encoder_facts))
@@ -430,7 +422,7 @@ class DecoderTransformer(nn.Module):
             for li, layer in enumerate(stack.layers):
                 items += [((tag, li, "so"), layer.self_attn.out_proj.weight), ((tag, li, "l1"), layer.linear1.weight),
                           ((tag, li, "l2"), layer.linear2.weight)]
-                if li > 0 or ops.chain_proj_on():
+                if li > 0:
                     items.append(((tag, li, "si"), layer.self_attn.in_proj_weight))
         return items
 
@@ -527,9 +519,7 @@ class DecoderTransformer(nn.Module):
         n = len(stack.layers)
         qkv = None
         for li, layer in enumerate(stack.layers):
-            if qkv is None and chain and ops.chain_proj_on():
-                qkv = ops.chain_project_heads(x, pk[(tag, li, "si")], layer.self_attn.in_proj_bias.detach(), 3, H, T, slim=slim)
-            elif qkv is None:
+            if qkv is None:
                 qkv = ops.project_heads(x, layer.self_attn.in_proj_weight.detach(), layer.self_attn.in_proj_bias.detach(),
                                         3, H, T)
             sa = torch.empty_like(x)
@@ -563,12 +553,11 @@ class DecoderTransformer(nn.Module):
                 x = out
         return x
 
-    def _encode_context(self, enc_tok, entities, facts, gmap, side_first=None):
+    def _encode_context(self, enc_tok, entities, facts, gmap):
         """Entity / fact encoders, context transformers and the all-layer cross K/V projection.
         Returns (entities_encoded, facts_encoded, kv, contexts); kv is head-major
         (B, 2*layers, H, S, 32): segment 2i = keys of decoder layer i, 2i+1 = its values, over the
-        memory rows [196 image positions ; entity rows ; fact rows].
-        side_first(ee, fe, side): optional work for the head of the side stream, in front of the context chain."""
+        memory rows [196 image positions ; entity rows ; fact rows]."""
         d = self.emb_dim
         H = self.num_heads
         feats = None
@@ -601,23 +590,15 @@ class DecoderTransformer(nn.Module):
         # side stream before the first cross-attention (`side.join()`).
         side = ops.SideStream(priority=-1)
         ctx = [None, None]
-        # ICK_KV_SPLIT_LAYERS=1 (experiment, measured and left off: cfg2 forward 0.695 -> 0.826 ms): only layer 0's K/V of
-        # the image rows is projected in front of the decoder; the later layers' (two thirds of the GEMM) follow on the
-        # side stream behind the context chain, beside layer 0.  Same scores (tools/debug/kvsplit_check.py), but with a
-        # second fork / join pair in the captured graph the runtime starts the context chain only after conv1 and the
-        # first projection (device stamps: 222 us instead of 18) -- the hipGraph executor serialises the branches
-        split_kv = bool(os.environ.get("ICK_KV_SPLIT_LAYERS")) and nseg > 2 and not self.has_facts and gmap is None
-        side.split_kv = split_kv
-        wkv_parts = self._cross_kv_presplit_parts(wkv) if split_kv else None
+        # (Measured and removed in round 4: only layer 0's image K/V in front of the decoder and the later layers' on the side
+        # stream behind the context chain -- forward 0.695 -> 0.826 ms, a second fork / join pair makes the hipGraph
+        # executor start the context chain only after conv1)
 
         def entity_chain():
-            if side_first is not None:
-                side_first(ee, fe, side)
             ops.stamp("side: context chain starts")
             # beside Encoder.conv1 / the image K/V projection: the 8-wave form finds room on a CU that hosts bulk GEMM
-            # workgroups (as in the training step; ICK_SLIM_INFER=0 for A/B)
-            ctx[0] = self._context_encoder(self.transformer_encoder_entities, ee,
-                                           slim=os.environ.get("ICK_SLIM_INFER", "1") != "0")
+            # workgroups (as in the training step)
+            ctx[0] = self._context_encoder(self.transformer_encoder_entities, ee, slim=True)
             ops.project_heads(ctx[0], wkv, bkv, nseg, H, S, out=kv, s0=P, grp=K)
             side.signal("ctx")
             ops.stamp("side: context chain done")
@@ -649,18 +630,8 @@ class DecoderTransformer(nn.Module):
             if feats is not None:
                 conv1()
                 side.flush()       # the context chain starts beside Encoder.conv1
-            if split_kv:
-                ops.project_heads(enc_tok, wkv[:2 * d], bkv[:2 * d], 2, H, S, out=kv[:, :2], s0=0, grp=P, w_ps=wkv_parts[0])
-
-                def later_layers():
-                    ops.project_heads(enc_tok, wkv[2 * d:], bkv[2 * d:], nseg - 2, H, S, out=kv[:, 2:], s0=0, grp=P,
-                                      w_ps=wkv_parts[1])
-                    ops.stamp("side: K/V of the later layers done")
-
-                side.submit(later_layers, enc_tok, kv, wkv, bkv)
-            else:
-                ops.project_heads(enc_tok, wkv, bkv, nseg, H, S, out=kv, s0=0, grp=P, a_gmap=gmap, a_gs=enc_tok.stride(0),
-                                  w_ps=wkv_ps)
+            ops.project_heads(enc_tok, wkv, bkv, nseg, H, S, out=kv, s0=0, grp=P, a_gmap=gmap, a_gs=enc_tok.stride(0),
+                              w_ps=wkv_ps)
             side.flush()
         ops.stamp("main: image K/V projection done")
         ctx_e, ctx_f = ctx
@@ -697,12 +668,7 @@ class DecoderTransformer(nn.Module):
                              heads=(1, H, T, 0, T))
             ca = torch.empty_like(x)
             if side is not None:
-                # entity / fact rows of kv come from the side stream (split K/V: layer 0 waits for the context chain only,
-                # layer 1 for the later layers' image rows)
-                if getattr(side, "split_kv", False) and li == 0:
-                    side.wait_or_join("ctx")
-                else:
-                    side.join()
+                side.join()       # entity / fact rows of kv come from the side stream
             ops.attention_heads(q, kv, ca, H, dh, T, S, q_seg=0, k_seg=2 * li, v_seg=2 * li + 1)
             x2 = torch.empty_like(x)
             f = torch.empty(B, T, layer.linear1.out_features, device=x.device, dtype=torch.float32)
@@ -816,33 +782,14 @@ class DecoderTransformer(nn.Module):
             return ops.caption_embed(captions, caption_masks, self.word_embedding.weight.detach(), ee, fe, pe, V,
                                      self.word_map["<pad>"], math.sqrt(d), want_emb=True)
 
-        def first_in_proj(ee, fe, side):
-            # ICK_EARLY_IN_PROJ=1 (experiment, measured and left off: cfg2 forward 0.694 -> 0.715 ms).  Decoder layer 0's
-            # caption embedding and self-attention in_proj read neither the image nor the context rows; at the head of the
-            # SIDE stream they were meant to balance the two branches of the first phase.  They delay the context chain by
-            # 40 us instead (its 340 us beside the bulk GEMMs do not shrink), and that chain is what the first
-            # cross-attention waits for.
-            l0 = self.transformer_decoder.layers[0]
-            head["x"], head["emb"] = embed(ee, fe)
-            head["qkv"] = ops.project_heads(head["x"], l0.self_attn.in_proj_weight.detach(),
-                                            l0.self_attn.in_proj_bias.detach(), 3, self.num_heads, captions.shape[1])
-            side.signal("qkv0")
-
-        # (captured graphs only: there every tensor lives in the graph's own pool, whichever stream allocated it)
-        early = self.chain_supported() and gmap is None and not self.has_facts and stages is None and \
-            torch.cuda.is_current_stream_capturing() and bool(os.environ.get("ICK_EARLY_IN_PROJ"))
-        ee, fe, kv, ctx, side = self._encode_context(enc_tok, entities, facts, gmap,
-                                                     side_first=first_in_proj if early else None)
-        if early:
-            side.wait("qkv0")
-            x, emb, qkv = head["x"], head["emb"], head["qkv"]
-        else:
-            x, emb = embed(ee, fe)
-            qkv = None
+        # (Measured and removed in round 4: layer 0's caption embedding + in_proj at the head of the side stream -- it delays
+        # the context chain, which is what the first cross-attention waits for: forward 0.694 -> 0.715 ms.)
+        ee, fe, kv, ctx, side = self._encode_context(enc_tok, entities, facts, gmap)
+        x, emb = embed(ee, fe)
+        qkv = None
         S = kv.shape[3]
         for li, layer in enumerate(self.transformer_decoder.layers):
-            x, qkv = self._decoder_layer(li, layer, x, kv, S, qkv=qkv, want_next=True,
-                                         side=side if (li == 0 or (li == 1 and getattr(side, "split_kv", False))) else None)
+            x, qkv = self._decoder_layer(li, layer, x, kv, S, qkv=qkv, want_next=True, side=side if li == 0 else None)
             ops.stamp("main: decoder layer %d done" % li)
         side.join()
         eib = gate = None

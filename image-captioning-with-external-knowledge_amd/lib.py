@@ -85,6 +85,15 @@ class PresplitItem(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("N", i32), ("K", i32), ("src_rs", i64), ("src_cs", i64)]
 
 
+class AdamItem(C.Structure):      # ick_adam_item: a 2-D block of the bucket + the images of it the optimizer keeps current
+    _fields_ = [("off", i64), ("rows", i32), ("K", i32), ("drow0", i32), ("Nd", i32), ("pack", vp), ("pack_t", vp),
+                ("copy", vp), ("ps", vp), ("ps_t", vp), ("tr", vp), ("copy_ld", i64), ("tr_ld", i64)]
+
+
+class AdamBlock(C.Structure):     # ick_adam_block: the work of one workgroup of ick_adam_clamp_derive
+    _fields_ = [("item", i32), ("tn", i32), ("tk", i32), ("cnt4", i32), ("off4", i64), ("copy", vp)]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [
         ("Q", vp), ("K", vp), ("V", vp), ("O", vp), ("lse", vp),
@@ -184,6 +193,7 @@ SIGNATURES = {
     "ick_fact_encode_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "ick_context_gate_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "ick_adam_clamp": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, i32, vp, vp, vp],
+    "ick_adam_clamp_derive": [vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, f32, i32, vp, vp, vp],
     "ick_counter_add": [vp, u32, vp],
     "ick_timestamp": [vp, vp],
     "ick_copy_batch": [vp, vp, vp, i32, vp],

@@ -23,6 +23,14 @@ def _f32c(t, name):
     return t
 
 
+# TEMPORARY ceiling experiments (round 5): ICK_EXP=attn,wgrad=small|all,pack skips classes of launches (wrong results,
+# valid timing of everything else) to see what the step time is sensitive to
+_EXP = {"n": 0}
+for _kv in os.environ.get("ICK_EXP", "").split(","):
+    if _kv:
+        _k, _, _v = _kv.partition("=")
+        _EXP[_k] = _v or "1"
+
 # bench.py hook: when set to {"shape": (M, N, K), "events": []}, every ick_gemm launch of that shape is
 # bracketed by HIP events recorded on the launch stream (torch's current stream).
 TIMED = None
@@ -96,6 +104,8 @@ def presplit_weights(pairs):
         assert dst.numel() * dst.element_size() == presplit_bytes(src.shape[0], src.shape[1])
         it.src, it.dst, it.N, it.K = _p(src), _p(dst), src.shape[0], src.shape[1]
         it.src_rs, it.src_cs = src.stride(0), src.stride(1)
+    if _EXP.get("pack"):
+        return
     L.check(L.load().ick_presplit_weights(items, len(pairs), _stream()), "ick_presplit_weights")
 
 
@@ -141,10 +151,11 @@ def set_deterministic(on=True):
 
 
 def set_gemm_split(mode):
-    """Split-bf16 products on the large GEMM tiles (ick_set_gemm_split; default 0 = off, ICK_GEMM_SPLIT in the
-    environment): six bf16 x bf16 partial products of the exact three-way bf16 split of both fp32 operands, accumulated
-    in fp32, instead of the 16 x slower exact fp32 MFMA.  1 = where it is faster (B operand k-contiguous), 2 = every
-    large-tile problem."""
+    """Product mode of the large GEMM tiles (ick_set_gemm_split; ICK_GEMM_SPLIT in the environment; DEFAULT 1 since round
+    4): 0 = every product on the exact fp32 MFMA; 1 = six bf16 x bf16 partial products of the exact three-way bf16 split
+    of both fp32 operands, accumulated in fp32, where that is faster (B operand k-contiguous or pre-split); 2 = on every
+    large-tile problem.  Non-finite operands: the split of +-inf / NaN is (hi, 0, 0), so they propagate as in fp32; a
+    finite value within 2^-8 of FLT_MAX rounds to an infinite hi plane (documented difference to the exact mode)."""
     L.check(L.load().ick_set_gemm_split(int(mode)), "ick_set_gemm_split")
 
 
@@ -160,11 +171,11 @@ def wgrad_split(rows, n_out, k_in, grouped=False):
     """K split of a weight-gradient GEMM (reduction over `rows`): enough workgroups to fill the GPU (~1600), slices
     of at least 256 rows.  Measured (probe_ops): vocabulary 10000x300 over 1280 rows 121 us at 5 slices, 91 us at 2.
     grouped: the problem goes out in a layer's grouped launch (~1000 workgroups together): two slices are enough, more
-    only add atomics and prologues (train step 2.01 -> 1.98 ms; ICK_WGRAD_SPLIT_MAX overrides the cap)."""
+    only add atomics and prologues (train step 2.01 -> 1.98 ms)."""
     if is_deterministic():
         return 1       # slices of one reduction meet in float atomics: their order would decide the rounding
     tiles = ((n_out + 63) // 64) * ((k_in + 63) // 64)
-    cap = int(os.environ.get("ICK_WGRAD_SPLIT_MAX", "2" if grouped else "16"))
+    cap = 2 if grouped else 16
     return max(1, min(cap, rows // 256, (1600 + tiles // 2) // tiles))
 
 
@@ -283,6 +294,8 @@ def pack_weights(pairs, copies=()):
             else:
                 assert dst.is_contiguous() and dst.numel() == packed_weight_floats(src.shape[0], src.shape[1])
                 it.dst_rs = 0
+        if _EXP.get("pack"):
+            continue
         L.check(L.load().ick_pack_weights(items, len(chunk), _stream()), "ick_pack_weights")
 
 
@@ -349,34 +362,6 @@ def rowchain_fwd(a, w1p, b1, res, gamma, beta, eps, x_out, drop1=None, o_out=Non
     return (mean, rstd) if save_stats else None
 
 
-def chain_proj_on():
-    """ICK_CHAIN_PROJ=1 (experiment, measured and left off: cfg2 forward 0.728 -> 0.745 ms, train 1.747 -> 1.755): the first
-    in_proj of a stack on the row-chain kernel's projection-only form instead of the generic GEMM -- 160 priority
-    workgroups that stream the whole 900 x 300 weight each are slower than 1 200 small tiles even behind a bulk kernel."""
-    return bool(os.environ.get("ICK_CHAIN_PROJ"))
-
-
-def chain_project_heads(x, w2p, bias, nseg, H, S, out=None, slim=False):
-    """project_heads(x, W, bias, nseg, H, S) for x (B, T, d) on the row-chain kernel's projection-only form
-    (ICK_CHAIN_PROJ; w2p = pack_weights copy of the (nseg * d, d) weight): 8 rows per workgroup, raised wave priority --
-    for the first in_proj of a stack, which as a generic GEMM of ~1 200 small workgroups queues behind the bulk kernels of
-    the other stream (14 us alone, 32-48 us inside the steps)."""
-    B, T, d = x.shape
-    N2 = bias.shape[0]
-    if out is None:
-        out = torch.empty(B, nseg, H, S, DHP, device=x.device, dtype=torch.float32)
-    x2 = x.reshape(-1, d)
-    g = L.RowChainArgs()
-    g.A, g.a_rs, g.a_grp, g.a_gs = _p(x2), x2.stride(0), 0, 0
-    g.M, g.K1, g.d = x2.shape[0], d, d
-    g.w2p, g.b2, g.N2, g.y2 = _p(w2p), _p(bias), N2, _p(out)
-    g.y2_rs, g.y2_grp, g.y2_gs = 0, T, out.stride(0)
-    g.hs_dh, g.hs_dhp, g.hs_H, g.hs_S, g.hs_s0 = (N2 // nseg) // H, DHP, H, S, 0
-    g.flags = 512 | (256 if slim else 0)
-    L.check(L.load().ick_rowchain_fwd(C.byref(g), _stream()), "ick_rowchain_fwd(proj)")
-    return out
-
-
 def rowchain_bwd_supported(K0, d, N1=0):
     return bool(L.load_raw().ick_rowchain_bwd_supported(int(K0), int(d), int(N1)))
 
@@ -387,21 +372,17 @@ def ln_partials(rows, d, device):
     return torch.empty((rows + rpb - 1) // rpb, 2 * d, device=device, dtype=torch.float32)
 
 
-def rowchain_bwd(M, d, norm1, w3p, out3, dz_out, g0=None, w0p=None, dzin=None, ffn=None, norm2=None, slim=None):
+def rowchain_bwd(M, d, norm1, w3p, out3, dz_out, g0=None, w0p=None, dzin=None, ffn=None, norm2=None):
     """One launch for the data-gradient path between two attention-backward kernels (include/ick_amd.h,
     ick_rowchain_bwd).  norm1 / norm2 = dict(o, res, mean, rstd, gamma, drop, do, part): saved forward tensors of an
     add & norm, its dropout triple, and the outputs do (M, d) / part (ln_partials).  ffn = dict(w1p, w2p, act,
     gate_scale, t_out) with packed linear2.weight.T / linear1.weight.T.  g0 (M, K0) @ W0 (packed W0.T = w0p) and dzin
-    (M, d) are the two addends of the incoming gradient.  slim: the 8-wave form (ICK_CHAIN_SLIM, same bits; default off,
-    ICK_SLIM_BWD=1 turns it on).  Built in round 4 on the observation that the 16-wave kernel takes 480 of a SIMD's 512
-    registers, so its workgroups only start on CUs that hold nothing of the other stream -- and measured slower inside the
-    step all the same: 1.746 against 1.700 ms (profiles/r04_y_ab_slim_bwd.txt); two units per wave, every partial tile
-    through LDS, cost more than the earlier start gains."""
+    (M, d) are the two addends of the incoming gradient.  (An 8-wave form of this kernel was built in round 4 -- the 16-wave
+    one takes 480 of a SIMD's 512 registers, so its workgroups only start on CUs that hold nothing of the other stream --
+    and measured slower inside the step all the same, 1.746 against 1.700 ms, profiles/r04_y_ab_slim_bwd.txt; removed.)"""
     a = L.RowChainBwdArgs()
     a.M, a.d = M, d
-    if slim is None:
-        slim = os.environ.get("ICK_SLIM_BWD", "0") not in ("", "0")
-    a.flags = 256 if slim else 0
+    a.flags = 0
     seeds = []
 
     def norm(prefix, n):
@@ -456,6 +437,8 @@ def attention_raw(Q, K, V, O, B, H, T, S, dh, q_bs, q_hs, q_ts, k_bs, k_hs, k_ss
     a.scale = 1.0 / math.sqrt(dh)
     a.causal, a.q_pos0, a.kv_len = int(causal), q_pos0, _p(kv_len)
     _drop(a, drop)
+    if _EXP.get("attn"):
+        return O
     L.check(L.load().ick_attention(C.byref(a), _stream()), "ick_attention")
     return O
 
@@ -704,6 +687,8 @@ def attention_heads_bwd(q, kv, O, dO, lse, dQ, dK, dV, H, dh, T, S, q_seg=0, k_s
     a.scale = 1.0 / math.sqrt(dh)
     a.causal, a.q_pos0 = int(causal), 0
     _drop(a, drop)
+    if _EXP.get("attn"):
+        return
     L.check(L.load().ick_attention_bwd(C.byref(a), _stream()), "ick_attention_bwd")
 
 
@@ -829,30 +814,27 @@ class SideStream:
                          # allocator cannot hand their memory to the main stream meanwhile (also under capture)
         self.deferred = []
         self.group = []  # weight-gradient problems (ick_gemm_args) waiting for the next flush_group()
-        self.late = []   # (fn, tensors) enqueued with the next grouped launch
         self.signals = {}
 
     def add_problem(self, args, *tensors):
         """Queue a GEMM whose operands are complete on the main stream by the next flush_group()."""
+        if _EXP.get("wgrad") == "all" or (_EXP.get("wgrad") == "small" and not args.b_ps):
+            return
         self.group.append(args)
         self.keep.extend(t for t in tensors if t is not None)
 
     def flush_group(self):
         """One grouped launch (ick_gemm_grouped) of the queued problems on the side stream, ordered after
         everything enqueued so far on the main stream; like submit() it is enqueued at the next flush()."""
-        if self.group or self.late:
+        if self.group:
             problems, self.group = self.group, []
-            late, self.late = self.late, []
 
             def launch():
                 stamp("side: group of %d starts" % len(problems))
-                if problems:
-                    gemm_grouped(problems)
-                for fn, _ in late:
-                    fn()
+                gemm_grouped(problems)
                 stamp("side: group of %d done" % len(problems))
 
-            self.deferred.append((self.mark(), launch, tuple(t for _, ts in late for t in ts)))
+            self.deferred.append((self.mark(), launch, ()))
 
     def flush_group_here(self):
         """The queued problems as one grouped launch on the CALLER's stream, right now: for the tail of a pass, where the
@@ -899,12 +881,6 @@ class SideStream:
     def submit(self, fn, *tensors):
         self.deferred.append((self.mark(), fn, tensors))
 
-    def submit_with_group(self, fn, *tensors):
-        """Side work that may wait for the layer's grouped launch: it shares that launch's dependency point, so
-        the main-stream kernel that produced its input does not become a fork point of the captured graph
-        (each one costs the main chain ~4 us)."""
-        self.late.append((fn, tensors))
-
     def flush(self):
         work, self.deferred = self.deferred, []
         for ev, fn, tensors in work:
@@ -941,7 +917,7 @@ def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False, gro
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
         split = max(1, min(8, 480 // tiles, M // 512))
         wg = gemm_args(dy, x, dw, N, K, M, 1, dy.stride(0), 1, x.stride(0), dw.stride(0), atomic=True,
-                       split_k=int(os.environ.get("ICK_VOCAB_WGRAD_SPLIT", split)), b_ps=xt_ps)
+                       split_k=split, b_ps=xt_ps)
         if db is not None:
             extra.append(colsum_problem(dy, db, split_k=max(1, min(16, M // 256))))
     elif dw is not None:
@@ -982,7 +958,7 @@ def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False, gro
             split = max(1, min(8, (N + 150) // 300))
         if wt_ps is not None and split > 1 and gemm_split_mode() >= 1 and K <= 320:
             # the pre-split kernel's 64 x 320 tile covers every output column: ~256 workgroups = row tiles x K slices
-            split = int(os.environ.get("ICK_VOCAB_DGRAD_SPLIT", max(1, min(16, N // 512, 256 // ((M + 63) // 64)))))
+            split = max(1, min(16, N // 512, 256 // ((M + 63) // 64)))
         if split > 1:
             if dx is None:
                 dx = torch.zeros(M, K, device=dy.device, dtype=torch.float32)
@@ -1050,6 +1026,17 @@ def adam_clamp(p, g, m, v, step, lr, clip=5.0, gscale=1.0, beta1=0.9, beta2=0.99
     scaled by gscale (/ the device scalar gscale_den, if given) before the clamp."""
     L.check(L.load().ick_adam_clamp(_p(p), _p(g), _p(m), _p(v), p.numel(), gscale, clip, lr, beta1, beta2, eps, step,
                                     _p(step_tensor), _p(gscale_den), _stream()), "ick_adam_clamp")
+
+
+def adam_clamp_derive(p, g, m, v, items_dev, blocks_dev, n_blocks, step, lr, clip=5.0, gscale=1.0, beta1=0.9, beta2=0.999,
+                      eps=1e-8, step_tensor=None, gscale_den=None, nbytes=0):
+    """adam_clamp over the whole bucket + the re-laid-out copies of the updated weights in the same pass
+    (ick_adam_clamp_derive; items_dev / blocks_dev: device arrays of ick_adam_item / ick_adam_block built by
+    training.DerivedWeights).  nbytes: the launch's algorithmic bytes, for profiling.py."""
+    L.ADAM_DERIVE_BYTES = nbytes
+    L.check(L.load().ick_adam_clamp_derive(_p(p), _p(g), _p(m), _p(v), _p(items_dev), _p(blocks_dev), n_blocks, gscale,
+                                           clip, lr, beta1, beta2, eps, step, _p(step_tensor), _p(gscale_den), _stream()),
+            "ick_adam_clamp_derive")
 
 
 def counter_add(counter, inc=1):

@@ -93,6 +93,9 @@ def classify(name, args):
         return "packed cross entropy (+ gradient)", 4.0 * B * Lc * Vx * (2 if args[11] else 1), "byte"
     if name == "ick_adam_clamp":
         return "clamp + Adam", 4.0 * args[4] * 7, "byte"
+    if name == "ick_adam_clamp_derive":
+        # the seven streams of the update + every image of the updated weights (packed, transposed, bf16 planes)
+        return "clamp + Adam + re-laid-out weight copies", float(getattr(L, "ADAM_DERIVE_BYTES", 0)), "byte"
     if name == "ick_decode_layers":
         c = _struct(args[0])
         kv = 4.0 * c.R * c.layers * 2 * c.H * c.S * 32

@@ -72,8 +72,6 @@ def _context_encoder_fwd(dec, stack, x, tape_list, ds, pk=None, tag="e", out=Non
              "d2": ds.site(layer.dropout2.p)}
         if qkv is not None:
             t["qkv"] = qkv
-        elif pk is not None and ops.chain_proj_on():
-            t["qkv"] = ops.chain_project_heads(x, pk[(tag, li, "si")], _p(layer.self_attn.in_proj_bias), 3, H, T, slim=slim)
         else:
             t["qkv"] = ops.project_heads(x, _p(layer.self_attn.in_proj_weight), _p(layer.self_attn.in_proj_bias), 3, H, T)
         qkv = None
@@ -126,8 +124,6 @@ def _decoder_self_block(dec, li, layer, x, ds, pk=None, qkv=None):
          "d_ff": ds.site(layer.dropout.p), "d3": ds.site(layer.dropout3.p)}
     if qkv is not None:
         t["qkv"] = qkv
-    elif pk is not None and ops.chain_proj_on():
-        t["qkv"] = ops.chain_project_heads(x, pk[("d", li, "si")], _p(layer.self_attn.in_proj_bias), 3, H, T)
     else:
         t["qkv"] = ops.project_heads(x, _p(layer.self_attn.in_proj_weight), _p(layer.self_attn.in_proj_bias), 3, H, T)
     t["sa"] = torch.empty_like(x)
@@ -151,10 +147,10 @@ def _decoder_self_block(dec, li, layer, x, ds, pk=None, qkv=None):
     return t
 
 
-def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds, side=None, pk=None, qkv=None, t=None, early=None):
+def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds, side=None, pk=None, qkv=None, t=None):
     """Returns (x, qkv of the next layer or None).  pk: packed weights -> row-chain launches (see above); then the
     in_proj of layer li + 1 rides on this layer's linear2 + norm3 launch.  t: the tape dict of a self-attention block
-    that already ran (on the stream `early`, joined here)."""
+    that already ran."""
     H, d = dec.num_heads, dec.emb_dim
     dh = d // H
     B, T, _ = x.shape
@@ -166,8 +162,6 @@ def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds, side=None, pk=No
         for k in ("o2", "x2", "o3"):
             t[k] = torch.empty_like(x)
         ops.stamp("fwd: layer %d reaches cross-attention" % li)
-        if early is not None:
-            early.join()
         if side is not None:
             side.wait_or_join("ctx")    # the context rows of kv come from the side stream (its tail may still run)
         ops.attention_heads(t["qc"], kv, t["ca"], H, dh, T, S, 0, 2 * li, 2 * li + 1, lse=t["lse_c"], drop=t["d_ca"])
@@ -189,8 +183,6 @@ def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds, side=None, pk=No
         tape_list.append(t)
         return x3, qkv_n
     ops.stamp("fwd: layer %d reaches cross-attention" % li)
-    if early is not None:
-        early.join()
     if side is not None:
         side.wait_or_join("ctx")    # the context rows of kv come from the side stream (its tail may still run)
     ops.attention_heads(t["qc"], kv, t["ca"], H, dh, T, S, 0, 2 * li, 2 * li + 1, lse=t["lse_c"], drop=t["d_ca"])
@@ -206,11 +198,14 @@ def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds, side=None, pk=No
 
 
 def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gmap, seed=0, epoch=None,
-                      fresh_pack=False, overlap=False, feats=None, conv1=None, side_tail=None):
+                      fresh_pack=False, overlap=False, feats=None, conv1=None, side_tail=None, derived=None):
     """Teacher-forced forward on already length-sorted inputs; returns (scores, tape).  Dropout is
     active iff the module is in train() mode (masks derive from `seed` + the device counter `epoch`).
     fresh_pack: rebuild the packed cross-K/V / transposed predicate weights from the live parameters
     (needed when they are updated behind torch's version counters, and inside captured graphs).
+    derived: TrainStep's persistent re-laid-out copies of the weights (DerivedWeights: packed row-chain copies, forward
+    and transposed, the gathered cross K/V weight / bias and the bf16 planes of the large GEMMs' weights), kept current by
+    the optimizer kernel itself -- no packing launch at all in this pass.
     overlap: run the context-encoder chain (small, latency-bound kernels) on a second stream beside the
     image-row K/V projection and the first self-attention block (for captured graphs; eager launches are
     host-bound and gain nothing).
@@ -239,28 +234,24 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     side = ops.SideStream(priority=-1) if overlap else None
     if side is None and side_tail is not None:
         side_tail()
-    # ICK_SIDE_HEAD=1 (measured, left off): the entity / fact encoders, the packed K/V weight and the first packed copies
-    # open the side stream while the main stream starts with Encoder.conv1 at once.  The ~10 small kernels then sit
-    # behind conv1's 490 workgroups: the context chain starts at 158 us instead of 43 us (train step 2.00 -> 2.06 ms).
-    head_on_side = side is not None and feats is not None and bool(os.environ.get("ICK_SIDE_HEAD"))
-    conv1_done = False
-    if head_on_side:
-        ev0 = side.mark()
-        cw, cb = conv1[0], conv1[1]
-        Cc = feats.shape[1]
-        ops.gemm_raw(feats, cw.view(d, Cc), mem, B * P, d, Cc, 1, P, Cc, 1, d, bias=cb, a_grp=P, a_gs=Cc * P,
-                     c_grp=P, c_gs=S * d, b_ps=conv1[2] if len(conv1) > 2 else None)
-        conv1_done = True
 
     chain = dec.chain_supported()
-    staged = chain and fresh_pack and overlap
+    staged = chain and fresh_pack and overlap and derived is None
     first = lambda k: k[0] != "d" or (k[1] == 0 and k[2] in ("so", "cq", "si"))     # context encoders + layer 0's self block
+    split_on = ops.gemm_split_mode() >= 1 and not ops.is_deterministic()
 
-    def head():
-        ee = ops.entity_encode(dec.variant, entities, _p(dec.entity_encoder.type_embedding.weight), d,
-                               facts=facts if dec.has_facts else None,
-                               word_emb=_p(dec.word_embedding.weight) if dec.variant == "news" else None)
-        fe = ops.fact_encode(facts, ee, _p(dec.predicate_embedding.weight)) if dec.has_facts else None
+    ee = ops.entity_encode(dec.variant, entities, _p(dec.entity_encoder.type_embedding.weight), d,
+                           facts=facts if dec.has_facts else None,
+                           word_emb=_p(dec.word_embedding.weight) if dec.variant == "news" else None)
+    fe = ops.fact_encode(facts, ee, _p(dec.predicate_embedding.weight)) if dec.has_facts else None
+    if derived is not None:
+        wkv, bkv, pk = derived.wkv, derived.bkv, derived.pk
+        m["pkb"] = derived.pkb
+        if split_on:
+            m["wkv_ps"] = derived.wkv_ps
+            if B * L >= 256:
+                m["vocab_ps"], m["vocab_t_ps"] = derived.vocab_ps, derived.vocab_t_ps
+    else:
         copies = []
         if fresh_pack:
             layers_ = dec.transformer_decoder.layers
@@ -278,73 +269,49 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
                 bkv = torch.cat([_p(l.multihead_attn.in_proj_bias)[d:] for l in layers_])
         else:
             wkv, bkv = dec._packed_cross_kv()
-        # packed weight copies of the row-chain launches.  Inside the captured step they are refreshed in three
-        # launches placed where they cost nothing: the context encoders' copies now (the side chain needs them
-        # first), the decoder layers' after Encoder.conv1 has been enqueued, the transposed copies of the backward
-        # chains on the side stream once the context chain is done (it idles until the backward pass).
+        # packed weight copies of the row-chain launches.  Inside a captured step that does not keep them current itself
+        # (derived is None) they are refreshed in three launches placed where they cost least: the context encoders'
+        # copies now (the side chain needs them first), the decoder layers' after Encoder.conv1 has been enqueued, the
+        # transposed copies of the backward chains on the side stream once the context chain is done.
         pk = dec._chain_pack(fresh=fresh_pack, subset=first if staged else None, copies=copies) if chain else None
+
+    def kv_presplit():
         # pre-split copy (three bf16 planes) of the all-layer cross K/V weight for the image rows' projection (ick_gemm's
-        # b_ps, csrc/gemm_ps.hip); fc_vocab's copy is made on the side stream behind the context chain (vocab_presplit)
-        if not late_kv_presplit:
-            kv_presplit(wkv)
-        return ee, fe, wkv, bkv, pk
-
-    # with a side stream the context chain (the longest dependency of the first phase) forks behind head(): the K/V
-    # weight's pre-split copy, which only the main stream's projection reads, is made behind the fork (5 us earlier start)
-    late_kv_presplit = side is not None and not head_on_side and not os.environ.get("ICK_EARLY_KV_PRESPLIT")
-
-    def kv_presplit(wkv):
-        if ops.gemm_split_mode() >= 1 and not ops.is_deterministic():
+        # b_ps, csrc/gemm_ps.hip); with a side stream it is made behind the fork: only the main stream reads it
+        if derived is None and split_on:
             if fresh_pack:
                 m["wkv_ps"] = ops.presplit_buffer(nseg * d, d, dev)
                 ops.presplit_weights([(wkv, m["wkv_ps"])])
             else:
                 m["wkv_ps"] = dec._cross_kv_presplit(wkv)
 
-    if head_on_side:
-        with side.fork(after=ev0):
-            ee, fe, wkv, bkv, pk = head()
-            side.signal("head")
-    else:
-        ee, fe, wkv, bkv, pk = head()
-    # the context chains run beside Encoder.conv1 and the image K/V projection: 8-wave workgroups find room there
-    slim_ctx = overlap and not os.environ.get("ICK_NO_SLIM")
+    if side is None:
+        kv_presplit()
 
     def vocab_presplit():
-        # fc_vocab's pre-split copy: nothing needs it before the score head, so it is made where the side stream idles
-        if ops.gemm_split_mode() >= 1 and not ops.is_deterministic() and B * L >= 256:
+        # fc_vocab's pre-split copies: nothing needs them before the score head, so they are made where the side stream
+        # idles.  The transposed one is the B operand of the data gradient dh = dscores @ W on the pre-split kernel (128 x 80
+        # tile, 40 tiles x 12 K slices: cfg2 train step 1.770 -> 1.741 ms, profiles/r04_y_ab_vocab_dgrad_ps.txt)
+        if derived is None and split_on and B * L >= 256:
             if fresh_pack:
                 m["vocab_ps"] = ops.presplit_buffer(V, d, dev)
-                ops.presplit_weights([(_p(dec.fc_vocab.weight), m["vocab_ps"])])
+                m["vocab_t_ps"] = ops.presplit_buffer(d, V, dev)
+                ops.presplit_weights([(_p(dec.fc_vocab.weight), m["vocab_ps"]),
+                                      (_p(dec.fc_vocab.weight).t(), m["vocab_t_ps"])])
             else:
                 m["vocab_ps"] = dec._vocab_presplit()
-            if fresh_pack and os.environ.get("ICK_VOCAB_DGRAD_PS", "1") != "0":
-                # the data gradient dh = dscores @ W on the pre-split kernel takes W^T as its B operand: on the 128 x 80
-                # tile (40 tiles x 12 K slices = 480 workgroups, two per CU) the cfg2 train step is 1.770 -> 1.741 ms
-                # (profiles/r04_y_ab_vocab_dgrad_ps.txt; on the 64 x 320 and 128 x 128 tiles it gained nothing)
-                m["vocab_t_ps"] = ops.presplit_buffer(d, V, dev)
-                ops.presplit_weights([(_p(dec.fc_vocab.weight).t(), m["vocab_t_ps"])])
 
     def entity_chain():
         ops.stamp("side: context chain starts")
-        # the stack's last add & norm writes the entity rows of the memory buffer directly
+        # the stack's last add & norm writes the entity rows of the memory buffer directly; beside Encoder.conv1 and the
+        # image K/V projection the chain runs in its 8-wave form, which finds room on the CUs the bulk GEMMs occupy
         ctx_e = _context_encoder_fwd(dec, dec.transformer_encoder_entities, ee, tape.enc_layers["entities"], ds, pk=pk,
-                                     tag="e", out=mem[:, P:P + K], slim=slim_ctx)
+                                     tag="e", out=mem[:, P:P + K], slim=overlap)
         ops.project_heads(ctx_e, wkv, bkv, nseg, H, S, out=kv, s0=P, grp=K)
         if side is not None:
             side.signal("ctx")      # the first cross-attention waits for this point, not for the packing / zeroing below
         ops.stamp("side: context chain done")
-        if not tail_on_main:
-            bulk_tail()
-
-    # Bulk work nothing waits for before the score head / the backward pass: the transposed packed copies of the backward
-    # chains, fc_vocab's pre-split copies, the zero fills.  ICK_TAIL_ON_MAIN=1 (experiment, measured and left off: train
-    # step 1.764 -> 1.817 ms): on the main stream between Encoder.conv1 and the image K/V projection instead of on the
-    # side stream behind the context chain -- there they delay the K/V projection, and the decoder's first
-    # cross-attention waits for that as much as for the context chain.
-    tail_on_main = side is not None and staged and bool(os.environ.get("ICK_TAIL_ON_MAIN"))
-
-    def bulk_tail():
+        # bulk work nothing waits for before the score head / the backward pass
         if staged and dec.chain_bwd_supported():
             m["pkb"] = dec._chain_pack(fresh=True, bwd=True, extra=[(("kv", "T"), wkv.t())])
         vocab_presplit()
@@ -353,26 +320,10 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
 
     def fact_chain():
         ctx_f = _context_encoder_fwd(dec, dec.transformer_encoder_facts, fe, tape.enc_layers["facts"], ds, pk=pk,
-                                     tag="f", out=mem[:, P + K:], slim=slim_ctx)
+                                     tag="f", out=mem[:, P + K:], slim=overlap)
         ops.project_heads(ctx_f, wkv, bkv, nseg, H, S, out=kv, s0=P + K, grp=Fn)
 
-    # Decoder layer 0's self-attention block (caption embedding, in_proj, causal attention, out-projection + norm1 +
-    # q-projection) reads neither the image nor the context rows, so a third branch could run it beside Encoder.conv1.
-    # Measured and left off (ICK_EARLY_SELF=1 turns it on): with three concurrent branches in the captured graph every
-    # kernel of the step runs ~2x slower on ROCm 7.2 (train step 2.03 -> 3.65 ms).
-    early = ops.SideStream(priority=-1) if (overlap and os.environ.get("ICK_EARLY_SELF")) else None
     pe = dec.pos_encoder.pe.view(-1, d)
-    head0 = {}
-
-    def layer0_self_block():
-        m["d_pos"] = ds.site(dec.pos_encoder.dropout.p)
-        x0 = ops.caption_embed(captions, caption_masks, _p(dec.word_embedding.weight), ee, fe, pe, V,
-                               dec.word_map["<pad>"], math.sqrt(d), drop=m["d_pos"])
-        head0["x"] = x0
-        head0["t"] = _decoder_self_block(dec, 0, dec.transformer_decoder.layers[0], x0, ds, pk, None)
-
-    if early is not None:
-        early.submit(layer0_self_block, ee, fe, captions, caption_masks)
     if feats is not None:
         img = mem[:, :P]
     else:
@@ -381,9 +332,7 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         side.submit(entity_chain, ee, fe, mem, kv, wkv, bkv, img)
     else:
         entity_chain()
-    if conv1_done:
-        pass
-    elif feats is not None:
+    if feats is not None:
         cw, cb = conv1[0], conv1[1]
         Cc = feats.shape[1]
         ops.gemm_raw(feats, cw.view(d, Cc), mem, B * P, d, Cc, 1, P, Cc, 1, d, bias=cb, a_grp=P, a_gs=Cc * P,
@@ -392,17 +341,10 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         mem[:, :P].copy_(img)
     if side is not None:
         side.flush()     # enqueued after the main stream's next kernel (see SideStream)
-    if late_kv_presplit:
-        kv_presplit(wkv)
-    if head_on_side:
-        side.wait("head")    # the main stream needs the packed K/V weight, the entity rows and the first copies from here on
-    if early is not None:
-        early.flush()
+        kv_presplit()
     if staged:
         dec._chain_pack(fresh=True, subset=lambda k: not first(k))
-        if tail_on_main:
-            bulk_tail()
-    elif pk is not None and dec.chain_bwd_supported():
+    elif derived is None and pk is not None and dec.chain_bwd_supported():
         m["pkb"] = dec._chain_pack(fresh=fresh_pack, bwd=True, extra=[(("kv", "T"), wkv.t())])
     if dec.has_facts:
         # on the main stream, beside the entity chain on the side stream: two chains of small kernels overlap well
@@ -413,20 +355,23 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     # a 5000-workgroup GEMM beside a chain of small kernels delays the chain by about its own duration either way.
     ops.project_heads(img, wkv, bkv, nseg, H, S, out=kv, s0=0, grp=P, w_ps=m.get("wkv_ps"))
     ops.stamp("fwd: image K/V projection done")
-    if early is None:
-        layer0_self_block()
-    x = head0["x"]
+    m["d_pos"] = ds.site(dec.pos_encoder.dropout.p)
+    x = ops.caption_embed(captions, caption_masks, _p(dec.word_embedding.weight), ee, fe, pe, V,
+                          dec.word_map["<pad>"], math.sqrt(d), drop=m["d_pos"])
+    t0 = _decoder_self_block(dec, 0, dec.transformer_decoder.layers[0], x, ds, pk, None)
     qkv = None
     for li, layer in enumerate(dec.transformer_decoder.layers):
         x, qkv = _decoder_layer_fwd(dec, li, layer, x, kv, S, tape.dec_layers, ds, side=side if li == 0 else None,
-                                    pk=pk, qkv=qkv, t=head0["t"] if li == 0 else None,
-                                    early=early if li == 0 else None)
+                                    pk=pk, qkv=qkv, t=t0 if li == 0 else None)
     if side is not None:
         side.join()
     ops.stamp("fwd: decoder layers done")
     eib = gate = hv = None
     if dec.has_facts:
-        pred_wt = _p(dec.fc_predicate.weight).t().contiguous() if fresh_pack else dec._pred_wt()
+        if derived is not None:
+            pred_wt = derived.pred_wt
+        else:
+            pred_wt = _p(dec.fc_predicate.weight).t().contiguous() if fresh_pack else dec._pred_wt()
         eib, gate = ops.context_indicators(captions, facts, K, V, pred_wt, _p(dec.fc_predicate.bias), mode=0)
         hv = ops.mul(x, gate)
     Vx = V + K + Fn
@@ -497,7 +442,6 @@ def _context_encoder_bwd(dec, stack, tapes, dx, grads, pkb=None, tag="e", g_firs
     layers = list(stack.layers)
     if pkb is not None:
         dev = tapes[0]["x"].device
-        tail_on_main = not os.environ.get("ICK_NO_TAIL_ON_MAIN")
         dz, g0, w0p = dx, None, None
         if g_first is not None:
             dz, (g0, w0p) = None, g_first
@@ -521,7 +465,7 @@ def _context_encoder_bwd(dec, stack, tapes, dx, grads, pkb=None, tag="e", g_firs
             _lin_bwd(grads, dpre, t["x1"].view(M, d), layer.linear1.weight, layer.linear1.bias, need_dx=False)
             _lin_bwd(grads, n1["do"], t["sa"].view(M, d), layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias,
                      need_dx=False)
-            if ops.SIDE is not None and not (li == 0 and tail_on_main):
+            if ops.SIDE is not None and li > 0:
                 # everything queued so far only needs the chain launch above: it goes out now, beside the attention
                 # backward (the in_proj weight gradient follows with the next group) -- the side stream's last group,
                 # which nothing on the main stream overlaps any more, shrinks to one problem
@@ -540,13 +484,10 @@ def _context_encoder_bwd(dec, stack, tapes, dx, grads, pkb=None, tag="e", g_firs
                 dx = _lin_bwd(grads, dqkv.view(M, 3 * d), t["x"].view(M, d), layer.self_attn.in_proj_weight,
                               layer.self_attn.in_proj_bias, dx=dz_out, acc=True).view(B, T, d)
                 if ops.SIDE is not None:
-                    if tail_on_main:
-                        # the stack's first layer is the last thing the backward pass computes: the main stream has
-                        # nothing left while the side stream still works off the layers above -- its weight gradients
-                        # run here instead of queueing behind them
-                        ops.SIDE.flush_group_here()
-                    else:
-                        ops.SIDE.flush_group()
+                    # the stack's first layer is the last thing the backward pass computes: the main stream has
+                    # nothing left while the side stream still works off the layers above -- its weight gradients
+                    # run here instead of queueing behind them
+                    ops.SIDE.flush_group_here()
         return dx
     for layer, t in zip(reversed(layers), reversed(tapes)):
         B, T, _ = t["x"].shape
@@ -571,8 +512,7 @@ def _context_encoder_bwd(dec, stack, tapes, dx, grads, pkb=None, tag="e", g_firs
     return dx
 
 
-def _decoder_layer_bwd_chain(dec, li, layer, t, state, dkv_rows, kv, S, grads, pkb, mem2=None, mem_t_ps=None,
-                             on_done=None):
+def _decoder_layer_bwd_chain(dec, li, layer, t, state, dkv_rows, kv, S, grads, pkb, mem2=None, mem_t_ps=None):
     """Backward of decoder layer li as two ops.rowchain_bwd launches around the cross-attention backward + the
     self-attention backward.  state = (dz, g0, w0p): the residual-path gradient of this layer's output, and -- from the
     layer above -- the in_proj gradient whose data gradient rides on this layer's first launch.  Returns the state
@@ -602,20 +542,18 @@ def _decoder_layer_bwd_chain(dec, li, layer, t, state, dkv_rows, kv, S, grads, p
     # The layer's weight gradients go out in two grouped launches: linear2 / linear1 / cross out-projection + the two
     # norms' partials right behind the chain launch above, the rest at the layer's end (the side stream finishes last:
     # starting its work earlier shortens the step, 651 -> 654 k decode-steps/s; a third launch right behind the
-    # cross-attention backward costs more in fork points than it gains: 645 k).  ICK_BWD_SUBGROUPS=0 / 2 for A/B.
-    sub = int(os.environ.get("ICK_BWD_SUBGROUPS", "1")) if ops.SIDE is not None else 0
-    if sub >= 1:
+    # cross-attention backward -- the K/V-projection weight gradient behind its operand -- costs more in fork points than
+    # it gains: round 2 645 k, round 5 1.733 -> 1.739 ms, gpurun_out/r5_c1_ab_subgroups.txt)
+    if ops.SIDE is not None:
         ops.SIDE.flush_group()
     dq = torch.empty(B, T, d, device=dev, dtype=torch.float32)
     c0 = 2 * li * d
     ops.attention_heads_bwd(t["qc"], kv, t["ca"], dca.view(B, T, d), t["lse_c"], dq, dkv_rows[:, :, c0:c0 + d],
                             dkv_rows[:, :, c0 + d:c0 + 2 * d], H, dh, T, S, 0, 2 * li, 2 * li + 1, drop=t["d_ca"])
-    if sub >= 1:
+    if ops.SIDE is not None:
         ops.SIDE.flush()
     if mem2 is not None:
         _kv_proj_param_grads(layer, li, dkv_rows, mem2, grads, d, mem_t_ps)
-    if sub >= 2:
-        ops.SIDE.flush_group()      # the K/V-projection weight gradient (the heavy one) starts right behind its operand
     n1 = _norm_args(t, 1, t["x"], layer.norm1, grads, M, d, dev)
     dsa = torch.empty(M, d, device=dev, dtype=torch.float32)
     dz_b = torch.empty(M, d, device=dev, dtype=torch.float32)
@@ -640,10 +578,6 @@ def _decoder_layer_bwd_chain(dec, li, layer, t, state, dkv_rows, kv, S, grads, p
                        layer.self_attn.in_proj_bias, dx=dz_b, acc=True).view(B, T, d)
         out = (dx0, None, None)
     if ops.SIDE is not None:
-        if on_done is not None:
-            # behind this layer's last group, in the same side-stream launch: every gradient of the layer is complete
-            # there and nothing of this pass reads the layer's parameters any more (the chains read packed copies)
-            ops.SIDE.submit_with_group(on_done)
         ops.SIDE.flush_group()          # this layer's weight gradients: one grouped launch
     return out
 
@@ -701,12 +635,12 @@ def _kv_proj_param_grads(layer, li, dkv_rows, mem2, grads, d, mem_t_ps=None):
             # 5 x 4 tiles of 128 x 80 (two workgroups per CU): K slices so that ~320 workgroups exist (sweep inside the
             # step, profiles/r04_y_ab_bwd_splits.txt: 16 slices 1.695-1.705 ms, 12 / 24 / 32 slices 1.711-1.720)
             split = max(1, min(32, 320 // (((2 * d + 127) // 128) * ((d + 79) // 80)), rows // 256))
-            wg = ops.gemm_args(sl, mem2, gw[d:], 2 * d, d, rows, 1, sl.stride(0), 1, d, d, atomic=True,
-                               split_k=int(os.environ.get("ICK_KV_WGRAD_SPLIT", split)), b_ps=mem_t_ps)
+            wg = ops.gemm_args(sl, mem2, gw[d:], 2 * d, d, rows, 1, sl.stride(0), 1, d, d, atomic=True, split_k=split,
+                               b_ps=mem_t_ps)
             extra = [] if gb is None else [ops.colsum_problem(sl, gb[d:], split_k=max(1, min(16, rows // 512)))]
         else:
             wg = ops.gemm_args(sl, mem2, gw[d:], 2 * d, d, rows, 1, sl.stride(0), 1, d, d, atomic=True,
-                               split_k=1 if ops.is_deterministic() else int(os.environ.get("ICK_KV_WGRAD_SPLIT", "16")),
+                               split_k=1 if ops.is_deterministic() else 16,
                                colsum_a=None if gb is None else gb[d:])
             extra = []
         if ops.SIDE is not None:
@@ -722,7 +656,7 @@ def _kv_proj_param_grads(layer, li, dkv_rows, mem2, grads, d, mem_t_ps=None):
 def _memory_t_presplit(m, B, S, d):
     """Pre-split copy of memory^T (csrc/gemm_ps.hip's B operand for the cross K/V weight gradients), made where the side
     stream starts its backward work; None in the exact / deterministic modes."""
-    if ops.gemm_split_mode() < 1 or ops.is_deterministic() or os.environ.get("ICK_NO_KV_WGRAD_PS") or B * S < 2048:
+    if ops.gemm_split_mode() < 1 or ops.is_deterministic() or B * S < 2048:
         return None
     mem2 = m["mem"].view(B * S, d)
     buf = ops.presplit_buffer(d, B * S, mem2.device)
@@ -742,7 +676,7 @@ def _rows_t_presplit(x2):
     csrc/gemm_ps.hip's kernel -- the vocabulary's (10 000 x 300 outputs over the 1 280 caption rows), made on the side
     stream in front of that gradient; None in the exact / deterministic modes and for few rows."""
     rows, d = x2.shape
-    if ops.gemm_split_mode() < 1 or ops.is_deterministic() or os.environ.get("ICK_NO_VOCAB_WGRAD_PS") or rows < 1024:
+    if ops.gemm_split_mode() < 1 or ops.is_deterministic() or rows < 1024:
         return None
     buf = ops.presplit_buffer(d, rows, x2.device)
 
@@ -756,17 +690,14 @@ def _rows_t_presplit(x2):
     return buf
 
 
-def backward_from_tape(dec, tape, dscores, grads, overlap=True, want_image_grad=False, early_update=None):
+def backward_from_tape(dec, tape, dscores, grads, overlap=True, want_image_grad=False):
     """Accumulate parameter gradients of `dec` into `grads` (dict id(param) -> zero-initialised
     tensor shaped like the parameter; frozen parameters are simply absent).  With `overlap` the weight /
     bias gradients of the Linear layers run on a second HIP stream beside the data-gradient chain.
     want_image_grad: also return the gradient of the (length-sorted) image memory rows (B, P, d) -- what
     fine_tune_encoder=True back-propagates into Encoder.conv1; the default step skips that 13.5 GFLOP GEMM because
-    the reference never uses the result (geo-aware/train.py:93-100,283-284).
-    early_update: {"head": fn, "layer": fn(li)} -- called (with overlap only) on the SIDE stream once every gradient of
-    fc_vocab / of decoder layer li is complete and nothing of this pass reads those parameters any more: TrainStep's
-    optimizer update of that part of the bucket then fills the side stream's idle gaps instead of the step's tail."""
-    bp = BackwardPass(dec, tape, dscores, grads, overlap, want_image_grad, early_update=early_update)
+    the reference never uses the result (geo-aware/train.py:93-100,283-284)."""
+    bp = BackwardPass(dec, tape, dscores, grads, overlap, want_image_grad)
     bp.early(join=False)     # one pass: the side stream is only joined at the very end
     bp.late()
     return tape.misc.get("d_img")
@@ -794,12 +725,9 @@ class BackwardPass:
     early() = score head + decoder stack, with the side stream joined at its end; late() = context encoders and
     embeddings.  The two phases may be captured into two hipGraphs."""
 
-    def __init__(self, dec, tape, dscores, grads, overlap=True, want_image_grad=False, early_update=None):
-        # ICK_BWD_SIDE_PRIO (experiment): priority of the stream that carries the bulk weight-gradient GEMMs beside the
-        # latency-bound data-gradient chain (torch: larger number = lower priority)
-        self.side_prio = int(os.environ.get("ICK_BWD_SIDE_PRIO", "0"))
-        self.side = ops.SideStream(priority=self.side_prio) if overlap else None
-        self.gen = _backward_phases(dec, tape, dscores, grads, want_image_grad, early_update if overlap else None)
+    def __init__(self, dec, tape, dscores, grads, overlap=True, want_image_grad=False):
+        self.side = ops.SideStream() if overlap else None
+        self.gen = _backward_phases(dec, tape, dscores, grads, want_image_grad)
 
     def _run(self, join):
         ops.SIDE = self.side
@@ -819,11 +747,11 @@ class BackwardPass:
             # the two phases may be captured into two graphs: each graph gets a side stream of its own (one stream
             # object forked into two captures made every kernel of both graphs run ~2.5x slower on ROCm 7.2)
             self.retired = self.side          # keeps the tensors the first phase's side work read alive
-            self.side = ops.SideStream(priority=self.side_prio)
+            self.side = ops.SideStream()
         self._run(True)
 
 
-def _backward_phases(dec, tape, dscores, grads, want_image_grad=False, early_update=None):
+def _backward_phases(dec, tape, dscores, grads, want_image_grad=False):
     m = tape.misc
     d, V, H = dec.emb_dim, dec.vocab_size, dec.num_heads
     h, ee, fe = m["h"], m["ee"], m["fe"]
@@ -859,10 +787,6 @@ def _backward_phases(dec, tape, dscores, grads, want_image_grad=False, early_upd
     else:
         dhv = _lin_bwd(grads, dsc2[:, :V], hv.view(M, d), dec.fc_vocab.weight, dec.fc_vocab.bias,
                        group_now=True, wt_ps=m.get("vocab_t_ps"), xt_ps=hv_t_ps).view(B, L, d)
-    if early_update is not None and ops.SIDE is not None:
-        # rides behind the NEXT grouped launch of the side stream (no fork point of its own: each costs the main chain
-        # ~4 us), whose dependency point lies behind the data gradient, the last reader of fc_vocab.weight
-        ops.SIDE.submit_with_group(early_update["head"])
     if dec.has_facts:
         dh = ops.mul(dhv, m["gate"])
         dgate = ops.mul(dhv, h)
@@ -891,9 +815,8 @@ def _backward_phases(dec, tape, dscores, grads, want_image_grad=False, early_upd
     if pkb is not None:
         state = (dh.view(M, d), None, None)
         for li in reversed(range(len(layers))):
-            done = functools.partial(early_update["layer"], li) if early_update is not None else None
             state = _decoder_layer_bwd_chain(dec, li, layers[li], tape.dec_layers[li], state, dkv_rows, m["kv"], S,
-                                             grads, pkb, mem2=m["mem"].view(B * S, d), mem_t_ps=mem_t_ps, on_done=done)
+                                             grads, pkb, mem2=m["mem"].view(B * S, d), mem_t_ps=mem_t_ps)
             ops.stamp("bwd: decoder layer %d done" % li)
         dx = state[0]
     else:
@@ -906,7 +829,7 @@ def _backward_phases(dec, tape, dscores, grads, want_image_grad=False, early_upd
     # context rows only (the image rows' gradient would be Encoder.conv1's, which the reference never uses)
     nctx = K + Fn
     dkv_ctx = dkv_rows[:, P:]                       # (B, nctx, 2 * layers * d) view of the K/V gradient rows
-    fuse_ctx = pkb is not None and ops.rowchain_bwd_supported(nseg * d, d, 0) and not os.environ.get("ICK_NO_CTX_FUSE")
+    fuse_ctx = pkb is not None and ops.rowchain_bwd_supported(nseg * d, d, 0)
     dctx = None
     if not fuse_ctx:
         # K = 2 * layers * d = 1800 over only B * nctx x d outputs: split the reduction (40 -> ~15 us with the fill)
@@ -984,6 +907,184 @@ def unique_parameters(dec):
 # ----------------------------------------------------------------------------------------------
 # fused data-parallel training step
 # ----------------------------------------------------------------------------------------------
+class DerivedWeights:
+    """The re-laid-out copies of the decoder's weights that a training step's kernels read, as persistent buffers which
+    the optimizer kernel itself keeps current (ops.adam_clamp_derive / ick_adam_clamp_derive): nothing re-packs a weight
+    between optimizer.step() (geo-aware/train.py:292) and the next forward pass.
+
+      pk / pkb        packed row-chain images of every nn.Linear the chains multiply with, forward and transposed
+                      (decoder._chain_pack's persistent buffers), incl. the transposed all-layer cross K/V weight
+      wkv, bkv        rows [d:3d] of every decoder layer's cross-attention in_proj gathered into one (2 * layers * d, d)
+                      weight and bias (one GEMM projects the memory for all layers)
+      wkv_ps          bf16 hi / mid / lo planes of wkv (csrc/gemm_ps.hip's B operand)
+      vocab_ps / vocab_t_ps   the planes of fc_vocab.weight and of its transpose (forward, data gradient)
+      pred_wt         fc_predicate.weight transposed (knowledge / news variants)
+
+    build() returns None when the widths do not meet the kernel's alignment rules (include/ick_amd.h); the step then keeps
+    the per-step packing launches.  refresh() fills every image from the live parameters with the stand-alone packing
+    kernels (first step, after load_state_dict, after a capture's rewound warm-up step, after outside writes)."""
+
+    @staticmethod
+    def build(ts):
+        dec = ts.dec
+        if not (dec.chain_supported() and dec.chain_bwd_supported()):
+            return None
+        try:
+            return DerivedWeights(ts)
+        except _Unsupported:
+            return None
+
+    def __init__(self, ts):
+        import ctypes as C
+        from . import lib as L
+        dec = self.dec = ts.dec
+        self.ts = ts
+        d, V = dec.emb_dim, dec.vocab_size
+        layers = list(dec.transformer_decoder.layers)
+        nseg = 2 * len(layers)
+        dev = ts.flat_p.device
+        base, nfl = ts.flat_p.data_ptr(), ts.n
+        self.wkv = torch.empty(nseg * d, d, device=dev, dtype=torch.float32)
+        self.bkv = torch.empty(nseg * d, device=dev, dtype=torch.float32)
+        self.wkv_ps = ops.presplit_buffer(nseg * d, d, dev)
+        self.vocab_ps = ops.presplit_buffer(V, d, dev)
+        self.vocab_t_ps = ops.presplit_buffer(d, V, dev)
+        self.pred_wt = None
+        if dec.has_facts:
+            w = dec.fc_predicate.weight
+            self.pred_wt = torch.empty(w.shape[1], w.shape[0], device=dev, dtype=torch.float32)
+        self.pk = dec._chain_pack()
+        self.pkb = dec._chain_pack(bwd=True, extra=[(("kv", "T"), self.wkv.t())])
+        self.stale = True
+        self._seen = None
+
+        def where(w):
+            """Float offset in the bucket of a (row slice of a) trainable parameter; None for frozen ones (their images are
+            filled by refresh() and never change)."""
+            off = (w.data_ptr() - base) // 4
+            if not (0 <= off and off + w.numel() <= nfl):
+                return None
+            if w.dim() != 2 or w.stride() != (w.shape[1], 1) or w.shape[1] % 4 or off % 4:
+                raise _Unsupported()
+            return off
+
+        items, nbytes = [], 0
+
+        def item(w, drow0=0, Nd=None, pack=None, pack_t=None, copy=None, ps=None, ps_t=None, tr=None):
+            nonlocal nbytes
+            off = where(w)
+            if off is None:
+                return
+            rows, K = w.shape
+            if (pack_t is not None and (drow0 % 4 or rows % 4)) or (ps_t is not None and (drow0 % 8 or rows % 8)):
+                raise _Unsupported()
+            it = L.AdamItem()
+            it.off, it.rows, it.K, it.drow0, it.Nd = off, rows, K, drow0, Nd if Nd is not None else rows
+            for name, t in (("pack", pack), ("pack_t", pack_t), ("copy", copy), ("ps", ps), ("ps_t", ps_t), ("tr", tr)):
+                if t is not None:
+                    setattr(it, name, t.data_ptr())
+                    nbytes += rows * K * (6 if name in ("ps", "ps_t") else 4)
+            if copy is not None:
+                it.copy_ld = copy.stride(0)
+            if tr is not None:
+                it.tr_ld = tr.stride(0)
+            items.append(it)
+
+        for key, w in dec._chain_items():
+            item(w.detach(), pack=self.pk[key], pack_t=self.pkb[(key[0], key[1], key[2] + "T")])
+        for i, l in enumerate(layers):
+            item(l.multihead_attn.in_proj_weight.detach()[d:], drow0=2 * d * i, Nd=nseg * d, copy=self.wkv, ps=self.wkv_ps,
+                 pack_t=self.pkb[("kv", "T")])
+        item(dec.fc_vocab.weight.detach(), ps=self.vocab_ps, ps_t=self.vocab_t_ps)
+        if dec.has_facts:
+            item(dec.fc_predicate.weight.detach(), tr=self.pred_wt)
+        # flat runs that are mirrored into a plain copy: rows [d:3d] of the cross-attention in_proj biases -> bkv
+        mirrors = []
+        for i, l in enumerate(layers):
+            b = l.multihead_attn.in_proj_bias.detach()[d:]
+            off = (b.data_ptr() - base) // 4
+            if 0 <= off and off + b.numel() <= nfl:
+                if off % 4 or b.numel() % 4:
+                    raise _Unsupported()
+                mirrors.append((off, off + b.numel(), self.bkv[2 * d * i:].data_ptr()))
+        # ---- the cover of [0, n): tiles of the items, flat runs of <= 1024 float4 everywhere else
+        blocks = []
+
+        def flat(lo, hi, copy=0):
+            while lo < hi:
+                c = min(4096, hi - lo)
+                bl = L.AdamBlock()
+                bl.item, bl.cnt4, bl.off4, bl.copy = -1, c // 4, lo // 4, copy
+                blocks.append(bl)
+                lo += c
+                if copy:
+                    copy += 4 * c
+
+        cuts = sorted([(it.off, it.off + it.rows * it.K, "item", i) for i, it in enumerate(items)] +
+                      [(lo, hi, "mirror", ptr) for lo, hi, ptr in mirrors])
+        pos = 0
+        for lo, hi, kind, what in cuts:
+            if lo < pos:
+                raise _Unsupported()       # overlapping views of one parameter
+            flat(pos, lo)
+            if kind == "mirror":
+                flat(lo, hi, what)
+            else:
+                it = items[what]
+                for tn in range(it.drow0 // 64, (it.drow0 + it.rows - 1) // 64 + 1):
+                    for tk in range((it.K + 63) // 64):
+                        bl = L.AdamBlock()
+                        bl.item, bl.tn, bl.tk = what, tn, tk
+                        blocks.append(bl)
+            pos = hi
+        flat(pos, nfl)
+        assert nfl % 4 == 0
+        self.n_blocks = len(blocks)
+        self.nbytes = 28 * nfl + nbytes      # seven streams of the update + the images' bytes (profiling)
+
+        def upload(structs, typ):
+            arr = (typ * max(1, len(structs)))(*structs)
+            return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+
+        self.items_dev = upload(items, L.AdamItem)
+        self.blocks_dev = upload(blocks, L.AdamBlock)
+        self.n_items = len(items)
+
+    def _key(self):
+        return tuple(p._version for p in self.ts.params) + (self.dec.__dict__.get("_param_epoch", 0),)
+
+    def mark_current(self):
+        """The optimizer kernel has just written every image from the weights it updated."""
+        self.stale = False
+        self._seen = self._key()
+
+    def ensure_current(self):
+        if self.stale or self._seen != self._key():
+            self.refresh()
+
+    def refresh(self):
+        """Every image from the live parameters, with the stand-alone packing kernels (eager launches on the current stream)."""
+        dec, d = self.dec, self.dec.emb_dim
+        copies = []
+        for i, l in enumerate(dec.transformer_decoder.layers):
+            copies.append((_p(l.multihead_attn.in_proj_weight)[d:], self.wkv[2 * d * i:2 * d * (i + 1)]))
+            copies.append((_p(l.multihead_attn.in_proj_bias)[d:].view(1, -1), self.bkv[2 * d * i:2 * d * (i + 1)].view(1, -1)))
+        pk = dec._chain_pack(fresh=True, copies=copies)
+        pkb = dec._chain_pack(fresh=True, bwd=True, extra=[(("kv", "T"), self.wkv.t())])
+        # the images live in the decoder's persistent pack buffers: the views this object handed to the item table
+        assert all(pk[k].data_ptr() == v.data_ptr() for k, v in self.pk.items())
+        assert all(pkb[k].data_ptr() == v.data_ptr() for k, v in self.pkb.items())
+        w = _p(dec.fc_vocab.weight)
+        ops.presplit_weights([(self.wkv, self.wkv_ps), (w, self.vocab_ps), (w.t(), self.vocab_t_ps)])
+        if self.pred_wt is not None:
+            self.pred_wt.copy_(_p(dec.fc_predicate.weight).t())
+        self.mark_current()
+
+
+class _Unsupported(Exception):
+    pass
+
+
 class TrainStep:
     """forward -> packed CE -> backward -> all-reduce -> clamp + Adam over one flat fp32 bucket.
 
@@ -1025,13 +1126,7 @@ class TrainStep:
         # bucket order: the parameters whose gradients are complete first come first, so that with several ranks
         # their part of the bucket can be all-reduced while the rest of the backward pass still runs
         early_ids = {id(p) for p in early_parameters(decoder)}
-        # ... and inside the early part fc_vocab, then the decoder layers, come first: with one rank their optimizer
-        # update runs inside the backward pass (see _early_update), over bucket ranges [lo, hi) of their own
-        first = list(decoder.fc_vocab.parameters()) + [q for l in decoder.transformer_decoder.layers for q in l.parameters()]
-        first_ids = {id(p) for p in first if p.requires_grad}
-        params = [p for p in params if id(p) in first_ids] + \
-                 [p for p in params if id(p) in early_ids and id(p) not in first_ids] + \
-                 [p for p in params if id(p) not in early_ids]
+        params = [p for p in params if id(p) in early_ids] + [p for p in params if id(p) not in early_ids]
         dev = params[0].device
         # every parameter starts at a multiple of 64 floats (256 bytes): the GEMM's 16-byte vector loads need aligned
         # weight rows, and one odd-sized parameter (fc_entity.bias has a single element) would misalign all that follow
@@ -1057,23 +1152,11 @@ class TrainStep:
                 off += pad(k)
         self.params = params
         self._graphs = {}
-        # bucket range of a module whose trainable parameters lie next to each other in the bucket (else None)
-        offs = {}
-        off = 0
-        for p in params:
-            offs[id(p)] = (off, off + pad(p.numel()))
-            off += pad(p.numel())
-
-        def span(mod):
-            r = sorted(offs[id(q)] for q in mod.parameters() if id(q) in offs)
-            if not r or any(a[1] != b[0] for a, b in zip(r, r[1:])):
-                return None
-            return r[0][0], r[-1][1]
-
-        self._spans = {"head": span(decoder.fc_vocab)}
-        for li, l in enumerate(decoder.transformer_decoder.layers):
-            self._spans[li] = span(l)
-        self._early_done = []
+        # the re-laid-out copies of the weights (packed row-chain images, cross K/V gather, bf16 planes) that the optimizer
+        # kernel keeps current itself: built on the first call (DerivedWeights); ICK_ADAM_DERIVE=0 keeps the per-step
+        # packing launches of rounds 2-4 instead (A/B runs, and the fallback for layer widths the images do not cover)
+        self.derived = None
+        self._derived_tried = False
         # several ranks: every replica starts from rank 0's weights (a freshly built decoder is randomly initialised
         # per process; the reference has a single process, geo-aware/train.py:16-18).  One broadcast of the bucket.
         dp.broadcast_bucket(self.flat_p, self.pg)
@@ -1123,7 +1206,7 @@ class TrainStep:
         scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, gmap=gmap,
                                          seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
                                          overlap=self._overlap("ICK_NO_FWD_OVERLAP"),
-                                         side_tail=tail, **self._enc_kwargs(enc_in))
+                                         side_tail=tail, derived=self.derived, **self._enc_kwargs(enc_in))
         decode_len = box["decode_len"]
         tape.misc["prezero"] = box.get("prezero")
         ops.stamp("fwd: scores done")
@@ -1132,43 +1215,21 @@ class TrainStep:
         _, _, dscores = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True,
                                       out_sum=self.flat_g[self.n:self.n + 1], out_count=self.flat_g[self.n + 1:])
         ops.stamp("CE done")
-        self._early_done = []
-        backward_from_tape(dec, tape, dscores, self.grads,
-                           overlap=self._overlap("ICK_NO_BWD_OVERLAP"), early_update=self._early_update())
+        backward_from_tape(dec, tape, dscores, self.grads, overlap=self._overlap("ICK_NO_BWD_OVERLAP"))
         ops.stamp("A: end (after join)")
         return self.flat_g
 
-    def _adam(self, lo, hi):
-        # divide by the global token count (device-resident), clamp, Adam with the device step counter
-        ops.adam_clamp(self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi], 1, self.lr,
-                       self.clip, 1.0, self.betas[0], self.betas[1], self.eps, step_tensor=self.counter,
-                       gscale_den=self.flat_g[self.n + 1:])
-
-    def _early_update(self):
-        """ICK_EARLY_ADAM=all | head | layers (opt-in experiment; one rank, overlapped backward pass): clamp + Adam of
-        fc_vocab and / or of each decoder layer run on the side stream as soon as that part's gradients are complete (the
-        side stream idles 30-40 us between its weight-gradient groups; the single update at the step's end is 56-60 us
-        of HBM time on the critical path).  Element-wise clamp (geo-aware/train.py:287-288) and Adam are per-element,
-        the token count is known since the loss kernel, and the step counter moves in part B: the same numbers as the
-        single launch (tests/test_round4_gpu.py).  MEASURED AND LEFT OFF: on one box, interleaved runs, 1.828 ms without,
-        1.838 all, 1.829 head only, 1.841 layers only -- the 3 000-workgroup streaming kernels take the slots the
-        latency-bound main chain is waiting for, which costs what the shorter tail gains.  With several ranks the
-        gradients first meet in the all-reduce between the graphs, so nothing can be updated early anyway."""
-        which = os.environ.get("ICK_EARLY_ADAM", "")
-        if which not in ("all", "head", "layers") or dp.world_size(self.pg) > 1 or self.split or self.deterministic:
-            return None
-
-        def update(key):
-            r = self._spans.get(key)
-            if (which == "head" and key != "head") or (which == "layers" and key == "head"):
-                r = None
-            if r is not None:
-                ops.stamp("side: early update starts")
-                self._adam(*r)
-                ops.stamp("side: early update done")
-                self._early_done.append(r)
-
-        return {"head": functools.partial(update, "head"), "layer": update}
+    def _adam(self):
+        # divide by the global token count (device-resident), clamp, Adam with the device step counter -- and, with
+        # self.derived, the re-laid-out copies of the updated weights in the same pass (ick_adam_clamp_derive)
+        hyper = (1, self.lr, self.clip, 1.0, self.betas[0], self.betas[1], self.eps)
+        if self.derived is not None:
+            ops.adam_clamp_derive(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.derived.items_dev,
+                                  self.derived.blocks_dev, self.derived.n_blocks, *hyper, step_tensor=self.counter,
+                                  gscale_den=self.flat_g[self.n + 1:], nbytes=self.derived.nbytes)
+        else:
+            ops.adam_clamp(self.flat_p[:self.n], self.flat_g[:self.n], self.flat_m, self.flat_v, *hyper,
+                           step_tensor=self.counter, gscale_den=self.flat_g[self.n + 1:])
 
     # ---- the same step in two halves (several ranks: the early half's all-reduce overlaps the late half) ----
     def _part_a1(self, captions, caption_masks, entities, facts, enc_in, gmap, lengths):
@@ -1183,7 +1244,7 @@ class TrainStep:
         scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, gmap=gmap,
                                          seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
                                          overlap=self._overlap("ICK_NO_FWD_OVERLAP"),
-                                         side_tail=tail, **self._enc_kwargs(enc_in))
+                                         side_tail=tail, derived=self.derived, **self._enc_kwargs(enc_in))
         decode_len = box["decode_len"]
         tape.misc["prezero"] = box.get("prezero")
         self._loss = ops.packed_ce(scores, captions, decode_len, dec.word_map["<pad>"], want_grad=True,
@@ -1200,11 +1261,7 @@ class TrainStep:
     def _part_b(self):
         # divide by the global token count (device-resident), clamp, Adam with the device step counter
         ops.stamp("B: start")
-        lo = 0
-        for a, b in sorted(self._early_done) + [(self.n, self.n)]:      # what part A has not updated already
-            if a > lo:
-                self._adam(lo, a)
-            lo = max(lo, b)
+        self._adam()
         ops.counter_add(self.counter, 1)
         ops.stamp("B: end")
         return self.flat_g
@@ -1301,6 +1358,14 @@ class TrainStep:
         self.eps = float(groups[0].get("eps", self.eps))
         self._graphs.clear()          # lr / betas / eps are baked into the captured optimizer graph
         self.dec.invalidate_caches()
+        self.parameters_changed()
+
+    def parameters_changed(self):
+        """Tell the step that parameter VALUES were written from outside it (through .data, a raw kernel, a restored
+        checkpoint): the re-laid-out copies the optimizer kernel maintains are rebuilt before the next step.  In-place
+        torch operations on the parameters are noticed without this call (their version counters move)."""
+        if self.derived is not None:
+            self.derived.stale = True
 
     def as_torch_optimizer(self):
         """A live torch.optim.Adam over the decoder's parameters carrying this step's state: what goes into the
@@ -1359,6 +1424,13 @@ class TrainStep:
                            % (ops.is_deterministic(), self.deterministic))
         # the large GEMM tiles' product mode is baked into a capture as well
         key = tuple(None if t is None else tuple(t.shape) for t in inputs) + (ops.gemm_split_mode(),)
+        if not self._derived_tried:
+            self._derived_tried = True
+            if os.environ.get("ICK_ADAM_DERIVE", "1") != "0":
+                self.derived = DerivedWeights.build(self)
+                self._graphs.clear()
+        if self.derived is not None:
+            self.derived.ensure_current()
         if self.use_graph and key not in self._graphs:
             if len(self._graphs) >= 4:
                 self._graphs.clear()
@@ -1381,6 +1453,9 @@ class TrainStep:
                 self.use_graph = False
             for t, sv in zip(state, snap):
                 t.copy_(sv)
+            if self.derived is not None:      # the warm-up's optimizer step wrote the images of weights that were just rewound
+                self.derived.stale = True
+                self.derived.ensure_current()
         if self.use_graph:
             ga, static, gb, ga2 = self._graphs[key]
             from .decoder import copy_inputs
@@ -1412,5 +1487,7 @@ class TrainStep:
             self._part_b()
         self.step_count += 1
         dec.invalidate_caches()   # the update went around torch's version counters
+        if self.derived is not None:
+            self.derived.mark_current()
         # token-mean loss of the global batch, still on the device
         return self.flat_g[self.n:self.n + 1] / self.flat_g[self.n + 1:]

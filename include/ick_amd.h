@@ -484,6 +484,41 @@ int ick_context_gate_bwd(const int64_t* captions, const int64_t* facts, const fl
 int ick_adam_clamp(float* p, float* g, float* m, float* v, int64_t n, float gscale, float clip, float lr,
                    float beta1, float beta2, float eps, int32_t step, const uint32_t* step_ptr,
                    const float* gscale_den, void* stream);
+/* ick_adam_clamp over the whole bucket which ALSO keeps the re-laid-out copies of the weights current that the
+ * next step's kernels read (geo-aware/train.py:292 optimizer.step() is the only writer of the parameters, so the
+ * packed / transposed / bf16-plane images need no launches of their own: round 4 spent 126 us of kernel time per cfg2
+ * step on ick_pack_weights + ick_presplit_weights).  The bucket is cut into workgroup-sized `blocks`:
+ *   - a flat run of <= 1024 float4 (item < 0), optionally mirrored into a plain copy (the gathered cross K/V bias);
+ *   - a 64 x 64 tile of an `item`: `rows` x K floats, row-major with row stride K, starting `off` floats into the
+ *     bucket, which are rows drow0 .. drow0 + rows - 1 of a logical (Nd, K) matrix W.  The tile (tn, tk) covers rows
+ *     64 tn .. 64 tn + 63 of W and columns 64 tk .. 64 tk + 63; after the update its new values are written to every
+ *     non-NULL image of W: `pack` = ick_pack_weights(W), `pack_t` = ick_pack_weights(W^T), `copy` = W with row stride
+ *     copy_ld, `ps` = ick_presplit_weights(W), `ps_t` = ick_presplit_weights(W^T), `tr` = W^T with row stride tr_ld.
+ *     The images must have been filled once by those entry points (their zero padding is never rewritten).
+ *     Constraints: K % 4 == 0, off % 4 == 0; pack_t needs drow0 % 4 == 0 and rows % 4 == 0; ps_t needs drow0 % 8 == 0
+ *     and rows % 8 == 0; copy_ld % 4 == 0.
+ * Every float of [0, n) must lie in exactly one block (the caller builds the cover).  items / blocks are DEVICE arrays.
+ * Arithmetic: the operations of ick_adam_clamp in the same order (bit-identical parameters, moments, clamped gradients). */
+typedef struct ick_adam_item {
+    int64_t off;
+    int32_t rows, K, drow0, Nd;
+    float* pack;
+    float* pack_t;
+    float* copy;
+    void* ps;
+    void* ps_t;
+    float* tr;
+    int64_t copy_ld, tr_ld;
+} ick_adam_item;
+typedef struct ick_adam_block {
+    int32_t item, tn, tk, cnt4;
+    int64_t off4;
+    float* copy;
+} ick_adam_block;
+int ick_adam_clamp_derive(float* p, float* g, float* m, float* v, const ick_adam_item* items,
+                          const ick_adam_block* blocks, int32_t n_blocks, float gscale, float clip, float lr,
+                          float beta1, float beta2, float eps, int32_t step, const uint32_t* step_ptr,
+                          const float* gscale_den, void* stream);
 /* *counter += inc on the stream (step / dropout-epoch counter of captured training graphs). */
 int ick_counter_add(uint32_t* counter, uint32_t inc, void* stream);
 /* n <= 8 device-to-device copies (src[i] -> dst[i], bytes[i]) in one launch; host arrays of device pointers. */

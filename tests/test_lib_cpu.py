@@ -43,13 +43,13 @@ def test_struct_layout_matches_header(built_lib):
     import subprocess
     import tempfile
     import ick_amd.lib as L
-    src = '#include <stdio.h>\n#include "ick_amd.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu", sizeof(ick_presplit_item), sizeof(ick_gemm_args), sizeof(ick_attn_args), sizeof(ick_attn_bwd_args), sizeof(ick_gemm_plan_info), sizeof(ick_decode_layer), sizeof(ick_decode_ctx), sizeof(ick_beam_state), sizeof(ick_rowchain_args), sizeof(ick_pack_item), sizeof(ick_rowchain_bwd_args));}\n'
+    src = '#include <stdio.h>\n#include "ick_amd.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu", sizeof(ick_presplit_item), sizeof(ick_gemm_args), sizeof(ick_attn_args), sizeof(ick_attn_bwd_args), sizeof(ick_gemm_plan_info), sizeof(ick_decode_layer), sizeof(ick_decode_ctx), sizeof(ick_beam_state), sizeof(ick_rowchain_args), sizeof(ick_pack_item), sizeof(ick_rowchain_bwd_args)); printf(" %zu %zu", sizeof(ick_adam_item), sizeof(ick_adam_block));}\n'
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, "sz.c")
         open(c, "w").write(src)
         exe = os.path.join(td, "sz")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
-        ps, g, a, ab, gp, dl, dc, bm, rc, ti, rb = (int(x) for x in subprocess.check_output([exe]).split())
+        ps, g, a, ab, gp, dl, dc, bm, rc, ti, rb, ai, abk = (int(x) for x in subprocess.check_output([exe]).split())
     assert ctypes.sizeof(L.PresplitItem) == ps
     assert ctypes.sizeof(L.GemmArgs) == g
     assert ctypes.sizeof(L.AttnArgs) == a
@@ -61,6 +61,7 @@ def test_struct_layout_matches_header(built_lib):
     assert ctypes.sizeof(L.RowChainArgs) == rc
     assert ctypes.sizeof(L.PackItem) == ti
     assert ctypes.sizeof(L.RowChainBwdArgs) == rb
+    assert ctypes.sizeof(L.AdamItem) == ai and ctypes.sizeof(L.AdamBlock) == abk
 
 
 def test_code_object_targets_gfx950(built_lib):

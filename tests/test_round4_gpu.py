@@ -73,50 +73,6 @@ def test_default_product_mode_and_graph_key():
         ops.set_gemm_split(before)
 
 
-def test_early_optimizer_update_equals_the_single_update(monkeypatch):
-    """One rank, captured step, ICK_EARLY_ADAM=all (opt-in): clamp + Adam of fc_vocab and of every decoder layer run inside
-    the backward pass on the side stream (TrainStep._early_update); the rest in part B.  Same gradients, moments and parameters as the single
-    update at the step's end (ICK_NO_EARLY_ADAM=1) up to the run-to-run noise of the split-K float atomics; the
-    vocabulary's weight gradient takes the pre-split kernel (x^T as its B operand) and agrees with the exact one."""
-    from ick_amd.training import TrainStep
-    from test_training_gpu import zero_dropout
-    variant, B, L, K, V, seed = "geo", 64, 20, 20, 10000, 5
-    P = synth.make_params(variant, V, seed)
-    b = synth.make_batch(variant, B, L, K, V, 0, seed)
-    args = [b["captions"].cuda(), synth.make_enc_out(B, seed).cuda(), b["caption_masks"].cuda(),
-            b["caption_lengths"].cuda(), b["entities"]]
-
-    def run(env):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        dec = zero_dropout(build_decoder(variant, V, P).train())
-        ts = TrainStep(dec, lr=4e-4, grad_clip=5.0)
-        loss = ts(*args).item()
-        torch.cuda.synchronize()
-        for k in env:
-            monkeypatch.delenv(k)
-        return ts, loss
-
-    ts1, l1 = run({"ICK_EARLY_ADAM": "all"})
-    ts0, l0 = run({"ICK_NO_VOCAB_WGRAD_PS": "1"})
-    done = sorted(ts1._early_done)
-    assert len(done) == 1 + len(ts1.dec.transformer_decoder.layers) and not ts0._early_done
-    assert done[0][0] == 0 and all(a[1] == b_[0] for a, b_ in zip(done, done[1:]))     # a prefix of the bucket
-    n_vocab = sum(q.numel() for q in ts1.dec.fc_vocab.parameters())
-    head = ts1._spans["head"]
-    assert head in done and head[1] - head[0] >= n_vocab and done[-1][1] < ts1.n
-    assert abs(l1 - l0) < 1e-5
-    g1, g0 = ts1.flat_g[:ts1.n], ts0.flat_g[:ts0.n]
-    assert (g1 - g0).abs().max().item() < 2e-6 * max(1.0, g0.abs().max().item())
-    assert (ts1.flat_m - ts0.flat_m).abs().max().item() < 1e-6
-    # first Adam step: +-lr wherever the gradient is well away from zero
-    sure = g0.abs() > 1e-5
-    assert sure.float().mean().item() > 0.2
-    assert ((ts1.flat_p - ts0.flat_p).abs()[sure]).max().item() < 1e-6
-    assert (ts1.flat_p - ts0.flat_p).abs().max().item() <= 2 * 4e-4 + 1e-6
-    assert ts1.counter.item() == ts0.counter.item() == 1
-
-
 def test_feature_map_inputs_run_conv1_inside_the_graph(gemm_split):
     """attach_encoder(): forward() / predict() / predict_beam() on the (B, 2048, 14, 14) feature map give exactly what
     they give on Encoder(feats) -- the same conv1 GEMM, only launched inside the captured graph beside the context

@@ -2,7 +2,7 @@
 """The four large GEMMs of the path on the pre-split kernel (csrc/gemm_ps.hip), per tile shape and A-load policy:
 duration (events around `reps` back-to-back launches, operands as cold as a 256 MB Infinity Cache leaves them) and the
 maximum difference from the exact fp32 MFMA path.  Every (tile, nt) setting runs in a child process: the plan reads
-ICK_PS_TILE / ICK_PS_NT once.   python tools/gemm_ps_bench.py [shape-name-prefix]"""
+ICK_PS_TILE once.   python tools/gemm_ps_bench.py [shape-name-prefix]"""
 import os
 import subprocess
 import sys
@@ -72,8 +72,8 @@ def child(name):
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3)
         times[cold] = sorted(ts)[len(ts) // 2]
-    print("%-15s tile %3dx%-3d presplit %d split_k %2d nt %s: hot %7.1f us  cold %7.1f us  (%5.1f TF fp32-eq cold)  max|diff to exact| %.2e"
-          % (name, info.tile_m, info.tile_n, info.presplit, info.split_k, os.environ.get("ICK_PS_NT", "auto"), times[False],
+    print("%-15s tile %3dx%-3d presplit %d split_k %2d: hot %7.1f us  cold %7.1f us  (%5.1f TF fp32-eq cold)  max|diff to exact| %.2e"
+          % (name, info.tile_m, info.tile_n, info.presplit, info.split_k, times[False],
              times[True], 2.0 * M * N * K / times[True] / 1e6, diff), flush=True)
 
 
@@ -85,18 +85,12 @@ if __name__ == "__main__":
     for name in SHAPES:
         if not name.startswith(want):
             continue
-        for tile in (os.environ.get("TILES", "off,,0,1,2,3,4,5,6").split(",")):
-            for nt in (("", "0", "1") if os.environ.get("SWEEP_NT") else ("",)):
-                if tile == "" and nt != "":
-                    continue
+        for tile in (os.environ.get("TILES", ",0,1,2,3,4,5,6,7,8,9,10").split(",")):
+            if True:
                 env = dict(os.environ)
-                if tile == "off":
-                    env["ICK_GEMM_PS"] = "0"         # the stager-split kernel of csrc/gemm.hip on the same operands
-                elif tile:
+                if tile:
                     env["ICK_PS_TILE"] = tile
-                if nt:
-                    env["ICK_PS_NT"] = nt
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", name], env=env, capture_output=True,
                                    text=True, timeout=300)
-                sys.stdout.write(("auto: " if tile == "" else ("noPS: " if tile == "off" else "      ")) + (r.stdout if r.returncode == 0 else "FAILED %s %s: %s\n" % (name, tile, r.stderr[-300:])))
+                sys.stdout.write(("auto: " if tile == "" else "      ") + (r.stdout if r.returncode == 0 else "FAILED %s %s: %s\n" % (name, tile, r.stderr[-300:])))
                 sys.stdout.flush()

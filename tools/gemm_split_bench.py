@@ -47,7 +47,6 @@ def run(name, M, N, K, akm, bkm, split_k=1, reps=30, a_grp=0):
 
 import os  # noqa: E402
 MODES = (1,) if os.environ.get("SPLIT_ONLY") else ((0,) if os.environ.get("EXACT_ONLY") else (0, 1))
-print("ICK_GEMM_XL=%s ICK_GEMM_TILE=%s" % (os.environ.get("ICK_GEMM_XL"), os.environ.get("ICK_GEMM_TILE")), flush=True)
 shapes = [("conv1 12544x300x2048 A k-major   ", 12544, 300, 2048, True, False, 1),
           ("cross K/V 13824x1800x300         ", 13824, 1800, 300, False, False, 1),
           ("vocab fwd 1280x10000x300         ", 1280, 10000, 300, False, False, 1),
