@@ -693,14 +693,17 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
         if (ps_tile_env == -2) { const char* e = getenv("ICK_PS_TILE"); ps_tile_env = e ? atoi(e) : -1; }
         const double flop = 2.0 * a.M * a.N * a.K;
         // a one-column-tile problem (N <= 320, no K split) needs ~180 row tiles of 128 to fill the chip with the pre-split
-        // kernel's one-workgroup-per-CU tile (Encoder.conv1 at batch 32 -- 98 workgroups -- took as long as at batch 64);
-        // below that the stager-split kernel's 128 x 64 tiles (five per row panel) are the better fit
-        static int narrow_min = -1;
-        if (narrow_min < 0) { const char* e = getenv("ICK_PS_NARROW_MIN"); narrow_min = e ? atoi(e) : 180; }
-        const bool narrow_underfilled = a.N <= 320 && split_req == 1 && ceil_div(a.M, 128) * ceil_div(a.N, 160) < narrow_min;
+        // kernel's 128-row tiles (Encoder.conv1 at batch 32 -- 98 workgroups -- took as long as at batch 64).  Below that
+        // the 64 x 160 four-wave tile (two per CU) keeps the problem on this kernel as long as it brings >= 128 of them:
+        // Encoder.conv1 at batch 32 (cfg5's prefill) 99 us on the stager-split 128 x 64 tiles -> ~35 us less per greedy
+        // decode (2.12 -> 2.05 ms, gpurun_out/r5_c1_ab_conv1_b32.txt; the 128 x 80 tile: 2.06); smaller problems stay on
+        // the stager-split kernel's 128 x 64 tiles (five per row panel)
+        const bool narrow = a.N <= 320 && split_req == 1;
+        const bool narrow_underfilled = narrow && ceil_div(a.M, 128) * ceil_div(a.N, 160) < 180;
+        const bool narrow_small_tile = narrow_underfilled && ceil_div(a.M, 64) * ceil_div(a.N, 160) >= 128;
         // the pre-split copy is addressed through one buffer descriptor: it must stay below 2 GiB
         const bool ps_fits = (int64_t)ceil_div(a.K, 32) * 3 * ceil_div(a.N, 64) * 64 * 64 < ((int64_t)1 << 31);
-        if (ps_fits && flop >= 1.0e9 && a.M >= 256 && a.N >= 128 && (!narrow_underfilled || ps_tile_env >= 0)) {
+        if (ps_fits && flop >= 1.0e9 && a.M >= 256 && a.N >= 128 && (!narrow_underfilled || narrow_small_tile || ps_tile_env >= 0)) {
             // Tile choice, measured (tools/gemm_ps_bench.py, profiles/r04_e_gemm_ps_tiles.txt: every tile x every shape):
             // 128 x 128 with two workgroups per CU wins wherever the output is wider than 320 columns (cross K/V 100 us
             // against 129-143 on the other tiles, vocabulary 65 against 80-88); outputs at most 320 wide (Encoder.conv1,
@@ -713,7 +716,7 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
             // workgroups cannot share a CU with a 139 KB tile: on 128 x 80 (62 KB, two per CU; alone 2-8 % slower than
             // 128 x 160) the cfg2 train step is 1.748 -> 1.722 ms and the forward pass 0.702 -> 0.693
             // (profiles/r04_y_ab_narrow_tile.txt)
-            int best = (a.N <= 320 && split_req == 1) ? 9 : 1;
+            int best = narrow ? (narrow_small_tile ? 8 : 9) : 1;
             // split-K problems at most 320 columns wide (the vocabulary's data gradient 1280 x 300 over K = 10 000, the
             // cross K/V and vocabulary weight gradients): 128 x 80 as well -- the data gradient's 40 x 12 = 480 workgroups
             // fill the chip's two slots per CU once (train step 1.770 -> 1.741 ms), the weight gradients are unchanged

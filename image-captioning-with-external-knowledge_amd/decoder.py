@@ -649,9 +649,7 @@ class DecoderTransformer(nn.Module):
         sa = torch.empty_like(x)
         chain = qkv_buf is None and self.chain_supported()
         if qkv_buf is None:
-            if qkv is None and chain and ops.chain_proj_on():
-                qkv = ops.chain_project_heads(x, self._chain_pack()[("d", li, "si")], sa_b, 3, H, T)
-            elif qkv is None:
+            if qkv is None:
                 qkv = ops.project_heads(x, sa_w, sa_b, 3, H, T)
             ops.attention_heads(qkv, qkv, sa, H, dh, T, T, q_seg=0, k_seg=1, v_seg=2, causal=True)
         else:
