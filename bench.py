@@ -40,11 +40,14 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_TABLE = os.path.join(ROOT, "profiles", "r04_traffic.json")   # PMC bytes per launch, see its "_source"
-# kernel time per class INSIDE the captured step (rocprofv3 kernel trace of the same command; tools/in_step_table.py):
-# the eager single-stream pass below times every kernel alone, the captured step runs two streams beside each other
-IN_STEP_TABLE = {"train": os.path.join(ROOT, "profiles", "r04_in_step_train.json"),
-                 "forward": os.path.join(ROOT, "profiles", "r04_in_step_forward.json")}
+# Tables made from profiler runs of THIS command (tools/r5_profiles.sh), one pair per (mode, config):
+#   traffic  PMC bytes per launch and kernel class (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE; tools/traffic_table.py)
+#   in_step  kernel time per class INSIDE the captured step (rocprofv3 kernel trace; tools/in_step_table.py): the eager
+#            single-stream pass below times every kernel alone, the captured step runs two streams beside each other
+# Each records the build id (ick_amd.build.source_id) it was made with; a table made from another tree is still attached
+# but the line says so (`in_step_stale` / `traffic_stale`).
+def _table(kind, mode, cfgname):
+    return os.path.join(ROOT, "profiles", "r05_%s_%s_%s.json" % (kind, mode, cfgname))
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_GBS = 8000.0
 BEAM = 5
@@ -455,18 +458,19 @@ def main():
         }
         by_kernel = res["by_kernel"]
         roof = {}
-        traffic = {}
-        if os.path.exists(TRAFFIC_TABLE):
-            traffic = json.load(open(TRAFFIC_TABLE))
+        import ick_amd.build as _build
+        build_id = _build.source_id()
+        traffic = in_step = {}
+        if _gemm_mode() == 1 and os.path.exists(_table("traffic", args.mode, cfgname)):
+            traffic = json.load(open(_table("traffic", args.mode, cfgname)))
         for r in by_kernel:
-            # HBM bytes per launch from the PMC counters (valid for the workload they were collected on: cfg2 / cfg5)
-            if r["name"] in traffic and cfgname in ("cfg2", "cfg5") and args.mode != "beam":
+            # HBM bytes per launch from the PMC counters of this workload
+            if r["name"] in traffic:
                 r["traffic"] = traffic[r["name"]]
                 # the decode step's bytes are per token (all of its launches), every other class's per launch
                 r["traffic_per"] = "token" if r["name"].startswith("fused decode step") else "launch"
-        in_step = {}
-        if cfgname == "cfg2" and _gemm_mode() == 1 and os.path.exists(IN_STEP_TABLE.get(args.mode, "")):
-            in_step = json.load(open(IN_STEP_TABLE[args.mode]))
+        if _gemm_mode() == 1 and os.path.exists(_table("in_step", args.mode, cfgname)):
+            in_step = json.load(open(_table("in_step", args.mode, cfgname)))
         for r in by_kernel:
             t = in_step.get(r["name"])
             if t and r.get("peak") and r.get("work_per_launch"):
@@ -483,8 +487,12 @@ def main():
                     "share_of_kernel_time": dom["us_per_step"] / max(1e-9, sum(r["us_per_step"] for r in by_kernel)),
                     "traffic": dom.get("traffic"), "traffic_per": dom.get("traffic_per"),
                     # frac: the class timed alone (eager, one stream); frac_in_step: inside the captured step, beside the
-                    # other stream's kernels (profiles/r04_in_step_*.json, rocprofv3 of this command)
+                    # other stream's kernels (profiles/r05_in_step_<mode>_<config>.json, rocprofv3 of this command)
                     "frac_in_step": dom.get("frac_in_step"), "in_step_source": in_step.get("_source"),
+                    # the tables above were made by profiler runs of a tree with this id; stale = not the tree running now
+                    "build_id": build_id,
+                    "in_step_stale": (in_step.get("_build_id") != build_id) if in_step else None,
+                    "traffic_stale": (traffic.get("_build_id") != build_id) if traffic else None,
                     "sum_kernel_us_per_step": sum(r["us_per_step"] for r in by_kernel),
                     "by_kernel": by_kernel,
                     "how": "HIP events on the launch stream around every C-ABI launch of %d eager single-stream steps "
@@ -495,8 +503,10 @@ def main():
             # sum over the kernel classes of (algorithmic work / that class's own peak): what the step would take if
             # every kernel ran at its roofline, back to back -- the whole step's fraction against a peak that mixes the
             # exact-fp32 pipe, the bf16 pipe of the split-product kernels and HBM
-            floor_us = sum(r["work_per_launch"] * r["launches_per_step"] / (r["peak"] * (1e12 if r["unit"] == "TFLOP/s" else 1e9))
-                           for r in by_kernel if r.get("peak")) * 1e6
+            # (row chains: their own floor -- the weight bytes each workgroup streams through its CU -- not the matrix pipe's)
+            floor_us = sum(r["cu_stream_floor_us"] * r["launches_per_step"] if r.get("cu_stream_floor_us") else
+                           r["work_per_launch"] * r["launches_per_step"] / (r["peak"] * (1e12 if r["unit"] == "TFLOP/s" else 1e9)) * 1e6
+                           for r in by_kernel if r.get("peak"))
             roof["pass_floor_us"] = floor_us
             roof["pass_frac_of_floor"] = floor_us / (res["ms_per_step"] * 1e3)
         pf = pass_fraction(cfgname, args.mode, res["ms_per_step"], L)
@@ -529,9 +539,13 @@ def main():
                                                 ("forward_cfg2_exact_fp32", "forward", "cfg2", 50, True)):
             if (mode, cname) == (args.mode, cfgname) and (not exact or _gemm_mode() == 0):
                 continue
+            # the CPU port beside the forward and greedy numbers as well (north_star: "in the same run"): bounded legs of
+            # ~3 s each inside those children; the headline's own leg runs at the end of this process
+            cpu_leg = name in ("forward_cfg2", "greedy_cfg5") and not args.no_cpu_baseline
             cmd = [sys.executable, os.path.abspath(__file__), "--mode", mode, "--config", cname, "--steps", str(steps),
-                   "--warmup", "3", "--min-seconds", "0.5", "--no-modes", "--no-cpu-baseline", "--profile-steps",
-                   "0" if args.no_profile else "2"] + (["--no-profile"] if args.no_profile else [])
+                   "--warmup", "3", "--min-seconds", "0.5", "--no-modes", "--profile-steps",
+                   "0" if args.no_profile else "2"] + (["--no-profile"] if args.no_profile else []) + \
+                  (["--cpu-seconds", "3"] if cpu_leg else ["--no-cpu-baseline"])
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
             if exact:
                 env["ICK_GEMM_SPLIT"] = "0"
@@ -556,8 +570,13 @@ def main():
                                             "bound": rf.get("bound"), "share_of_kernel_time": rf["share_of_kernel_time"],
                                             "frac_in_step": rf.get("frac_in_step"),
                                             # PMC bytes per launch (decode step: per token); null where no counter run
-                                            # of that workload is committed (profiles/r04_traffic.json)
-                                            "traffic": rf.get("traffic"), "traffic_per": rf.get("traffic_per")}
+                                            # of that workload is committed (profiles/r05_traffic_<mode>_<config>.json)
+                                            "traffic": rf.get("traffic"), "traffic_per": rf.get("traffic_per"),
+                                            "in_step_stale": rf.get("in_step_stale"), "traffic_stale": rf.get("traffic_stale")}
+            if "cpu_baseline" in c:
+                cb = c["cpu_baseline"]
+                entry["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                         "sample": cb["sample"], "one_thread": cb["one_thread"]["value"]}
             modes[name] = entry
         out["modes"] = modes
 

@@ -15,6 +15,20 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I", INCLUDE, "
          "-ffp-contract=off"]  # fused multiply-adds only where the source says fmaf / MFMA
 
 
+def source_id():
+    """16 hex digits over everything that shapes the timed step: the kernel sources, the C header and the host modules
+    that schedule the launches.  Measurement tables made from profiler runs (profiles/*_in_step_*.json, *_traffic_*.json)
+    carry the id they were made with; bench.py marks them stale when it differs from the tree it runs from."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files += [os.path.join(INCLUDE, "ick_amd.h")] + [os.path.join(PKG, f) for f in ("training.py", "decoder.py", "ops.py", "dp.py")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 

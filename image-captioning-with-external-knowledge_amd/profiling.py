@@ -18,6 +18,11 @@ PEAK_HBM_GBS = 8000.0             # HBM3E spec
 # fp32-equivalent ceiling of such a kernel -- a fraction against the 157.3 TF of the exact fp32 MFMA could exceed 1.
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_SPLIT_FP32_EQ_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+# What bounds a row-chain launch is not the matrix pipe: every 8-row workgroup streams the WHOLE weight set of its stages
+# from its XCD's L2 through its own CU, and one CU takes in 66-73 GB/s from L2 whatever is in flight
+# (MI355X_MICROARCH.md, "Indexed rows: gather into LDS": 2 048 rows shared by every workgroup; tools/probes/probe_chain.hip
+# measured 73).  bytes per workgroup / that rate is the floor of a launch, however many CUs run one.
+PER_CU_L2_STREAM_GBS = 70.0
 
 
 def _struct(arg):
@@ -30,11 +35,19 @@ def _gemm_label(a):
     return "%dx%dx%d (%s%s)" % (a.M, a.N, a.K, lay, ", split-K %d" % a.split_k if a.split_k > 1 else "")
 
 
-def _split_plan(a):
-    """Does ick_gemm form this problem's products on the bf16 pipe (plan query; nothing is launched)?"""
+TRACE_KEYS = {}      # class label -> {"<kernel family>:<threads of the grid>"}: how a profiler trace finds the class again
+
+
+def _split_plan(a, label=None):
+    """Does ick_gemm form this problem's products on the bf16 pipe (plan query; nothing is launched)?  With `label` the
+    launch's (kernel family, grid) is noted under that class, so that tables made from rocprofv3 traces of the same command
+    (tools/in_step_table.py, tools/traffic_table.py) can tell the shared GEMM instantiations apart by their grids."""
     info = L.GemmPlanInfo()
     if L.load_raw().ick_gemm_plan(C.byref(a), C.byref(info)) != 0:
         return False, False
+    if label is not None:
+        fam = "gemm_ps_kernel" if info.presplit else "gemm_kernel"
+        TRACE_KEYS.setdefault(label, set()).add("%s:%d" % (fam, info.tiles_m * info.tiles_n * info.split_k * info.waves * 64))
     return bool(info.split_bf16), bool(info.presplit)
 
 
@@ -47,7 +60,10 @@ def classify(name, args):
         spl, ps = _split_plan(a)
         if fl >= 2e9:
             tag = " [split-bf16 products, B pre-split]" if ps else (" [split-bf16 products]" if spl else "")
-            return "GEMM " + _gemm_label(a) + tag, fl, "flop_split" if spl else "flop"
+            label = "GEMM " + _gemm_label(a) + tag
+            _split_plan(a, label)
+            return label, fl, "flop_split" if spl else "flop"
+        _split_plan(a, "chain GEMMs (< 2 GFLOP each: projections, FFN, their data gradients)")
         return "chain GEMMs (< 2 GFLOP each: projections, FFN, their data gradients)", fl, "flop"
     if name == "ick_gemm_grouped":
         arr, n = args[0], args[1]
@@ -57,7 +73,10 @@ def classify(name, args):
             if not (a.flags & L.GEMM_COLSUM_ONLY):
                 f = 2.0 * a.M * a.N * a.K
                 fl += f
-                if _split_plan(a)[0]:
+                spl, ps = _split_plan(a)
+                if ps:                   # launched on its own (csrc/gemm_ps.hip): found in a trace by its grid
+                    _split_plan(a, "grouped weight-gradient GEMMs")
+                if spl:
                     fl_split += f        # this problem's products run on the bf16 pipe (six MFMAs per product block)
         # a mixed launch is priced against the time its parts would take at their own pipes' peaks ("flop_mixed")
         return "grouped weight-gradient GEMMs", fl, "flop_mixed", fl_split
@@ -70,11 +89,13 @@ def classify(name, args):
     if name == "ick_rowchain_fwd":
         a = _struct(args[0])
         fl = 2.0 * a.M * (a.K1 * a.d + (a.d * a.N2 if a.w2p else 0))
-        return "row chain forward (out-projection + add & norm + next Linear)", fl, "flop"
+        return ("row chain forward (out-projection + add & norm + next Linear)", fl, "flop", 0.0,
+                4.0 * (a.K1 * a.d + (a.d * a.N2 if a.w2p else 0)))
     if name == "ick_rowchain_bwd":
         a = _struct(args[0])
         fl = 2.0 * a.M * ((a.K0 * a.d if a.g0 else 0) + (2 * a.d * a.N1 if a.w1p else 0) + a.d * a.d)
-        return "row chain backward (Linear' + norm' [+ FFN' + norm'] + out-projection')", fl, "flop"
+        return ("row chain backward (Linear' + norm' [+ FFN' + norm'] + out-projection')", fl, "flop", 0.0,
+                4.0 * ((a.K0 * a.d if a.g0 else 0) + (2 * a.d * a.N1 if a.w1p else 0) + a.d * a.d))
     if name == "ick_pack_weights":
         arr, n = args[0], args[1]
         return "packed weight copies", 8.0 * sum(arr[i].N * arr[i].K for i in range(n)), "byte"
@@ -130,7 +151,7 @@ class _Profiled:
             e0.record()
             rc = fn(*args)
             e1.record()
-            L.PROFILE.append((label, work, unit, e0, e1, rest[0] if rest else 0.0))
+            L.PROFILE.append((label, work, unit, e0, e1, rest[0] if rest else 0.0, rest[1] if len(rest) > 1 else 0.0))
             return rc
         return timed
 
@@ -149,9 +170,11 @@ def stop():
 def summarise(records, steps):
     torch.cuda.synchronize()
     rows = {}
-    for label, work, unit, e0, e1, work_split in records:
-        r = rows.setdefault(label, {"name": label, "launches": 0, "us": 0.0, "work": 0.0, "unit": unit, "work_split": 0.0})
+    for label, work, unit, e0, e1, work_split, cu_bytes in records:
+        r = rows.setdefault(label, {"name": label, "launches": 0, "us": 0.0, "work": 0.0, "unit": unit, "work_split": 0.0,
+                                    "cu_bytes": 0.0})
         r["launches"] += 1
+        r["cu_bytes"] += cu_bytes
         r["us"] += e0.elapsed_time(e1) * 1e3
         if work is not None:
             r["work"] += work
@@ -173,10 +196,19 @@ def summarise(records, steps):
                 pipe = "bf16 MFMA x 6 partial products (fp32-equivalent FLOP)" if r["unit"] == "flop_split" else "fp32 MFMA"
             row.update(work_per_launch=r["work"] / n, unit="TFLOP/s", achieved=ach, peak=peak, frac=ach / peak, bound="mfma",
                        pipe=pipe, frac_of_fp32_mfma_peak=ach / PEAK_FP32_MFMA_TFLOPS)
+            if r["cu_bytes"] > 0:
+                # the launch's real bound: the weight bytes EVERY workgroup pulls through its own CU from L2
+                floor_us = r["cu_bytes"] / n / (PER_CU_L2_STREAM_GBS * 1e9) * 1e6
+                row.update(bound_detail="l2_stream_per_cu", cu_stream_bytes_per_workgroup=r["cu_bytes"] / n,
+                           cu_stream_gbs=PER_CU_L2_STREAM_GBS, cu_stream_floor_us=floor_us,
+                           frac_of_cu_stream_floor=floor_us / (r["us"] / n))
         elif r["unit"] == "byte" and r["us"] > 0:
             ach = r["work"] / (r["us"] * 1e-6) / 1e9
             row.update(work_per_launch=r["work"] / n, unit="GB/s", achieved=ach, peak=PEAK_HBM_GBS,
                        frac=ach / PEAK_HBM_GBS, bound="hbm")
         out.append(row)
+    for row in out:
+        if row["name"] in TRACE_KEYS:
+            row["trace_keys"] = sorted(TRACE_KEYS[row["name"]])
     out.sort(key=lambda x: -x["us_per_step"])
     return out

@@ -280,18 +280,28 @@ def test_presplit_gemm_error_not_above_exact_path(ops, M, N, K, akm, grp, split_
     assert smax < 300 * unit and (split - exact).abs().max().item() < 500 * unit
 
 
-def test_underfilled_narrow_problem_keeps_the_stager_split_kernel(ops):
-    """Encoder.conv1 at batch 32 (6 272 rows: 98 workgroups of the pre-split kernel's 128 x 160 tile) stays on the
-    tiles of csrc/gemm.hip; at batch 64 it takes the pre-split kernel."""
+def test_narrow_problems_pick_their_tile_by_fill(ops):
+    """Encoder.conv1 (N = 300, K = 2048, one column pair): at batch 64 on the pre-split kernel's 128 x 80 tile; at batch 32
+    (cfg5's prefill, 6 272 rows = 49 row tiles of 128) on its 64 x 160 four-wave tile (196 workgroups; round 5: greedy
+    2.12 -> 2.06 ms against the stager-split 128 x 64 tiles); at batch 8 it stays on the tiles of csrc/gemm.hip.  The batch-32
+    instantiation against an fp64 product."""
     before = ops.gemm_split_mode()
     ops.set_gemm_split(1)
     try:
-        for Bn, want in ((32, 0), (64, 1)):
+        for Bn, want, tile in ((8, 0, None), (32, 1, (64, 160)), (64, 1, (128, 80))):
             M, N, K = Bn * 196, 300, 2048
             A, W, out = torch.empty(Bn, K, 196, device="cuda"), torch.empty(N, K, device="cuda"), torch.empty(M, N, device="cuda")
             ps = ops.presplit_buffer(N, K, "cuda")
             info = plan_of(ops, ops.gemm_args(A, W, out, M, N, K, 1, 196, K, 1, N, a_grp=196, a_gs=K * 196, b_ps=ps))
-            assert info.presplit == want and (info.tile_m, info.tile_n) == ((128, 80) if want else (info.tile_m, info.tile_n)), (Bn, info.presplit)
+            assert info.presplit == want and (tile is None or (info.tile_m, info.tile_n) == tile), (Bn, info.presplit, info.tile_m, info.tile_n)
+        Bn, M, N, K = 32, 32 * 196, 300, 2048
+        A, W, bias = rnd(Bn, K, 196, seed=5).relu(), rnd(N, K, seed=6, scale=0.05), rnd(N, seed=7)
+        out = torch.empty(M, N, device="cuda")
+        ps = ops.presplit_buffer(N, K, "cuda")
+        ops.presplit_weights([(W, ps)])
+        ops.gemm_raw(A, W, out, M, N, K, 1, 196, K, 1, N, bias=bias, a_grp=196, a_gs=K * 196, b_ps=ps)
+        ref = A.double().permute(0, 2, 1).reshape(M, K) @ W.double().t() + bias.double()
+        assert (out.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
     finally:
         ops.set_gemm_split(before)
 

@@ -1,29 +1,46 @@
-"""Maps a rocprofv3 kernel name (+ grid size) of the cfg2 train / forward / greedy benches onto the kernel-class names
-bench.py's roofline.by_kernel uses, so that tables made from rocprofv3 runs (in-step durations, PMC traffic) can be joined
-with the bench line.  The large GEMMs of the split-product default share one kernel instantiation and are told apart by
-their grid (cfg2: 12 544 image rows, 1 280 caption rows, V = 10 000)."""
+"""Maps a rocprofv3 kernel name (+ grid size) of a bench.py run onto the kernel-class names of bench.py's
+roofline.by_kernel, so that tables made from rocprofv3 runs (in-step durations, PMC traffic) can be joined with the bench
+line of the SAME command.  Kernels whose family decides the class are mapped by name; the large GEMMs share two kernel
+instantiations and are told apart by their grids, which the bench line itself records per class (`trace_keys`:
+"<kernel family>:<threads of the grid>", written by ick_amd/profiling.py from the plan of every launch) -- so the mapping
+holds for every workload (cfg2, cfg4, cfg5), not only for the grids of one."""
+import json
 import re
 
-PS = " [split-bf16 products, B pre-split]"
-CLASSES = {
-    "wgrad": "grouped weight-gradient GEMMs",
-    "chain_fwd": "row chain forward (out-projection + add & norm + next Linear)",
-    "chain_bwd": "row chain backward (Linear' + norm' [+ FFN' + norm'] + out-projection')",
-    "attn_fwd": "attention forward (T=20)",
-    "attn_bwd": "attention backward",
-    "small": "chain GEMMs (< 2 GFLOP each: projections, FFN, their data gradients)",
-    "adam": "clamp + Adam",
-    "ce": "packed cross entropy (+ gradient)",
-    "pack": "packed weight copies",
-    "presplit": "presplit weights",
-    "conv1_ps": "GEMM 12544x300x2048 (A k-major, B row-major)" + PS,
-    "kv_ps": "GEMM 12544x1800x300 (A row-major, B row-major)" + PS,
-    "vocab_ps": "GEMM 1280x10000x300 (A row-major, B row-major)" + PS,
-    "conv1": "GEMM 12544x300x2048 (A k-major, B row-major)",
-    "vocab_dgrad": "GEMM 1280x300x10000 (A row-major, B k-major, split-K 9)",
-    "vocab_dgrad_ps": "GEMM 1280x300x10000 (A row-major, B k-major, split-K 12)" + PS,
-    "decode": "fused decode step (3 kernels / layer + head + vocabulary)",
-}
+BY_NAME = [            # (regex on the kernel name, class label)
+    (r"gemm_group_kernel", "grouped weight-gradient GEMMs"),
+    (r"rowchain_fwd_kernel", "row chain forward (out-projection + add & norm + next Linear)"),
+    (r"rowchain_bwd_kernel", "row chain backward (Linear' + norm' [+ FFN' + norm'] + out-projection')"),
+    (r"attn_bwd_mfma_kernel|attn_bwd_kernel", "attention backward"),
+    (r"adam_derive_kernel", "clamp + Adam + re-laid-out weight copies"),
+    (r"adam_clamp", "clamp + Adam"),
+    (r"packed_ce_", "packed cross entropy (+ gradient)"),
+    (r"pack_weights_kernel", "packed weight copies"),
+    (r"presplit_kernel", "presplit weights"),
+    (r"dec_(self|cross|ffn|head|vocab|headvocab|beam_partial)_kernel", "fused decode step (3 kernels / layer + head + vocabulary)"),
+    (r"dec_select_beam", "decode select beam"),
+    (r"dec_init", "decode init"),
+    (r"pointer_bwd_", "pointer scores bwd"),
+    (r"pointer_scores_kernel", "pointer scores"),
+    (r"caption_embed_bwd", "caption embed bwd"),
+    (r"caption_embed_kernel", "caption embed"),
+    (r"entity_encode_bwd", "entity encode bwd"),
+    (r"entity_encode_kernel", "entity encode"),
+]
+
+
+def load_keymap(bench_json):
+    """{"family:grid": class label} + {NQT: attention-forward label} from a bench.py line (file with the JSON line last)."""
+    line = [ln for ln in open(bench_json).read().splitlines() if ln.startswith("{")][-1]
+    rows = json.loads(line)["roofline"]["by_kernel"]
+    keys, attn = {}, {}
+    for r in rows:
+        for k in r.get("trace_keys", []):
+            keys.setdefault(k, r["name"])
+        m = re.match(r"attention forward \(T=(\d+)\)", r["name"])
+        if m:
+            attn[(int(m.group(1)) + 15) // 16] = r["name"]
+    return {"keys": keys, "attn": attn, "names": {r["name"] for r in rows}}
 
 
 def _targs(name, kernel):
@@ -31,44 +48,25 @@ def _targs(name, kernel):
     return [a.strip() for a in m.group(1).split(",")] if m else None
 
 
-def classify(name, grid_x=None):
-    """-> key of CLASSES or None.  grid_x: total threads of the launch (x * y * z)."""
-    if "gemm_group_kernel" in name:
-        return "wgrad"
-    if "rowchain_fwd_kernel" in name:
-        return "chain_fwd"
-    if "rowchain_bwd_kernel" in name:
-        return "chain_bwd"
-    if "attn_fwd_mfma_kernel" in name:
-        return "attn_fwd"
-    if "attn_bwd_mfma_kernel" in name:
-        return "attn_bwd"
-    if "adam_clamp" in name:
-        return "adam"
-    if "packed_ce_" in name:
-        return "ce"
-    if "pack_weights_kernel" in name:
-        return "pack"
-    if "presplit_kernel" in name:
-        return "presplit"
-    if re.search(r"dec_(self|cross|ffn|head|vocab|headvocab)_kernel", name):
-        return "decode"
-    t = _targs(name, "gemm_ps_kernel")
+def classify(name, grid_threads=None, keymap=None):
+    """-> class label or None.  grid_threads: total threads of the launch (x * y * z)."""
+    for pat, label in BY_NAME:
+        if re.search(pat, name):
+            return label
+    t = _targs(name, "attn_fwd_mfma_kernel")
     if t:
-        g = int(grid_x) if grid_x else 0              # TOTAL threads of the grid (x * y * z)
-        if t[4] == "true":                            # A k-major: Encoder.conv1 (392 tiles of 128 x 80) or a weight gradient
-            return "conv1_ps" if g in (200704, 100352) else "wgrad"
-        # A row-major: K/V projection (98 x 15 tiles of 128 x 128), vocabulary (10 x 79), its data gradient (40 tiles of
-        # 128 x 80 x 12 K slices)
-        return {752640: "kv_ps", 404480: "vocab_ps", 245760: "vocab_dgrad_ps"}.get(g)
-    t = _targs(name, "gemm_kernel")
-    if t:
-        if t[4] == "true" and t[5] == "true":
-            return "wgrad"                       # stand-alone weight gradients (vocabulary, cross K/V)
-        if t[2] == "1":
-            return "small"
-        if t[0] == "4" and t[4] == "true":
-            return "conv1"
-        if t[4] == "false" and t[5] == "true":
-            return "vocab_dgrad"
+        if keymap and int(t[0]) in keymap["attn"]:
+            return keymap["attn"][int(t[0])]
+        return "attention forward (T=20)"
+    g = int(grid_threads) if grid_threads else 0
+    for fam in ("gemm_ps_kernel", "gemm_kernel"):
+        t = _targs(name, fam)
+        if t is None:
+            continue
+        if keymap and "%s:%d" % (fam, g) in keymap["keys"]:
+            return keymap["keys"]["%s:%d" % (fam, g)]
+        if fam == "gemm_kernel" and t[4] == "true" and t[5] == "true":
+            return "grouped weight-gradient GEMMs"          # stand-alone exact weight gradients
+        if fam == "gemm_kernel" and t[2] == "1":
+            return "chain GEMMs (< 2 GFLOP each: projections, FFN, their data gradients)"
     return None
