@@ -206,7 +206,7 @@ class Workload:
         return "%s: %s variant, per-GPU batch %d x %d decode positions, 14x14x2048 features, K=%d knowledge rows%s, vocab %d" % (
             self.cfgname, c["variant"], c["B"], c["L"], c["K"], (", F=%d facts" % c["F"]) if c["F"] else "", c["V"])
 
-    def make_step(self, use_graph=True):
+    def make_step(self, use_graph=True, adopt_buffers=True):
         mode, dec, enc, batch, feats, extra, L = self.mode, self.dec, self.enc, self.batch, self.feats, self.extra, self.cfg["L"]
         if mode == "train":
             from ick_amd.training import TrainStep
@@ -246,7 +246,7 @@ class Workload:
                    "caps": batch["captions"], "masks": batch["caption_masks"]}
 
             def adopt():
-                bufs = dec.input_buffers() if use_graph else None
+                bufs = dec.input_buffers() if (use_graph and adopt_buffers) else None
                 if bufs is None or cur.get("adopted"):
                     return
                 if mode == "forward":
@@ -320,6 +320,14 @@ def run_workload(wl, steps, warmup, min_seconds, world, profile_steps, max_repea
         times.append(block(step))
     dt = statistics.median(times)
     graph = wl.graph_in_use()
+    # The timed steps above find their batch in the graph's own input buffers (where a loader's host-to-device copy puts
+    # it: eval.py / train.py do).  A caller that hands over OTHER device tensors pays a device-to-device copy of the
+    # inputs in front of every replay (103 MB of features at B = 64): that number too, one block, not the headline.
+    dt_copy = None
+    if wl.mode != "train":
+        step_copy = wl.make_step(adopt_buffers=False)
+        step_copy()
+        dt_copy = block(step_copy)
 
     # ---- per-kernel pass: the same step launched eagerly on one stream, every C-ABI launch bracketed by HIP events
     # (every rank runs it -- the train step holds a collective -- but only rank 0 records)
@@ -342,7 +350,7 @@ def run_workload(wl, steps, warmup, min_seconds, world, profile_steps, max_repea
         wl.dec.use_hip_graphs = True
     return {"ms_per_step": dt / steps * 1e3, "value": world * wl.units_per_step * steps / dt, "repeats": len(times),
             "timed_region_s": sum(times), "block_s_min_median_max": [min(times), dt, max(times)], "graph": graph,
-            "by_kernel": by_kernel}
+            "by_kernel": by_kernel, "ms_per_step_with_input_copy": None if dt_copy is None else dt_copy / steps * 1e3}
 
 
 def pass_fraction(cfgname, mode, ms_per_step, L):
@@ -442,6 +450,9 @@ def main():
                                 "beam": "beam_decode (Encoder.conv1 + predict_beam, beam %d, KV-cached)" % BEAM}[args.mode],
                        "global_batch": world * B,
                        "graph": res["graph"],      # False = hipGraph capture failed and the steps were launched eagerly
+                       # forward / greedy / beam: the same step when the inputs are NOT already in the graph's input buffers
+                       # (one device-to-device copy of the feature map per call in front of the replay)
+                       "ms_per_step_with_input_copy": res["ms_per_step_with_input_copy"],
                        # how the large GEMM tiles form their fp32 products (csrc/gemm.hip; ICK_GEMM_SPLIT)
                        "gemm_products": {0: "exact fp32 MFMA (v_mfma_f32_16x16x4_f32)",
                                          1: "split: 6 bf16 MFMA partial products of the exact 3-way bf16 split, fp32 "
@@ -557,6 +568,7 @@ def main():
             c = json.loads(lines[-1])
             entry = {"workload": c["config"]["workload"], "mode": mode, "steps": steps, "repeats": c["repeats"],
                      "ms_per_step": c["ms_per_step"], "value": c["value"], "unit": c["unit"], "graph": c["config"]["graph"],
+                     "ms_per_step_with_input_copy": c["config"].get("ms_per_step_with_input_copy"),
                      "gemm_products": c["config"].get("gemm_products"), "dtype": c.get("dtype")}
             rf = c.get("roofline", {})
             if "pass_frac_executed" in rf:

@@ -177,13 +177,9 @@ int launch_attn(const ick_attn_args& a, hipStream_t s) {
     const bool vec = a.q_ts == DHP && a.k_ss == DHP && a.v_ss == DHP && al16(a.Q) && al16(a.K) && al16(a.V) &&
                      a.q_bs % 4 == 0 && a.q_hs % 4 == 0 && a.k_bs % 4 == 0 && a.k_hs % 4 == 0 && a.v_bs % 4 == 0 &&
                      a.v_hs % 4 == 0;
-    static bool attr_set[2] = {false, false};
+    static LdsAttrOnce attr_set[2];
     const void* kern = vec ? (const void*)attn_kernel<DHP, true> : (const void*)attn_kernel<DHP, false>;
-    if (!attr_set[vec]) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set[vec] = true;
-    }
+    if (int e = attr_set[vec].ensure(kern, 160 * 1024)) return e;
     const dim3 grid(a.H, a.B, ceil_div(a.T, TQ));
     if (vec) hipLaunchKernelGGL((attn_kernel<DHP, true>), grid, dim3(256), smem, s, a, TQ, SLD);
     else hipLaunchKernelGGL((attn_kernel<DHP, false>), grid, dim3(256), smem, s, a, TQ, SLD);
@@ -367,12 +363,8 @@ int launch_attn_bwd(const ick_attn_bwd_args& a, hipStream_t s) {
     const size_t fl = fixed + stage + (size_t)TQ * (2 * DHP + SLD + 2);
     if (fl > budget) return ICK_EINVAL;
     auto kern = attn_bwd_kernel<DHP>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static LdsAttrOnce attr_set;
+    if (int e = attr_set.ensure((const void*)kern, 160 * 1024)) return e;
     hipLaunchKernelGGL(kern, dim3(a.H, a.B, ceil_div(a.T, TQ)), dim3(256), fl * sizeof(float), s, a, TQ, SLD);
     ICK_LAUNCH_RET();
 }

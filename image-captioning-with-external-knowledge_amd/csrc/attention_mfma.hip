@@ -502,20 +502,13 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p,
 
 inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-template <typename K>
-int set_lds(K kern, size_t bytes) {
-    if (bytes <= 64 * 1024) return 0;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    return e == hipSuccess ? 0 : (int)e;
-}
-
 template <int NQT, int MAXT>
 int launch_fwd(const ick_attn_args& a, int SP, hipStream_t s) {
     const size_t fl = std::max<size_t>((size_t)DHP * SP, 4 * NQT * 2 * 256) + (size_t)NQT * 16 * QLD + 10 * NQT * 16;
     if (fl * sizeof(float) > 150 * 1024) return kAttnMfmaUnsupported;
     auto kern = attn_fwd_mfma_kernel<NQT, MAXT>;
-    static bool attr = false;
-    if (!attr) { if (int e = set_lds(kern, 160 * 1024)) return e; attr = true; }
+    static LdsAttrOnce attr;
+    if (int e = attr.ensure((const void*)kern, 160 * 1024)) return e;
     hipLaunchKernelGGL(kern, dim3(a.H, a.B), dim3(256), fl * sizeof(float), s, a, SP);
     ICK_LAUNCH_RET();
 }
@@ -530,8 +523,8 @@ int launch_bwd(const ick_attn_bwd_args& a, int SP, hipStream_t s) {
                                (size_t)NQ * SP + 64);
     if (fl * sizeof(float) > 150 * 1024) return kAttnMfmaUnsupported;
     auto kern = attn_bwd_mfma_kernel<NQT, MAXT>;
-    static bool attr = false;
-    if (!attr) { if (int e = set_lds(kern, 160 * 1024)) return e; attr = true; }
+    static LdsAttrOnce attr;
+    if (int e = attr.ensure((const void*)kern, 160 * 1024)) return e;
     // 8-byte stores of dK / dV: every (sample, key, head) row segment starts at an even float offset
     const bool st2 = a.dh % 2 == 0 && a.dk_bs % 2 == 0 && a.dk_ss % 2 == 0 && a.dv_bs % 2 == 0 && a.dv_ss % 2 == 0 &&
                      (reinterpret_cast<uintptr_t>(a.dK) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.dV) & 7) == 0;

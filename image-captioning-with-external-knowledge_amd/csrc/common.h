@@ -28,6 +28,23 @@ inline bool deterministic() {
         if (!(cond)) return ICK_EINVAL; \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): a process-wide "done" flag would leave a
+// second GPU of the process at the 64 KB default and its launches failing.  One bit per device ordinal in an
+// atomic mask per call site; setting the attribute twice from two threads is harmless.
+struct LdsAttrOnce {
+    unsigned long long done = 0;
+    int ensure(const void* kernel, int bytes) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return ICK_EINVAL;
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (__atomic_load_n(&done, __ATOMIC_ACQUIRE) & bit) return ICK_OK;
+        hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return (int)e;
+        __atomic_fetch_or(&done, bit, __ATOMIC_RELEASE);
+        return ICK_OK;
+    }
+};
+
 #define ICK_LAUNCH_RET()                       \
     do {                                       \
         hipError_t e__ = hipGetLastError();    \

@@ -510,14 +510,9 @@ int launch_tile_s(const Plan& pl, hipStream_t s) {
     static_assert(smem <= 160 * 1024, "tile exceeds the LDS of a CU");
     const size_t lds = smem;
     if (lds > 64 * 1024) {
-        static bool attr = false;
-        if (!attr) {
-            hipError_t e = hipFuncSetAttribute(
-                reinterpret_cast<const void*>(gemm_kernel<WM, WN, TM, TN, AKM, BKM, VEC, 32, SPL, LSTG>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return (int)e;
-            attr = true;
-        }
+        static LdsAttrOnce attr;
+        if (int e = attr.ensure(reinterpret_cast<const void*>(gemm_kernel<WM, WN, TM, TN, AKM, BKM, VEC, 32, SPL, LSTG>), 160 * 1024))
+            return e;
     }
     const int gx = pl.tiles_m * pl.tiles_n;
     hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, AKM, BKM, VEC, 32, SPL, LSTG>), dim3(gx, 1, pl.split),
@@ -560,14 +555,9 @@ int launch_group_s(const Plan* const* pls, int n, hipStream_t s) {
     static_assert(smem <= 160 * 1024, "tile exceeds the LDS of a CU");
     const size_t lds = smem;
     if (lds > 64 * 1024) {      // split planes of two k-major operands: 72 KB, above the default dynamic-LDS limit
-        static bool attr = false;
-        if (!attr) {
-            hipError_t e = hipFuncSetAttribute(
-                reinterpret_cast<const void*>(gemm_group_kernel<2, 2, TM, TN, AKM, BKM, true, 32, SPL>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return (int)e;
-            attr = true;
-        }
+        static LdsAttrOnce attr;
+        if (int e = attr.ensure(reinterpret_cast<const void*>(gemm_group_kernel<2, 2, TM, TN, AKM, BKM, true, 32, SPL>), 160 * 1024))
+            return e;
     }
     hipLaunchKernelGGL((gemm_group_kernel<2, 2, TM, TN, AKM, BKM, true, 32, SPL>), dim3(total), dim3(256), lds, s, ga);
     ICK_LAUNCH_RET();
@@ -780,7 +770,11 @@ extern "C" int ick_gemm_plan(const ick_gemm_args* in, ick_gemm_plan_info* out) {
     const int bmn = pl.big ? 64 : 32;
     out->tile_m = pl.wide ? 128 : bmn; out->tile_n = pl.xl ? 128 : bmn; out->waves = pl.wide ? 8 : 4;   // (xl: 4 or 8, ICK_GEMM_XL4)
     out->presplit = pl.ps;
-    if (pl.ps) { int wpc; gemm_ps_tile_dims(pl.ps_tile, &out->tile_m, &out->tile_n, &wpc); out->waves = 8; }
+    if (pl.ps) {
+        int wpc;
+        gemm_ps_tile_dims(pl.ps_tile, &out->tile_m, &out->tile_n, &wpc);
+        out->waves = (pl.ps_tile == 7 || pl.ps_tile == 8) ? 4 : 8;      // the four-wave tiles of csrc/gemm_ps.hip
+    }
     out->tiles_m = pl.tiles_m; out->tiles_n = pl.tiles_n; out->split_k = pl.split;
     out->a_kmajor = pl.akm; out->b_kmajor = pl.bkm; out->vec = pl.vec;
     out->split_bf16 = pl.spl;

@@ -432,13 +432,9 @@ namespace {
 template <class C>
 int launch_ps_cfg(const ick_gemm_args& a, int np_rows, int64_t bytes, int tiles_m, int tiles_n, int kchunk, int split,
                   int a_nt, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ps_kernel<C::WM, C::WN, C::TM, C::TN, C::AKM, C::D, C::PF>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
+    static LdsAttrOnce attr;
+    if (int e = attr.ensure(reinterpret_cast<const void*>(gemm_ps_kernel<C::WM, C::WN, C::TM, C::TN, C::AKM, C::D, C::PF>), 160 * 1024))
+        return e;
     hipLaunchKernelGGL((gemm_ps_kernel<C::WM, C::WN, C::TM, C::TN, C::AKM, C::D, C::PF>), dim3(tiles_m * tiles_n, 1, split),
                        dim3(C::NT), C::LDS, s, a, np_rows, bytes, tiles_m, tiles_n, kchunk, a_nt);
     ICK_LAUNCH_RET();

@@ -357,13 +357,8 @@ extern "C" int ick_rowchain_bwd(const ick_rowchain_bwd_args* in, void* stream) {
         ICK_CHECK_ARG(a.N1 > 0 && a.act && a.t_out && a.w2p);
         ICK_CHECK_ARG(a.o2 && a.mean2 && a.rstd2 && a.gamma2 && a.do2 && a.part2);
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowchain_bwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdSmemMax);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static LdsAttrOnce attr_set;
+    if (int e = attr_set.ensure(reinterpret_cast<const void*>(rowchain_bwd_kernel), (int)kBwdSmemMax)) return e;
     // the launch declares the LDS its own stage widths need (85-104 KB; 136 only with the 1 800-wide K/V gradient input)
     const size_t smem = bwd_smem(lda_for(a.g0 != nullptr ? a.K0 : 0, a.w1p != nullptr ? a.N1 : 0));
     hipLaunchKernelGGL(rowchain_bwd_kernel, dim3(ceil_div(a.M, kRows)), dim3(kThreads), smem, (hipStream_t)stream, a);

@@ -234,7 +234,13 @@ class Encoder(nn.Module):
         """The pre-split copy of conv1's (emb_dim, encoder_dim) weight for ick_gemm's b_ps (refreshed in place when the
         weight changes; None in the exact-fp32 product mode)."""
         w = self.conv1.weight
-        return ops.presplit_cached(self, "conv1", w.detach().view(w.shape[0], -1), (w._version, w.data_ptr()))
+        return ops.presplit_cached(self, "conv1", w.detach().view(w.shape[0], -1),
+                                   (w._version, w.data_ptr(), self.__dict__.get("_param_epoch", 0)))
+
+    def invalidate_caches(self):
+        """Call after conv1's weight was written behind torch's version counters (through .data, a fused optimizer): the
+        pre-split copy is rebuilt on the next use and graphs that captured this encoder are re-captured."""
+        self.__dict__["_param_epoch"] = self.__dict__.get("_param_epoch", 0) + 1
 
     def fine_tune(self, fine_tune=True):
         """Convolutional blocks 2-4 of the trunk train iff fine_tune (geo-aware/models.py:49-60); conv1 is left
@@ -774,7 +780,6 @@ class DecoderTransformer(nn.Module):
         K = entities.shape[1]
         ops.stamp("forward: start")
         pe = self.pos_encoder.pe.view(-1, d)
-        head = {}
 
         def embed(ee, fe):
             return ops.caption_embed(captions, caption_masks, self.word_embedding.weight.detach(), ee, fe, pe, V,
@@ -805,8 +810,10 @@ class DecoderTransformer(nn.Module):
         """Graph-key part for a feature-map input: the attached encoder's conv1 is read through its device pointers."""
         if enc_in.dim() != 4:
             return ()
-        c1 = self.__dict__["_enc"].conv1
-        return (c1.weight.data_ptr(), c1.bias.data_ptr())
+        enc = self.__dict__["_enc"]
+        c1 = enc.conv1
+        return (c1.weight.data_ptr(), c1.bias.data_ptr(), c1.weight._version, c1.bias._version,
+                enc.__dict__.get("_param_epoch", 0))
 
     def input_buffers(self):
         """The static input tensors of the graph the last forward() / predict() / predict_beam() call replayed (None
@@ -826,7 +833,9 @@ class DecoderTransformer(nn.Module):
             plist = self.__dict__["_plist"] = list(self.parameters())
         pkey = (self.__dict__.get("_param_epoch", 0),) + tuple(p._version for p in plist) + \
             tuple(p.data_ptr() for p in plist)
-        full = (kind, key, pkey)
+        # the product mode of the large GEMM tiles is baked into a capture (and decides whether the pre-split weight copies a
+        # graph reads are being refreshed at all): a graph is only replayed in the mode it was captured in
+        full = (kind, key, pkey, ops.gemm_split_mode())
         g = cache.get(full)
         if g is None:
             if len(cache) >= 8:

@@ -45,12 +45,22 @@ def evaluate(encoder, decoder, loader, word_map, max_caption_len=30, out_csv="ge
     # precomputed feature maps go to predict() as they are: Encoder.conv1 then runs inside the captured decode graph
     # beside the context encoders (decoder.attach_encoder); raw images go through the encoder's trunk first
     decoder.attach_encoder(encoder)
+    img_buf = None
     for batch in loader:                                      # any batch size: captions decode independently
-        image, ent, names = batch[0].to(device), batch[4], batch[5]
+        ent, names = batch[4], batch[5]
         has_facts = len(batch) > 6
         extra = (batch[6].to(device),) if has_facts else ()
-        feature_map = image.dim() == 4 and image.shape[1] == encoder.encoder_dim
+        feature_map = batch[0].dim() == 4 and batch[0].shape[1] == encoder.encoder_dim
+        if feature_map and img_buf is not None and img_buf.shape == batch[0].shape:
+            # the host-to-device copy lands straight in the decode graph's own input buffer (widening a float16 feature
+            # file on the way): predict() then skips its device-to-device copy of the feature map (51 MB at batch 32)
+            img_buf.copy_(batch[0], non_blocking=True)
+            image = img_buf
+        else:
+            image = batch[0].to(device)
         seq = decoder.predict(image if feature_map else encoder(image), max_caption_len, ent, *extra)   # (max_len, B)
+        bufs = decoder.input_buffers() if feature_map else None
+        img_buf = bufs[0] if bufs is not None and bufs[0] is not None and bufs[0].dim() == 4 else None
         for b in range(seq.shape[1]):
             ids = seq[:, b].tolist()
             sequences.append(ids)

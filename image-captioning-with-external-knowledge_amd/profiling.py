@@ -18,11 +18,13 @@ PEAK_HBM_GBS = 8000.0             # HBM3E spec
 # fp32-equivalent ceiling of such a kernel -- a fraction against the 157.3 TF of the exact fp32 MFMA could exceed 1.
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_SPLIT_FP32_EQ_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
-# What bounds a row-chain launch is not the matrix pipe: every 8-row workgroup streams the WHOLE weight set of its stages
-# from its XCD's L2 through its own CU, and one CU takes in 66-73 GB/s from L2 whatever is in flight
-# (MI355X_MICROARCH.md, "Indexed rows: gather into LDS": 2 048 rows shared by every workgroup; tools/probes/probe_chain.hip
-# measured 73).  bytes per workgroup / that rate is the floor of a launch, however many CUs run one.
-PER_CU_L2_STREAM_GBS = 70.0
+# What bounds a row-chain launch is not the chip's matrix peak: every 8-row workgroup streams the WHOLE weight set of its
+# stages from its XCD's L2 through its own CU.  A CU's vector L1 fills at 64 B/clk (134 GB/s at the ~2.1 GHz the chip holds
+# in these kernels), and the 4x4x1 MFMA consumes a 4 KiB weight chunk per wave in 256 cycles at 8 rows per workgroup, i.e.
+# the same 64 B/clk per CU: bytes per workgroup / that rate is the floor of a launch however many CUs run one.  (Measured:
+# a latency-limited probe with 72 KiB in flight takes in 66-73 GB/s per CU -- MI355X_MICROARCH.md "Indexed rows: gather
+# into LDS", tools/probes/probe_chain.hip; a 300 x 300 stage of the chain kernel itself ~109 GB/s, profiles/r02_m_chain_stamps.txt.)
+PER_CU_L2_STREAM_GBS = 134.0
 
 
 def _struct(arg):

@@ -75,24 +75,32 @@ class ThreadedBatches:
     """TRAIN batches fetched and pinned by a few threads of this process, handed out in sampler order.  Worker
     PROCESSES move every 51 MB batch of float16 feature maps through shared memory (measured on the GPU box: 267 ms
     per batch with 4 workers against 37 ms fetched in-process); the copies out of the memory map and into pinned
-    memory release the GIL, so threads overlap them."""
+    memory release the GIL, so threads overlap them.
+
+    Aliasing contract.  With a FENCED consumer (one that sets `fenced = True` and leaves, for every batch it took, an event
+    in `release[batch[0].data_ptr()]` after which the batch's feature tensor is no longer read -- the Prefetcher does, its
+    event follows the host-to-device copy) the feature maps are written into a ring of recycled pinned blocks: a batch's
+    image tensor is then only valid until that event, and is overwritten `depth + 4` batches later.  Without one
+    (prefetch=False, list(loader), a batch kept for logging) every batch owns its memory, as a DataLoader's would."""
 
     def __init__(self, dataset, batch_sampler, threads, depth=None):
         self.dataset, self.batch_sampler, self.threads = dataset, batch_sampler, threads
         self.depth = depth or threads + 1
-        # Pinned feature blocks, recycled: a batch's 26-51 MB are copied ONCE, out of the memory map straight into pinned
-        # memory (round 3 copied them into a fresh numpy block and then again into a freshly allocated pinned tensor).  A
-        # block is free again when the host-to-device copy that read it is done (RELEASE: event per block, set by the
-        # Prefetcher); the ring is deep enough that this wait never triggers in steady state.
+        # Pinned feature blocks, recycled (fenced consumers only): a batch's 26-51 MB are copied ONCE, out of the memory map
+        # straight into pinned memory (round 3 copied them into a fresh numpy block and then again into a freshly allocated
+        # pinned tensor).  A block is free again when the consumer's event for it has passed; the ring is deep enough that
+        # this wait never triggers in steady state.  The ring pins (depth + 4) x 26-103 MB for the loader's lifetime.
         self.ring, self.ring_at = [], 0
         self.ring_size = self.depth + 4
+        self.fenced = False
+        self.release = {}      # data_ptr of a ring block -> event after which it may be overwritten (set by the consumer)
 
     def __len__(self):
         return len(self.batch_sampler)
 
     def _block(self, n):
         spec = getattr(self.dataset, "batch_block_spec", lambda n_: None)(n)
-        if spec is None or not torch.cuda.is_available():
+        if spec is None or not torch.cuda.is_available() or not self.fenced:
             return None
         shape, dt = spec
         tdt = torch.float16 if dt == np.float16 else torch.float32
@@ -104,7 +112,7 @@ class ThreadedBatches:
         self.ring_at += 1
         if tuple(blk.shape) != tuple(shape):          # the epoch's last, smaller batch: a block of its own
             return None
-        ev = RELEASE.pop(blk.data_ptr(), None)
+        ev = self.release.pop(blk.data_ptr(), None)
         if ev is not None:
             ev.synchronize()
         return blk
@@ -135,7 +143,6 @@ class ThreadedBatches:
             pool.shutdown(wait=False, cancel_futures=True)
 
 
-RELEASE = {}   # data_ptr of a pinned feature block -> event after which the loader may overwrite it (ThreadedBatches)
 STATS = {}     # "last_epoch_steps_per_s": optimizer steps per second of the last pipelined training epoch (tools/train_rate.py)
 
 
@@ -151,6 +158,10 @@ class Prefetcher:
     the token count (taken from the host copy: no synchronisation)."""
 
     def __init__(self, loader, device, has_facts):
+        # a ThreadedBatches loader recycles its pinned feature blocks for a consumer that fences their reuse (this one)
+        self.release = getattr(loader, "release", None)
+        if self.release is not None:
+            loader.fenced = True
         self.it = iter(loader)
         self.device, self.has_facts = device, has_facts
         self.stream = torch.cuda.Stream(device)
@@ -176,8 +187,8 @@ class Prefetcher:
             facts = batch[6].to(self.device, non_blocking=True) if self.has_facts else None
             ev = torch.cuda.Event()
             ev.record(self.stream)
-        if batch[0].is_pinned():
-            RELEASE[batch[0].data_ptr()] = ev          # the loader's ring may reuse this block once the copy has run
+        if self.release is not None and batch[0].is_pinned():
+            self.release[batch[0].data_ptr()] = ev     # the loader's ring may reuse this block once the copy has run
         self.next = ((imgs, caps, caplens, capmasks, ent, facts), n_tok, ev, batch)   # batch: keeps the pinned source alive
 
     def __iter__(self):
