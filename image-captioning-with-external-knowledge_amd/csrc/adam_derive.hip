@@ -4,7 +4,7 @@
 // K/V weight / bias, the bf16 hi / mid / lo planes of the large GEMMs' weights (csrc/gemm_ps.hip), the transposed
 // predicate weight.  The optimizer is the only writer of the parameters, so nothing else has to re-lay them out: round 4
 // spent 3 ick_pack_weights + 3 ick_presplit_weights launches per step on it (126 us of kernel time at cfg2, 30 MB per
-// launch at 0.18 of the HBM rate; skipping them took 105 us off the 1.73 ms step, gpurun_out/r5_c2_ceilings.txt).
+// launch at 0.18 of the HBM rate; skipping them took 105 us off the 1.73 ms step, profiles/r05_x_ceilings_train.txt).
 //
 // One workgroup = one block of the caller's cover of the bucket (include/ick_amd.h, ick_adam_clamp_derive):
 //   flat run   <= 1024 float4, the seven 16-byte streams of adam_clamp_vec4_kernel (+ an optional plain copy);

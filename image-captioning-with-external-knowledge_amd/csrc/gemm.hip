@@ -686,7 +686,7 @@ int make_plan(const ick_gemm_args* in, Plan& pl, int force_big = 0) {
         // kernel's 128-row tiles (Encoder.conv1 at batch 32 -- 98 workgroups -- took as long as at batch 64).  Below that
         // the 64 x 160 four-wave tile (two per CU) keeps the problem on this kernel as long as it brings >= 128 of them:
         // Encoder.conv1 at batch 32 (cfg5's prefill) 99 us on the stager-split 128 x 64 tiles -> ~35 us less per greedy
-        // decode (2.12 -> 2.05 ms, gpurun_out/r5_c1_ab_conv1_b32.txt; the 128 x 80 tile: 2.06); smaller problems stay on
+        // decode (2.12 -> 2.05 ms, profiles/r05_x_ab_conv1_b32.txt; the 128 x 80 tile: 2.06); smaller problems stay on
         // the stager-split kernel's 128 x 64 tiles (five per row panel)
         const bool narrow = a.N <= 320 && split_req == 1;
         const bool narrow_underfilled = narrow && ceil_div(a.M, 128) * ceil_div(a.N, 160) < 180;

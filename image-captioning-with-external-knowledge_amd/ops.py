@@ -23,14 +23,6 @@ def _f32c(t, name):
     return t
 
 
-# TEMPORARY ceiling experiments (round 5): ICK_EXP=attn,wgrad=small|all,pack skips classes of launches (wrong results,
-# valid timing of everything else) to see what the step time is sensitive to
-_EXP = {"n": 0}
-for _kv in os.environ.get("ICK_EXP", "").split(","):
-    if _kv:
-        _k, _, _v = _kv.partition("=")
-        _EXP[_k] = _v or "1"
-
 # bench.py hook: when set to {"shape": (M, N, K), "events": []}, every ick_gemm launch of that shape is
 # bracketed by HIP events recorded on the launch stream (torch's current stream).
 TIMED = None
@@ -104,8 +96,6 @@ def presplit_weights(pairs):
         assert dst.numel() * dst.element_size() == presplit_bytes(src.shape[0], src.shape[1])
         it.src, it.dst, it.N, it.K = _p(src), _p(dst), src.shape[0], src.shape[1]
         it.src_rs, it.src_cs = src.stride(0), src.stride(1)
-    if _EXP.get("pack"):
-        return
     L.check(L.load().ick_presplit_weights(items, len(pairs), _stream()), "ick_presplit_weights")
 
 
@@ -294,8 +284,6 @@ def pack_weights(pairs, copies=()):
             else:
                 assert dst.is_contiguous() and dst.numel() == packed_weight_floats(src.shape[0], src.shape[1])
                 it.dst_rs = 0
-        if _EXP.get("pack"):
-            continue
         L.check(L.load().ick_pack_weights(items, len(chunk), _stream()), "ick_pack_weights")
 
 
@@ -437,8 +425,6 @@ def attention_raw(Q, K, V, O, B, H, T, S, dh, q_bs, q_hs, q_ts, k_bs, k_hs, k_ss
     a.scale = 1.0 / math.sqrt(dh)
     a.causal, a.q_pos0, a.kv_len = int(causal), q_pos0, _p(kv_len)
     _drop(a, drop)
-    if _EXP.get("attn"):
-        return O
     L.check(L.load().ick_attention(C.byref(a), _stream()), "ick_attention")
     return O
 
@@ -687,8 +673,6 @@ def attention_heads_bwd(q, kv, O, dO, lse, dQ, dK, dV, H, dh, T, S, q_seg=0, k_s
     a.scale = 1.0 / math.sqrt(dh)
     a.causal, a.q_pos0 = int(causal), 0
     _drop(a, drop)
-    if _EXP.get("attn"):
-        return
     L.check(L.load().ick_attention_bwd(C.byref(a), _stream()), "ick_attention_bwd")
 
 
@@ -818,8 +802,6 @@ class SideStream:
 
     def add_problem(self, args, *tensors):
         """Queue a GEMM whose operands are complete on the main stream by the next flush_group()."""
-        if _EXP.get("wgrad") == "all" or (_EXP.get("wgrad") == "small" and not args.b_ps):
-            return
         self.group.append(args)
         self.keep.extend(t for t in tensors if t is not None)
 

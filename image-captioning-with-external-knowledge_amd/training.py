@@ -543,7 +543,7 @@ def _decoder_layer_bwd_chain(dec, li, layer, t, state, dkv_rows, kv, S, grads, p
     # norms' partials right behind the chain launch above, the rest at the layer's end (the side stream finishes last:
     # starting its work earlier shortens the step, 651 -> 654 k decode-steps/s; a third launch right behind the
     # cross-attention backward -- the K/V-projection weight gradient behind its operand -- costs more in fork points than
-    # it gains: round 2 645 k, round 5 1.733 -> 1.739 ms, gpurun_out/r5_c1_ab_subgroups.txt)
+    # it gains: round 2 645 k, round 5 1.733 -> 1.739 ms, profiles/r05_x_ab_kv_wgrad_subgroups.txt)
     if ops.SIDE is not None:
         ops.SIDE.flush_group()
     dq = torch.empty(B, T, d, device=dev, dtype=torch.float32)
