@@ -214,7 +214,11 @@ class Workload:
             # the image rows straight into the decoder's memory buffer.  All-reduces its bucket when world > 1.
             if use_graph:
                 os.environ.setdefault("ICK_ALLREDUCE_PROBE", "1")     # several ranks: time one all-reduce of the bucket
-            ts = TrainStep(dec, lr=4e-4, grad_clip=5.0, seed=self.rank, use_graph=use_graph, encoder=enc)
+            # lazy_update: step i's clamp + Adam runs at the head of step i + 1's graph beside Encoder.conv1 (as
+            # `python -m ick_amd.train` runs it); run_workload() flushes in front of every timed block and again INSIDE it
+            # behind its last step, so a block of K steps holds exactly K forward / backward passes and K optimizer updates
+            ts = TrainStep(dec, lr=4e-4, grad_clip=5.0, seed=self.rank, use_graph=use_graph, encoder=enc,
+                           lazy_update=use_graph and os.environ.get("ICK_BENCH_EAGER_UPDATE") != "1")
             if use_graph:
                 self.train_step = ts
             live = (batch["captions"], feats, batch["caption_masks"], batch["caption_lengths"], batch["entities"], *extra)
@@ -299,11 +303,17 @@ def run_workload(wl, steps, warmup, min_seconds, world, profile_steps, max_repea
             dist.barrier()
         torch.cuda.synchronize()
 
+    def flush():
+        if wl.train_step is not None:
+            wl.train_step.flush()          # (lazy_update) the last step's optimizer update
+
     def block(step):
+        flush()
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        flush()
         fence()
         dt = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
         if world > 1:

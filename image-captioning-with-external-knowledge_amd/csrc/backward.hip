@@ -584,7 +584,9 @@ __global__ __launch_bounds__(256) void adam_clamp_vec4_kernel(float4* __restrict
     }
 }
 
-__global__ void counter_add_kernel(uint32_t* c, uint32_t inc) { *c += inc; }
+__global__ void counter_add_kernel(uint32_t* c, uint32_t inc, const float* flag) {
+    if (flag == nullptr || flag[0] > 0.f) *c += inc;
+}
 
 __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, int64_t n, const float* __restrict__ num,
                                                     const float* __restrict__ den) {
@@ -748,6 +750,12 @@ extern "C" int ick_scale_by_ratio(float* x, int64_t n, const float* num, const f
 
 extern "C" int ick_counter_add(uint32_t* counter, uint32_t inc, void* stream) {
     ICK_CHECK_ARG(counter != nullptr);
-    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, inc);
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, inc, (const float*)nullptr);
+    ICK_LAUNCH_RET();
+}
+
+extern "C" int ick_counter_add_if(uint32_t* counter, uint32_t inc, const float* flag, void* stream) {
+    ICK_CHECK_ARG(counter != nullptr && flag != nullptr);
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, inc, flag);
     ICK_LAUNCH_RET();
 }

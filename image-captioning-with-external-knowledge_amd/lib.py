@@ -195,6 +195,7 @@ SIGNATURES = {
     "ick_adam_clamp": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, i32, vp, vp, vp],
     "ick_adam_clamp_derive": [vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, f32, i32, vp, vp, vp],
     "ick_counter_add": [vp, u32, vp],
+    "ick_counter_add_if": [vp, u32, vp, vp],
     "ick_timestamp": [vp, vp],
     "ick_copy_batch": [vp, vp, vp, i32, vp],
     "ick_scale_by_ratio": [vp, i64, vp, vp, vp],

@@ -1025,5 +1025,10 @@ def counter_add(counter, inc=1):
     L.check(L.load().ick_counter_add(_p(counter), inc, _stream()), "ick_counter_add")
 
 
+def counter_add_if(counter, inc, flag):
+    """counter += inc iff flag[0] > 0 (device scalar), see ick_counter_add_if."""
+    L.check(L.load().ick_counter_add_if(_p(counter), inc, _p(flag), _stream()), "ick_counter_add_if")
+
+
 def scale_by_ratio(x, num, den):
     L.check(L.load().ick_scale_by_ratio(_p(x), x.numel(), _p(num), _p(den), _stream()), "ick_scale_by_ratio")

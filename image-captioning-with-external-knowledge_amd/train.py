@@ -288,6 +288,7 @@ def _train_fused_pipelined(loader, encoder, step, epoch, cfg, device, has_facts)
         start = time.time()
         if cfg.max_batches and i + 1 >= cfg.max_batches:
             break
+    step.flush()                                       # (lazy_update) the last step's optimizer update, before validation
     avg = loss_sum.item() / max(tok_sum, 1)            # the epoch's one synchronisation
     STATS["last_epoch_steps_per_s"] = n / max(time.time() - t_epoch, 1e-9)
     return avg
@@ -413,7 +414,10 @@ def main(cfg=None):
         if det is None and os.environ.get("ICK_DETERMINISTIC") is not None:
             det = os.environ["ICK_DETERMINISTIC"] not in ("", "0")      # the script's switch, read when main() runs
         step = TrainStep(decoder, lr=cfg.decoder_lr, grad_clip=cfg.grad_clip, seed=cfg.seed * 1000 + rank,
-                         encoder=encoder if cfg.prefetch else None, deterministic=det)
+                         encoder=encoder if cfg.prefetch else None, deterministic=det,
+                         # the pipelined loop lets step i's optimizer update run at the head of step i + 1's graph beside
+                         # Encoder.conv1; _train_fused_pipelined() flushes the last one of an epoch
+                         lazy_update=bool(cfg.prefetch))
         if decoder_optimizer is not None:
             # resume: Adam moments, step count (bias correction + dropout stream position) and the decayed lr come
             # back from the pickled optimizer (ours or one written by the reference, geo-aware/utils.py:32-46)

@@ -198,7 +198,7 @@ def _decoder_layer_fwd(dec, li, layer, x, kv, S, tape_list, ds, side=None, pk=No
 
 
 def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gmap, seed=0, epoch=None,
-                      fresh_pack=False, overlap=False, feats=None, conv1=None, side_tail=None, derived=None):
+                      fresh_pack=False, overlap=False, feats=None, conv1=None, side_tail=None, derived=None, pre_side=None):
     """Teacher-forced forward on already length-sorted inputs; returns (scores, tape).  Dropout is
     active iff the module is in train() mode (masks derive from `seed` + the device counter `epoch`).
     fresh_pack: rebuild the packed cross-K/V / transposed predicate weights from the live parameters
@@ -212,7 +212,11 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     feats + conv1 = (weight, bias): instead of enc_tok, the (B, 2048, 14, 14) feature map; Encoder.conv1 then runs
     here and writes the image rows straight into the memory buffer (no (B, 196, d) intermediate, no copy).
     side_tail: work of the caller that nothing in the forward pass waits for (TrainStep: zeroing the gradient bucket,
-    the decode lengths); with `overlap` it runs on the side stream once the context chain is done, else right away."""
+    the decode lengths); with `overlap` it runs on the side stream once the context chain is done, else right away.
+    pre_side (needs overlap, feats and derived): work of the caller that must run BEFORE anything here reads a parameter
+    -- TrainStep's deferred optimizer update of the previous step.  It opens the side stream, beside Encoder.conv1 on the
+    main stream (frozen weights, input features: the one large kernel of the step that reads no trainable parameter);
+    the entity / fact encoders follow it there and the main stream waits for that point behind conv1."""
     tape = Tape()
     m = tape.misc
     ds = DropSites(seed, dec.training, epoch)
@@ -240,10 +244,17 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     first = lambda k: k[0] != "d" or (k[1] == 0 and k[2] in ("so", "cq", "si"))     # context encoders + layer 0's self block
     split_on = ops.gemm_split_mode() >= 1 and not ops.is_deterministic()
 
-    ee = ops.entity_encode(dec.variant, entities, _p(dec.entity_encoder.type_embedding.weight), d,
-                           facts=facts if dec.has_facts else None,
-                           word_emb=_p(dec.word_embedding.weight) if dec.variant == "news" else None)
-    fe = ops.fact_encode(facts, ee, _p(dec.predicate_embedding.weight)) if dec.has_facts else None
+    def encode_context_inputs():
+        ee_ = ops.entity_encode(dec.variant, entities, _p(dec.entity_encoder.type_embedding.weight), d,
+                                facts=facts if dec.has_facts else None,
+                                word_emb=_p(dec.word_embedding.weight) if dec.variant == "news" else None)
+        fe_ = ops.fact_encode(facts, ee_, _p(dec.predicate_embedding.weight)) if dec.has_facts else None
+        return ee_, fe_
+
+    lazy = pre_side is not None and side is not None and feats is not None and derived is not None
+    if pre_side is not None and not lazy:
+        pre_side()
+    ee, fe = (None, None) if lazy else encode_context_inputs()
     if derived is not None:
         wkv, bkv, pk = derived.wkv, derived.bkv, derived.pk
         m["pkb"] = derived.pkb
@@ -301,7 +312,15 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
             else:
                 m["vocab_ps"] = dec._vocab_presplit()
 
+    head = {}
+
     def entity_chain():
+        nonlocal ee, fe
+        if lazy:
+            ops.stamp("side: deferred optimizer update starts")
+            pre_side()
+            ee, fe = head["ee"], head["fe"] = encode_context_inputs()
+            side.signal("head")
         ops.stamp("side: context chain starts")
         # the stack's last add & norm writes the entity rows of the memory buffer directly; beside Encoder.conv1 and the
         # image K/V projection the chain runs in its 8-wave form, which finds room on the CUs the bulk GEMMs occupy
@@ -329,7 +348,7 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
     else:
         img = enc_tok.index_select(0, gmap.long()) if gmap is not None else enc_tok
     if side is not None:
-        side.submit(entity_chain, ee, fe, mem, kv, wkv, bkv, img)
+        side.submit(entity_chain, ee, fe, mem, kv, wkv, bkv, img, entities, facts)
     else:
         entity_chain()
     if feats is not None:
@@ -341,6 +360,9 @@ def forward_with_tape(dec, captions, caption_masks, entities, facts, enc_tok, gm
         mem[:, :P].copy_(img)
     if side is not None:
         side.flush()     # enqueued after the main stream's next kernel (see SideStream)
+        if lazy:
+            side.wait("head")      # from here on the main stream reads parameters (and the encoded entity / fact rows)
+            ee, fe = head["ee"], head["fe"]
         kv_presplit()
     if staged:
         dec._chain_pack(fresh=True, subset=lambda k: not first(k))
@@ -1102,8 +1124,18 @@ class TrainStep:
     replays advance without re-capturing."""
 
     def __init__(self, decoder, lr=4e-4, grad_clip=5.0, betas=(0.9, 0.999), eps=1e-8, process_group=None, seed=0,
-                 use_graph=True, encoder=None, deterministic=None):
+                 use_graph=True, encoder=None, deterministic=None, lazy_update=False):
         self.dec = decoder
+        # lazy_update: the optimizer update of step i runs at the head of step i + 1's graph, on the side stream beside
+        # Encoder.conv1 (see forward_with_tape's pre_side) instead of as a graph of its own at the end of step i, where
+        # nothing overlaps its ~85 us of HBM streaming.  Between two calls the parameters then lag one update behind the
+        # gradients: flush() applies the pending update (state_dict / load_state_dict / set_lr / as_torch_optimizer do it
+        # themselves; call it before reading the decoder's parameters, validating or checkpointing).  Same arithmetic,
+        # same order of optimizer steps; needs the captured two-stream step with the feature-map input (encoder=) and the
+        # optimizer-maintained weight images, else the update stays where it was.
+        self.lazy = bool(lazy_update)
+        self._pending = False
+        self._gb = None
         # deterministic (default: ICK_DETERMINISTIC=1 in the environment): the library's fixed-order reductions, no
         # split GEMMs, everything on one stream -- two runs of the same steps end bit-identical (cost: DESIGN.md)
         # None inherits the library's current mode (ick_get_deterministic: ICK_DETERMINISTIC in the environment unless
@@ -1206,7 +1238,9 @@ class TrainStep:
         scores, tape = forward_with_tape(dec, captions, caption_masks, entities, facts, gmap=gmap,
                                          seed=self.seed * 2654435761 & 0xFFFFFFFF, epoch=self.counter, fresh_pack=True,
                                          overlap=self._overlap("ICK_NO_FWD_OVERLAP"),
-                                         side_tail=tail, derived=self.derived, **self._enc_kwargs(enc_in))
+                                         side_tail=tail, derived=self.derived,
+                                         pre_side=self._deferred_update if self._lazy_active(enc_in) else None,
+                                         **self._enc_kwargs(enc_in))
         decode_len = box["decode_len"]
         tape.misc["prezero"] = box.get("prezero")
         ops.stamp("fwd: scores done")
@@ -1218,6 +1252,31 @@ class TrainStep:
         backward_from_tape(dec, tape, dscores, self.grads, overlap=self._overlap("ICK_NO_BWD_OVERLAP"))
         ops.stamp("A: end (after join)")
         return self.flat_g
+
+    def _lazy_active(self, enc_in):
+        return bool(self.lazy and self.use_graph and self.derived is not None and not self.split and not self.deterministic
+                    and enc_in is not None and enc_in.dim() == 4 and self._overlap("ICK_NO_FWD_OVERLAP"))
+
+    def _deferred_update(self):
+        """The previous step's clamp + Adam and step counter, at the head of this step's graph.  Both are no-ops while the
+        token count in the gradient bucket's tail is zero: the very first step, and the step after a flush()."""
+        self._adam()
+        ops.counter_add_if(self.counter, 1, self.flat_g[self.n + 1:])
+
+    def flush(self):
+        """Apply a pending (lazy_update) optimizer update now; afterwards the parameters, moments, step counter and weight
+        images are what the eager order would have left."""
+        if not self._pending:
+            return
+        if self._gb is not None:
+            self._gb.replay()
+        else:
+            self._part_b()
+        self.flat_g[self.n + 1:].zero_()      # the next step's leading update finds nothing to apply
+        self._pending = False
+        self.dec.invalidate_caches()
+        if self.derived is not None:
+            self.derived.mark_current()
 
     def _adam(self):
         # divide by the global token count (device-resident), clamp, Adam with the device step counter -- and, with
@@ -1312,6 +1371,7 @@ class TrainStep:
         """The optimizer state as torch.optim.Adam.state_dict() would report it (exp_avg / exp_avg_sq / step per
         parameter, one param group), so checkpoints interchange with the reference's `decoder_optimizer`
         (geo-aware/utils.py:32-46) and with the fused=False path.  Tensors are copies."""
+        self.flush()
         self._check_views()
         order = self._adam_order()
         step = float(int(self.counter.item()) & 0xFFFFFFFF)
@@ -1328,6 +1388,7 @@ class TrainStep:
     def load_state_dict(self, sd):
         """Restore Adam moments, step count (which also positions the dropout stream) and learning rate from a
         torch.optim.Adam-layout state dict: ours, the reference's, or the fused=False path's."""
+        self.flush()
         self._check_views()
         order = self._adam_order()
         groups = sd["param_groups"]
@@ -1364,6 +1425,7 @@ class TrainStep:
         """Tell the step that parameter VALUES were written from outside it (through .data, a raw kernel, a restored
         checkpoint): the re-laid-out copies the optimizer kernel maintains are rebuilt before the next step.  In-place
         torch operations on the parameters are noticed without this call (their version counters move)."""
+        self.flush()
         if self.derived is not None:
             self.derived.stale = True
 
@@ -1386,6 +1448,7 @@ class TrainStep:
         return (captions, enc_in, masks, lengths, entities) + ((facts,) if facts is not None else ())
 
     def set_lr(self, lr):
+        self.flush()                  # a pending update was computed under the old rate
         self.lr = float(lr)
         self._graphs.clear()          # baked into the captured optimizer graph
 
@@ -1432,6 +1495,7 @@ class TrainStep:
         if self.derived is not None:
             self.derived.ensure_current()
         if self.use_graph and key not in self._graphs:
+            self.flush()                  # the warm-up runs below must not find gradients waiting to be applied
             if len(self._graphs) >= 4:
                 self._graphs.clear()
             # the eager warm-up run of part B is a real optimizer step: snapshot and rewind its state
@@ -1444,6 +1508,7 @@ class TrainStep:
                     ga, static = self._capture(self._part_a, inputs)
                     ga2 = None
                 gb, _ = self._capture(self._part_b, [])
+                self._gb = gb
                 self._graphs[key] = (ga, static, gb, ga2)
                 self._last_static = static
             except RuntimeError as e:   # capture refused (driver / collective library state): run eagerly
@@ -1456,8 +1521,13 @@ class TrainStep:
             if self.derived is not None:      # the warm-up's optimizer step wrote the images of weights that were just rewound
                 self.derived.stale = True
                 self.derived.ensure_current()
+            self.flat_g[self.n + 1:].zero_()  # (lazy_update: the warm-up's gradients are not a pending update)
         if self.use_graph:
             ga, static, gb, ga2 = self._graphs[key]
+            if self._lazy_active(enc_in) and not self._pending:
+                # nothing is waiting to be applied (first step, or the update was flushed / applied eagerly): the leading
+                # update of the graph must find a zero token count
+                self.flat_g[self.n + 1:].zero_()
             from .decoder import copy_inputs
             copy_inputs(static, inputs)
             ga.replay()
@@ -1471,7 +1541,10 @@ class TrainStep:
                 for w in (w1, w2):
                     if w is not None:
                         w.wait()
-            gb.replay()
+            if self._lazy_active(enc_in):
+                self._pending = True      # applied at the head of the next step's graph (or by flush())
+            else:
+                gb.replay()
         elif self.split:
             self._part_a1(*inputs)
             w1 = dp.allreduce_bucket(self.flat_g[:self.n_early], self.pg, async_op=True)

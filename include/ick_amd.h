@@ -521,6 +521,10 @@ int ick_adam_clamp_derive(float* p, float* g, float* m, float* v, const ick_adam
                           const float* gscale_den, void* stream);
 /* *counter += inc on the stream (step / dropout-epoch counter of captured training graphs). */
 int ick_counter_add(uint32_t* counter, uint32_t inc, void* stream);
+/* ... only if *flag > 0 (device scalar): the step counter of a training step whose optimizer update is deferred into the
+ * next step's graph advances exactly when that update is applied -- ick_adam_clamp[_derive] with gscale_den = flag is a
+ * no-op under the same condition (no pending gradients: first call, or the update was flushed). */
+int ick_counter_add_if(uint32_t* counter, uint32_t inc, const float* flag, void* stream);
 /* n <= 8 device-to-device copies (src[i] -> dst[i], bytes[i]) in one launch; host arrays of device pointers. */
 int ick_copy_batch(const void* const* src, void* const* dst, const long long* bytes, int n, void* stream);
 /* Diagnostic: *out = device wall clock (100 MHz ticks) when the stream reaches this point. */

@@ -134,3 +134,54 @@ def test_outside_writes_to_the_parameters_are_noticed():
     ts.parameters_changed()
     assert ts.derived.stale
     assert abs(ts(*args).item() - l_ref) < 1e-5 and not ts.derived.stale
+
+
+def test_lazy_update_is_the_eager_order_of_optimizer_steps(monkeypatch):
+    """TrainStep(lazy_update=True): step i's clamp + Adam runs at the head of step i + 1's graph (side stream, beside
+    Encoder.conv1) instead of behind step i.  Same optimizer steps in the same order: the loss sequence over alternating
+    batches equals the eager order's, the parameters lag exactly one update until flush(), the step counter advances with
+    the applied updates only, and state_dict() sees the flushed state."""
+    from test_bench_sizes_gpu import make_encoder
+    variant, B, L, K, V, seed = "geo", 6, 9, 6, 160, 13
+    P = synth.make_params(variant, V, seed)
+    enc, _, _ = make_encoder(seed)
+    batches = []
+    for s_ in (seed, seed + 1):
+        b = synth.make_batch(variant, B, L, K, V, 0, s_)
+        batches.append([b["captions"].cuda(), synth.make_feats(B, s_).cuda(), b["caption_masks"].cuda(),
+                        b["caption_lengths"].cuda(), b["entities"]])
+
+    def run(lazy):
+        dec = zero_dropout(build_decoder(variant, V, P).train())
+        ts = TrainStep(dec, lr=4e-4, grad_clip=5.0, encoder=enc, lazy_update=lazy)
+        losses, lagged = [], []
+        for i in range(5):
+            before = ts.flat_p.clone()
+            losses.append(ts(*batches[i % 2]).item())
+            torch.cuda.synchronize()
+            lagged.append(torch.equal(before, ts.flat_p) if i == 0 else None)
+            if i == 0:
+                assert ts._pending == lazy and int(ts.counter.item()) == (0 if lazy else 1)
+        assert ts.use_graph and ts.derived is not None
+        if lazy:
+            assert lagged[0] is True and int(ts.counter.item()) == 4        # four of the five updates applied so far
+            sd = ts.state_dict()                                             # flushes
+            assert not ts._pending and float(sd["state"][0]["step"]) == 5.0
+        else:
+            assert lagged[0] is False
+        assert int(ts.counter.item()) == 5
+        return ts, losses
+
+    ts1, l1 = run(True)
+    ts0, l0 = run(False)
+    assert l0[0] > l0[-1]
+    for a, b_ in zip(l1, l0):
+        assert abs(a - b_) < 2e-4 * max(1.0, abs(b_)), (l1, l0)
+    assert (ts1.flat_p - ts0.flat_p).abs().max().item() <= 5 * 4e-4 + 1e-6
+    assert ((ts1.flat_p - ts0.flat_p).abs() > 1e-4).float().mean().item() < 0.02
+    # a flushed step followed by more steps: nothing is applied twice
+    l_next1, l_next0 = ts1(*batches[1]).item(), ts0(*batches[1]).item()
+    assert abs(l_next1 - l_next0) < 2e-4 * max(1.0, abs(l_next0))
+    ts1.flush()
+    torch.cuda.synchronize()
+    assert int(ts1.counter.item()) == int(ts0.counter.item()) == 6

@@ -25,7 +25,8 @@ from ick_amd import ops  # noqa: E402
 if os.environ.get("ICK_TIMESTAMPS"):
     ops.stamps_enable()
 IN_GRAPH = os.environ.get("ICK_SEPARATE_ENCODER") is None     # conv1 inside the captured step (bench.py's path)
-ts = TrainStep(dec, lr=4e-4, grad_clip=5.0, seed=0, encoder=enc if IN_GRAPH else None)
+ts = TrainStep(dec, lr=4e-4, grad_clip=5.0, seed=0, encoder=enc if IN_GRAPH else None,
+               lazy_update=IN_GRAPH and os.environ.get("ICK_BENCH_EAGER_UPDATE") != "1")     # bench.py's path
 
 
 def step():
