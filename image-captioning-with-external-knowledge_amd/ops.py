@@ -144,8 +144,9 @@ def set_gemm_split(mode):
     """Product mode of the large GEMM tiles (ick_set_gemm_split; ICK_GEMM_SPLIT in the environment; DEFAULT 1 since round
     4): 0 = every product on the exact fp32 MFMA; 1 = six bf16 x bf16 partial products of the exact three-way bf16 split
     of both fp32 operands, accumulated in fp32, where that is faster (B operand k-contiguous or pre-split); 2 = on every
-    large-tile problem.  Non-finite operands: the split of +-inf / NaN is (hi, 0, 0), so they propagate as in fp32; a
-    finite value within 2^-8 of FLT_MAX rounds to an infinite hi plane (documented difference to the exact mode)."""
+    large-tile problem.  Non-finite operands (documented difference, tests/test_gemm_split_gpu.py): the residual planes
+    of a +-inf element -- and of a finite one within 2^-8 of FLT_MAX, whose bf16 hi plane rounds to infinity -- are NaN
+    (inf - inf), so its dot products are NaN in the split modes where the exact mode gives +-inf / a finite sum."""
     L.check(L.load().ick_set_gemm_split(int(mode)), "ick_set_gemm_split")
 
 
@@ -939,7 +940,8 @@ def linear_bwd(dy, x, w, dw, db, need_dx=True, dx=None, accumulate_dx=False, gro
             # (1280 x 300 x 900: 22 -> ~10 us; the kernel is bound by the latency of its K loop)
             split = max(1, min(8, (N + 150) // 300))
         if wt_ps is not None and split > 1 and gemm_split_mode() >= 1 and K <= 320:
-            # the pre-split kernel's 64 x 320 tile covers every output column: ~256 workgroups = row tiles x K slices
+            # the pre-split kernel (the plan picks its 128 x 80 tile for split-K problems at most 320 columns wide): K slices
+            # so that row tiles x 4 column tiles x slices take the chip's ~512 two-per-CU slots once (cfg2: 10 x 4 x 12)
             split = max(1, min(16, N // 512, 256 // ((M + 63) // 64)))
         if split > 1:
             if dx is None:

@@ -331,3 +331,30 @@ def test_presplit_gemm_epilogues(ops):
     exact, split = outs
     assert (split - exact).abs().max().item() < 2e-5
     assert torch.equal(split[..., 30:], exact[..., 30:]) and torch.equal(split[:, :, :, P:], exact[:, :, :, P:])   # untouched pads / rows
+
+
+def test_non_finite_operands_documented_behaviour(ops):
+    """the exact three-way split of +-inf (and of a finite value that rounds to an infinite bf16 hi plane) has
+    NaN residual planes, so its dot products are NaN in the split modes where the exact fp32 MFMA gives +-inf / a finite
+    sum.  Documented (ops.set_gemm_split), not patched: the split is on the instruction stream that bounds
+    those tiles.  Finite operands of ordinary magnitude are unaffected -- including 1e30, far beyond anything a network
+    holds."""
+    M, N, K = 1280, 2048, 300
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1)
+    A[3, 7] = float("inf")
+    A[5, 9] = 1e30
+    A[8, 1] = 3.4e38          # finite, but its bf16 hi plane rounds to infinity
+    W[11, 9] = 1e-30
+    out = {}
+    for mode in (0, 1):
+        ops.set_gemm_split(mode)
+        o = torch.empty(M, N, device="cuda")
+        ops.gemm_raw(A, W, o, M, N, K, K, 1, K, 1, N)
+        out[mode] = o.clone()
+    assert torch.isinf(out[0][3]).all() and not torch.isfinite(out[1][3]).any()          # +-inf vs NaN
+    assert torch.isfinite(out[0][8]).all() and not torch.isfinite(out[1][8]).any()       # finite vs NaN
+    ok = torch.ones(M, dtype=torch.bool, device="cuda")
+    ok[[3, 8]] = False
+    assert torch.isfinite(out[1][ok]).all()
+    ref5 = A[5].double() @ W.double().t()
+    assert (out[1][5].double() - ref5).abs().max().item() <= 1e-6 * ref5.abs().max().item()
