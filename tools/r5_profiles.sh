@@ -10,7 +10,7 @@ cd $GRAFT_REPO_ROOT
 for spec in $todo; do
   mode=${spec%%:*}; cfg=${spec##*:}
   t=${tag}_${cfg}
-  marker=adam_derive_kernel
+  marker=packed_ce_rows_kernel      # once per pass, eager warm-up passes included (the optimizer kernel is not: flushes, no-op launches)
   [ $mode = forward ] && marker=caption_embed_kernel
   [ $mode = greedy ] && marker=dec_init
   [ $mode = beam ] && marker=dec_init
@@ -22,5 +22,5 @@ for spec in $todo; do
   head -6 gpurun_out/${t}_traffic_${mode}.txt | cut -c1-150
   rm -rf gpurun_out/pmc_${t}_${mode}_FETCH_SIZE gpurun_out/pmc_${t}_${mode}_WRITE_SIZE      # large CSVs: the tables are what is kept
 done
-python3 tools/timeline.py gpurun_out/prof_${tag}_cfg2_train adam_derive > gpurun_out/${tag}_train_kernel_timeline.txt 2>&1
+python3 tools/timeline.py gpurun_out/prof_${tag}_cfg2_train packed_ce_reduce > gpurun_out/${tag}_train_kernel_timeline.txt 2>&1
 ICK_TIMESTAMPS=1 timeout -k 10 200 python3 tools/host_bound.py > gpurun_out/${tag}_train_device_timestamps.txt 2>&1; tail -42 gpurun_out/${tag}_train_device_timestamps.txt
