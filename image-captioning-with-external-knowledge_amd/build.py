@@ -22,7 +22,7 @@ def source_id():
     import hashlib
     h = hashlib.sha256()
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
-    files += [os.path.join(INCLUDE, "ick_amd.h")] + [os.path.join(PKG, f) for f in ("training.py", "decoder.py", "ops.py", "dp.py")]
+    files += [os.path.join(INCLUDE, "ick_amd.h")] + [os.path.join(PKG, f) for f in ("training.py", "weights.py", "decoder.py", "ops.py", "dp.py")]
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
