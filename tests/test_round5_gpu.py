@@ -184,3 +184,13 @@ def test_bench_two_gpus_over_rccl():
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["config"]["global_batch"] == 128 and d["value"] > 0
     assert d["config"]["collective_backend"] == "nccl" and d["config"]["graph"] is True
     assert d["config"]["allreduce_probe_ms"] > 0
+
+
+def test_news_train_step_vs_oracle(plan_log):
+    """The captured TrainStep of the NEWS variant (entity names averaged over the word embedding, facts, predicate gate:
+    news-knowledge-aware/models.py:79-134) against the reference sequence on the oracle -- loss, every gradient, Adam's
+    closed form on every element -- with the optimizer-maintained weight images (round 5): the news entity encoder reads
+    the word embedding, which the same kernel updates."""
+    from test_bench_sizes_gpu import run_train_step_vs_oracle
+    ts, _ = run_train_step_vs_oracle("news", 16, 12, 21, 400, 31, 41, plan_log)
+    assert ts.derived is not None and ts.derived.pred_wt is not None
