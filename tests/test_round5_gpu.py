@@ -194,3 +194,49 @@ def test_news_train_step_vs_oracle(plan_log):
     from test_bench_sizes_gpu import run_train_step_vs_oracle
     ts, _ = run_train_step_vs_oracle("news", 16, 12, 21, 400, 31, 41, plan_log)
     assert ts.derived is not None and ts.derived.pred_wt is not None
+
+
+def test_bench_train_step_with_lazy_update_b64(plan_log):
+    """bench.py's exact train configuration: TrainStep(encoder=, lazy_update=True) from the features at B = 64.  After the
+    first call the update is pending (parameters untouched, loss and raw gradients in the bucket: checked against the digest
+    and the oracle); the second call applies it at the head of its graph beside Encoder.conv1 -- the loss it then computes
+    is the oracle's loss AFTER one reference optimizer step; flush() leaves Adam's closed form on every element."""
+    from ick_amd.training import TrainStep
+    g = load_golden("digest_cfg2_b64")
+    cfg, P, wm, batch, _ = case_from_golden(g)
+    B, seed = int(g["B"]), int(g["seed"])
+    loss_ref, grads_ref, P_after = _oracle_step_from_features(g)
+    enc, cw, cb = make_encoder(seed)
+    dec = zero_dropout(build_decoder(cfg.variant, cfg.vocab_size, P).train())
+    ts = TrainStep(dec, lr=4e-4, grad_clip=5.0, encoder=enc, lazy_update=True)
+    args = [batch["captions"].cuda(), synth.make_feats(B, seed).cuda(), batch["caption_masks"].cuda(),
+            batch["caption_lengths"].cuda(), batch["entities"]]
+    p0 = ts.flat_p.clone()
+    loss1 = ts(*args).item()
+    torch.cuda.synchronize()
+    assert ts.use_graph and ts._pending and torch.equal(ts.flat_p, p0) and int(ts.counter.item()) == 0
+    assert abs(loss1 - float(g["loss"][0])) < 2e-5
+    named = dict(dec.named_parameters())
+    count = ts.flat_g[ts.n + 1].item()
+    for k in ("fc_vocab.weight", "transformer_decoder.layers.0.self_attn.in_proj_weight",
+              "transformer_encoder_entities.layers.2.linear2.weight", "entity_encoder.type_embedding.weight"):
+        mine = ts.grads[id(named[k])].detach().cpu() / count            # pending: the bucket still holds the raw token sums
+        gr = grads_ref[k]
+        assert (mine - gr).abs().max().item() < 2e-3 * max(1e-3, gr.abs().max().item()), k
+    # the oracle's loss after its own optimizer step, on the same batch
+    Pn = {k: v.detach() for k, v in P_after.items()}
+    with torch.no_grad():
+        enc_out = R.feat_proj(synth.make_feats(B, seed), cw, cb)
+        sc, caps, dl = R.forward(cfg, Pn, batch["captions"], enc_out, batch["caption_masks"], batch["caption_lengths"],
+                                 batch["entities"])
+        loss2_ref = R.packed_ce_loss(cfg, sc, caps, dl).item()
+    g1 = (ts.flat_g[:ts.n] / count).clamp(-5.0, 5.0).double().cpu()
+    loss2 = ts(*args).item()                                              # applies update 1 at the head of its graph
+    torch.cuda.synchronize()
+    assert int(ts.counter.item()) == 1 and ts._pending
+    assert abs(loss2 - loss2_ref) < 5e-4 * max(1.0, abs(loss2_ref)), (loss2, loss2_ref)
+    expect = p0.double().cpu() - 4e-4 * g1 / (g1.abs() + 1e-8)           # Adam's first step in closed form, every element
+    assert (ts.flat_p.double().cpu() - expect).abs().max().item() < 2e-7 + 1e-6 * p0.abs().max().item()
+    ts.flush()
+    torch.cuda.synchronize()
+    assert int(ts.counter.item()) == 2 and not ts._pending
