@@ -75,21 +75,40 @@ __global__ __launch_bounds__(256) void presplit_kernel(PsBatch b) {
     const int nb = local % blocks_n, s = local / blocks_n;
     const int t = threadIdx.x;
     const float* src = it.src;
+    // 32 contiguous source bytes per thread: two 16-byte loads where the view allows (the activation planes of the backward
+    // pass -- memory^T, h^T -- are made inside the step: a dword per lane moves a quarter of what a dwordx4 does)
+    const bool al16 = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
     if (it.src_cs == 1) {                 // k contiguous: 8 consecutive k of one row per thread
         const int r = t >> 2, kk = (t & 3) * 8;
         const int n = nb * 64 + r;
+        const int k0 = 32 * s + kk;
+        if (al16 && (it.src_rs & 3) == 0 && n < it.N && k0 + 7 < it.K) {
+            const float4* q = reinterpret_cast<const float4*>(src + (int64_t)n * it.src_rs + k0);
+            const float4 a = q[0], b = q[1];
+            tile[r][kk + 0] = a.x; tile[r][kk + 1] = a.y; tile[r][kk + 2] = a.z; tile[r][kk + 3] = a.w;
+            tile[r][kk + 4] = b.x; tile[r][kk + 5] = b.y; tile[r][kk + 6] = b.z; tile[r][kk + 7] = b.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = 32 * s + kk + j;
-            tile[r][kk + j] = (n < it.N && k < it.K) ? src[(int64_t)n * it.src_rs + k] : 0.f;
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j;
+                tile[r][kk + j] = (n < it.N && k < it.K) ? src[(int64_t)n * it.src_rs + k] : 0.f;
+            }
         }
     } else {                              // rows contiguous (a transposed view): 8 consecutive rows at one k per thread
         const int kk = t >> 3, r0 = (t & 7) * 8;
         const int k = 32 * s + kk;
+        const int n0 = nb * 64 + r0;
+        if (al16 && it.src_rs == 1 && (it.src_cs & 3) == 0 && n0 + 7 < it.N && k < it.K) {
+            const float4* q = reinterpret_cast<const float4*>(src + n0 + (int64_t)k * it.src_cs);
+            const float4 a = q[0], b = q[1];
+            tile[r0 + 0][kk] = a.x; tile[r0 + 1][kk] = a.y; tile[r0 + 2][kk] = a.z; tile[r0 + 3][kk] = a.w;
+            tile[r0 + 4][kk] = b.x; tile[r0 + 5][kk] = b.y; tile[r0 + 6][kk] = b.z; tile[r0 + 7][kk] = b.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int n = nb * 64 + r0 + j;
-            tile[r0 + j][kk] = (n < it.N && k < it.K) ? src[(int64_t)n * it.src_rs + (int64_t)k * it.src_cs] : 0.f;
+            for (int j = 0; j < 8; ++j) {
+                const int n = n0 + j;
+                tile[n - nb * 64][kk] = (n < it.N && k < it.K) ? src[(int64_t)n * it.src_rs + (int64_t)k * it.src_cs] : 0.f;
+            }
         }
     }
     __syncthreads();

@@ -1016,7 +1016,7 @@ def adam_clamp_derive(p, g, m, v, items_dev, blocks_dev, n_blocks, step, lr, cli
                       eps=1e-8, step_tensor=None, gscale_den=None, nbytes=0):
     """adam_clamp over the whole bucket + the re-laid-out copies of the updated weights in the same pass
     (ick_adam_clamp_derive; items_dev / blocks_dev: device arrays of ick_adam_item / ick_adam_block built by
-    training.DerivedWeights).  nbytes: the launch's algorithmic bytes, for profiling.py."""
+    weights.DerivedWeights).  nbytes: the launch's algorithmic bytes, for profiling.py."""
     L.ADAM_DERIVE_BYTES = nbytes
     L.check(L.load().ick_adam_clamp_derive(_p(p), _p(g), _p(m), _p(v), _p(items_dev), _p(blocks_dev), n_blocks, gscale,
                                            clip, lr, beta1, beta2, eps, step, _p(step_tensor), _p(gscale_den), _stream()),
