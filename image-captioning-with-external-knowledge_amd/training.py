@@ -655,9 +655,13 @@ def _kv_proj_param_grads(layer, li, dkv_rows, mem2, grads, d, mem_t_ps=None):
     sl = dkv_rows.view(rows, -1)[:, 2 * li * d:(2 * li + 2) * d]
     if gw is not None:
         if mem_t_ps is not None:
-            # 5 x 4 tiles of 128 x 80 (two workgroups per CU): K slices so that ~320 workgroups exist (sweep inside the
-            # step, profiles/r04_y_ab_bwd_splits.txt: 16 slices 1.695-1.705 ms, 12 / 24 / 32 slices 1.711-1.720)
-            split = max(1, min(32, 320 // (((2 * d + 127) // 128) * ((d + 79) // 80)), rows // 256))
+            # 5 x 4 tiles of 128 x 80: K slices so that ~160 workgroups exist -- 8 slices, one per XCD (the kernel deals the
+            # (slice, tile) pairs to the XCDs slice-major), half the float atomics of 16 slices and one workgroup per CU,
+            # which leaves the CU's other slot to the main stream's kernels.  Sweeps inside the step: round 4
+            # (profiles/r04_y_ab_bwd_splits.txt) 16 slices 1.695-1.705 ms against 12 / 24 / 32 at 1.711-1.720; round 5
+            # (profiles/r05_x_ab_kv_wgrad_slices.txt) 8 slices 1.703-1.726 against 16 at 1.727-1.743 on the same boxes,
+            # 4 / 6 / 10 / 24 slices 1.85 / 1.77 / 1.76 / 1.74-1.75
+            split = max(1, min(32, 160 // (((2 * d + 127) // 128) * ((d + 79) // 80)), rows // 256))
             wg = ops.gemm_args(sl, mem2, gw[d:], 2 * d, d, rows, 1, sl.stride(0), 1, d, d, atomic=True, split_k=split,
                                b_ps=mem_t_ps)
             extra = [] if gb is None else [ops.colsum_problem(sl, gb[d:], split_k=max(1, min(16, rows // 512)))]

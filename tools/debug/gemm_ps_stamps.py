@@ -25,8 +25,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     g = torch.Generator(device="cuda").manual_seed(1)
     if lay == "nchw":
         A = torch.randn(M // 196, K, 196, device="cuda", generator=g); aargs = (1, 196); akw = dict(a_grp=196, a_gs=K * 196)
+    elif lay.startswith("kmaj"):
+        ld = int(lay[4:])
+        A = torch.randn(K, ld, device="cuda", generator=g)[:, :M]; aargs = (1, ld); akw = {}    # element (m, k) at A[k, m]
     else:
         A = torch.randn(M, K, device="cuda", generator=g); aargs = (K, 1); akw = {}
+    if split_k > 1:
+        akw.update(atomic=True, split_k=split_k)
     W = torch.randn(N, K, device="cuda", generator=g) * 0.1
     ps = ops.presplit_buffer(N, K, "cuda")
     ops.presplit_weights([(W, ps)])

@@ -12,6 +12,7 @@ sys.path.insert(0, ROOT)
 
 SHAPES = {  # name: (M, N, K, a_layout, split_k)
     "conv1": (12544, 300, 2048, "nchw", 1),
+    "conv1_b32": (6272, 300, 2048, "nchw", 1),            # cfg5's prefill
     "vocab_dgrad": (1280, 300, 10000, "rows", 0),
     "cross_kv": (12544, 1800, 300, "rows", 1),
     "vocab_fwd": (1280, 10000, 300, "rows", 1),
