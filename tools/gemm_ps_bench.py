@@ -18,6 +18,7 @@ SHAPES = {  # name: (M, N, K, a_layout, split_k)
     "vocab_fwd": (1280, 10000, 300, "rows", 1),
     "kv_wgrad": (600, 300, 13824, "kmaj1800", 24),      # dW_kv of one layer: A = a 600-column slice of the (13824, 1800) K/V gradient
     "kv_wgrad_s16": (600, 300, 13824, "kmaj1800", 16),
+    "kv_wgrad_s8": (600, 300, 13824, "kmaj1800", 8),
     "cross_kv_cfg4": (12544, 1800, 300, "rows", 1),
     "vocab_fwd_cfg4": (1280, 50000, 300, "rows", 1),
 }
