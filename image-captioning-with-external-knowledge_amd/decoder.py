@@ -51,8 +51,7 @@ class _GraphedCall:
                 fn(*self.static_in)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        # thread_local: other threads (e.g. the RCCL watchdog) may touch the HIP runtime while we capture
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        with ops.capture(self.graph):
             self.static_out = fn(*self.static_in)
 
     def __call__(self, *inputs):

@@ -1,6 +1,8 @@
 """Per-op Python wrappers over the C ABI.  Tensors are torch CUDA(ROCm) tensors used purely as
 device memory + stream plumbing; all arithmetic happens in libick_amd.so."""
+import contextlib
 import ctypes as C
+import gc
 import math
 import os
 
@@ -774,6 +776,25 @@ def copy_batch(dst, src):
         dp = (C.c_void_p * n)(*[t.data_ptr() for t in d])
         nb = (C.c_longlong * n)(*[t.numel() * t.element_size() for t in d])
         L.check(L.load().ick_copy_batch(sp, dp, nb, n, _stream()), "ick_copy_batch")
+
+
+@contextlib.contextmanager
+def capture(graph):
+    """torch.cuda.graph(graph) for the package's hipGraph captures, with Python's cyclic garbage collector held off until
+    the capture has ended.  A collection that starts inside the capture region may finalise objects of EARLIER work that
+    sit in reference cycles -- a finished TrainStep's CUDAGraph, its streams -- and destroying those while the thread's
+    stream is capturing aborts the process (seen once in the full GPU suite: `Fatal Python error: Aborted`,
+    `Garbage-collecting`, inside a captured backward pass).  torch.cuda.graph itself collects right before it begins the
+    capture, so nothing is left waiting; whatever the captured function leaves behind is collected after capture_end.
+    thread_local: other threads (the RCCL watchdog) may touch the HIP runtime while this one captures."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class SideStream:

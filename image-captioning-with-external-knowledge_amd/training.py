@@ -1161,8 +1161,7 @@ class TrainStep:
             fn(*static)
         torch.cuda.current_stream().wait_stream(side)
         g = torch.cuda.CUDAGraph()
-        # thread_local: the RCCL watchdog thread may query events while this thread captures
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        with ops.capture(g):
             fn(*static)
         return g, static
 
@@ -1177,9 +1176,9 @@ class TrainStep:
             self._part_a2()
         torch.cuda.current_stream().wait_stream(side)
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+        with ops.capture(g1):
             self._part_a1(*static)
-        with torch.cuda.graph(g2, capture_error_mode="thread_local"):   # own pool: the tape keeps A1's tensors alive
+        with ops.capture(g2):   # own pool: the tape keeps A1's tensors alive
             self._part_a2()
         return g1, static, g2
 

@@ -240,3 +240,39 @@ def test_bench_train_step_with_lazy_update_b64(plan_log):
     ts.flush()
     torch.cuda.synchronize()
     assert int(ts.counter.item()) == 2 and not ts._pending
+
+
+def test_graph_capture_holds_the_cyclic_collector_off():
+    """ops.capture: no garbage collection may start inside a capture region (finalising an earlier step's graph or streams
+    there aborted the process once in the full suite), the collector's state is restored afterwards, also on an error."""
+    import gc
+
+    class Cycle:
+        def __init__(self):
+            self.me = self
+            self.graph = torch.cuda.CUDAGraph()      # what a finished TrainStep leaves in a reference cycle
+
+    x = torch.ones(1024, device="cuda")
+    y = torch.empty_like(x)
+    seen = {}
+    g = torch.cuda.CUDAGraph()
+    old = gc.get_threshold()
+    gc.set_threshold(1, 1, 1)          # any allocation would start a collection
+    try:
+        assert gc.isenabled()
+        with ops.capture(g):
+            seen["enabled"] = gc.isenabled()
+            Cycle()
+            junk = [[i] for i in range(1000)]        # allocations that would trigger the collector
+            del junk
+            torch.mul(x, 2.0, out=y)
+        assert seen["enabled"] is False and gc.isenabled()
+        with pytest.raises(RuntimeError):
+            with ops.capture(torch.cuda.CUDAGraph()):
+                raise RuntimeError("inside")
+        assert gc.isenabled()
+    finally:
+        gc.set_threshold(*old)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, x * 2)
