@@ -1,6 +1,6 @@
 """Phase timing of the row-chain kernel (diagnostic): builds a copy of the library with -DICK_CHAIN_STAMPS, runs one
 chain shape and prints, for thread 0 of workgroup 0 of the last launch, the shader-clock deltas between the phase
-stamps (100 MHz s_memtime ticks -> 10 ns each)."""
+stamps (s_memtime: shader-clock cycles)."""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -36,5 +36,8 @@ for M, K1, N2, heads in [(1280, 300, 300, True), (1280, 300, 512, False), (1280,
     assert lib.ick_debug_read_chain_stamps(buf) == 0
     n = 10 if N2 else 6
     t = [buf[i] for i in range(n + 1)]
-    print("K1=%d N2=%d: total %.2f us: " % (K1, N2, (t[-1] - t[0]) / 100.0) +
-          ", ".join("%s %.2f" % (names[i], (t[i + 1] - t[i]) / 100.0) for i in range(n)))
+    # s_memtime counts shader-clock cycles on gfx950 (~2.1 GHz while these kernels run; csrc/gemm_ps.hip's stamps measure the
+    # clock against s_memrealtime), not the 100 MHz of the reference clock: print cycles and shares
+    tot = t[-1] - t[0]
+    print("K1=%d N2=%d: %d cycles inside workgroup 0 (~%.1f us at 2.1 GHz): " % (K1, N2, tot, tot / 2100.0) +
+          ", ".join("%s %d (%.0f %%)" % (names[i], t[i + 1] - t[i], 100.0 * (t[i + 1] - t[i]) / tot) for i in range(n)))
