@@ -96,7 +96,21 @@ __global__ __launch_bounds__(NW * 64) void rowchain_fwd_kernel(ick_rowchain_args
         int64_t off = (int64_t)gr * p.a_rs;
         if (p.a_grp > 0) { const int g = small_div(gr, p.a_grp); off = (int64_t)g * p.a_gs + (int64_t)(gr - g * p.a_grp) * p.a_rs; }
         const float* arow = p.A + off;
-        for (int k = lane + 64 * part; k < K1p; k += 8 * NW) Xs[r * kLdx + k] = (gr < M && k < K1) ? arow[k] : 0.f;
+        // every load of the row is issued before the first LDS store waits for one (as a loop the compiler put a
+        // vmcnt(0) in front of every store: one memory round trip per 128 columns, and the first of them also waited
+        // for the weight chunks requested above)
+        constexpr int NA = (kMaxK + 16 + 8 * NW - 1) / (8 * NW);
+        float av[NA];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int k = lane + 64 * part + j * 8 * NW;
+            av[j] = (gr < M && k < K1) ? arow[k] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int k = lane + 64 * part + j * 8 * NW;
+            if (k < K1p) Xs[r * kLdx + k] = av[j];
+        }
     }
     ICK_CSTAMP(2);
     if (!proj) __syncthreads();      // (projection only: the barrier in front of GEMM 2 below covers the rows)

@@ -145,7 +145,21 @@ __global__ __launch_bounds__(kThreads) ICK_CHAIN_BWD_ATTR void rowchain_bwd_kern
         int64_t goff = (int64_t)gr * p.g0_rs;
         if (p.g0_grp > 0) { const int g = small_div(gr, p.g0_grp); goff = (int64_t)g * p.g0_gs + (int64_t)(gr - g * p.g0_grp) * p.g0_rs; }
         const float* grow = p.g0 + goff;
-        for (int k = lane + 64 * half; k < K0p; k += 128) XA[r * kLdA + k] = (gr < M && k < K0) ? grow[k] : 0.f;
+        // all loads of the row first, then the LDS stores (as a loop: one memory round trip per 128 columns, up to 15 for the
+        // 1 800-wide all-layer K/V gradient; train step 1.69 -> 1.65 ms together with the forward kernel's rows,
+        // profiles/r05_x_ab_chain_row_loads.txt)
+        constexpr int NA0 = (kMaxK0 + 16 + 127) / 128;
+        float gv[NA0];
+#pragma unroll
+        for (int j = 0; j < NA0; ++j) {
+            const int k = lane + 64 * half + 128 * j;
+            gv[j] = (gr < M && k < K0) ? grow[k] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NA0; ++j) {
+            const int k = lane + 64 * half + 128 * j;
+            if (k < K0p) XA[r * kLdA + k] = gv[j];
+        }
         __syncthreads();
         const Slab w = slab_of(g0p);
         f32x4 acc0, acc1;
