@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void attn_kernel(ick_attn_args p, int TQ, int 
     const int h = blockIdx.x, b = blockIdx.y, t0 = blockIdx.z * TQ;
     const int nt = min(TQ, p.T - t0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const Dropout drop = make_dropout(p.drop_p, p.drop_epoch ? p.drop_seed + *p.drop_epoch : p.drop_seed, p.drop_site);
+    const Dropout drop = make_dropout(p.drop_p, epoch_seed(p.drop_seed, p.drop_epoch), p.drop_site);
     int slen = S;
     if (p.kv_len) slen = min(S, p.kv_len[b]);
     const float* qb = p.Q + (int64_t)b * p.q_bs + (int64_t)h * p.q_hs + (int64_t)t0 * p.q_ts;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(ick_attn_bwd_args p, int 
     const int nt = min(TQ, p.T - t0);
     const int tid = threadIdx.x;
     const bool multi = gridDim.z > 1;
-    const Dropout drop = make_dropout(p.drop_p, p.drop_epoch ? p.drop_seed + *p.drop_epoch : p.drop_seed, p.drop_site);
+    const Dropout drop = make_dropout(p.drop_p, epoch_seed(p.drop_seed, p.drop_epoch), p.drop_site);
     const float* qb = p.Q + (int64_t)b * p.q_bs + (int64_t)h * p.q_hs + (int64_t)t0 * DHP;
     const float* kb = p.K + (int64_t)b * p.k_bs + (int64_t)h * p.k_hs;
     const float* vb = p.V + (int64_t)b * p.v_bs + (int64_t)h * p.v_hs;

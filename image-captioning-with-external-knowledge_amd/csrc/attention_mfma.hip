@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ick_attn_args p, int
     int slen = S;
     if (p.kv_len) slen = min(S, p.kv_len[b]);
     const int nkt = (S + 15) >> 4;       // key tiles
-    const Dropout drop = make_dropout(p.drop_p, p.drop_epoch ? p.drop_seed + *p.drop_epoch : p.drop_seed, p.drop_site);
+    const Dropout drop = make_dropout(p.drop_p, epoch_seed(p.drop_seed, p.drop_epoch), p.drop_site);
     const float* qb = p.Q + (int64_t)b * p.q_bs + (int64_t)h * p.q_hs;
     const float* kb = p.K + (int64_t)b * p.k_bs + (int64_t)h * p.k_hs;
     const float* vb = p.V + (int64_t)b * p.v_bs + (int64_t)h * p.v_hs;
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(ick_attn_bwd_args p,
     const int li = lane & 15, lq = lane >> 4;
     const int T = p.T, S = p.S, dh = p.dh;
     const int nkt = (S + 15) >> 4;
-    const Dropout drop = make_dropout(p.drop_p, p.drop_epoch ? p.drop_seed + *p.drop_epoch : p.drop_seed, p.drop_site);
+    const Dropout drop = make_dropout(p.drop_p, epoch_seed(p.drop_seed, p.drop_epoch), p.drop_site);
     const float* qb = p.Q + (int64_t)b * p.q_bs + (int64_t)h * p.q_hs;
     const float* kb = p.K + (int64_t)b * p.k_bs + (int64_t)h * p.k_hs;
     const float* vb = p.V + (int64_t)b * p.v_bs + (int64_t)h * p.v_hs;

@@ -154,11 +154,27 @@ __host__ __device__ __forceinline__ Dropout make_dropout(float p, uint32_t seed,
 }
 // Kernel-side form: the effective seed is `seed + *epoch` when a device-resident step counter is given, so a
 // captured hipGraph draws fresh masks on every replay (the counter is bumped by ick_counter_add in the graph).
+//
+// epoch_seed(): the counter is read through the SCALAR cache.  As `*epoch` the compiler issued a vector load of the
+// uniform address and waited for it on the spot (global_load_dword, s_waitcnt vmcnt(0), v_readfirstlane): one L2 round
+// trip at the head of every row-chain and attention launch of a training step, before any other load of the kernel had
+// been requested.  The counter is written by an earlier kernel of the stream and a dispatch starts with a clean scalar
+// cache, so the scalar read sees it; the wait sits inside the statement because the compiler does not count this load.
+__device__ __forceinline__ uint32_t epoch_seed(uint32_t seed, const uint32_t* epoch) {
+    if (epoch == nullptr) return seed;      // uniform
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(epoch) : "memory");
+    return seed + v;
+#else
+    return seed + *epoch;                   // (the host pass only parses device code)
+#endif
+}
 struct DropArg {
     float p;
     uint32_t seed, site;
     const uint32_t* epoch;
-    __device__ __forceinline__ Dropout get() const { return make_dropout(p, epoch ? seed + *epoch : seed, site); }
+    __device__ __forceinline__ Dropout get() const { return make_dropout(p, epoch_seed(seed, epoch), site); }
 };
 
 }  // namespace ick

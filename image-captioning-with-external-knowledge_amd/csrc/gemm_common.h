@@ -116,7 +116,7 @@ __device__ __forceinline__ void gemm_epilogue(const ick_gemm_args& p, f32x4 (&ac
     const float alpha = p.alpha;
     int64_t coff[TM][4];
     int rowid[TM][4];
-    const Dropout drop = make_dropout(p.drop_p, p.drop_epoch ? p.drop_seed + *p.drop_epoch : p.drop_seed, p.drop_site);
+    const Dropout drop = make_dropout(p.drop_p, epoch_seed(p.drop_seed, p.drop_epoch), p.drop_site);
     {
         int rws[TM * 4];
         int64_t mo[TM * 4];

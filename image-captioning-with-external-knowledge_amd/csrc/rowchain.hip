@@ -64,7 +64,7 @@ __global__ __launch_bounds__(NW * 64) void rowchain_fwd_kernel(ick_rowchain_args
     // Thread mappings are chosen so that nothing below divides per element: at 16 waves a VALU instruction of
     // every thread costs 16 cycles of the CU, a 32-bit division ~40 of them.
     ICK_CSTAMP(0);
-    const uint32_t seed = p.drop_epoch ? p.drop_seed + *p.drop_epoch : p.drop_seed;
+    const uint32_t seed = epoch_seed(p.drop_seed, p.drop_epoch);
     // ICK_CHAIN_PROJ: projection only -- y2 = act(A W2^T + b2) with A (M, d) as the rows GEMM 2 multiplies: the first
     // in_proj of a stack as a 160-workgroup priority launch instead of a 1 160-workgroup generic GEMM that queues behind
     // the bulk kernels of the other stream

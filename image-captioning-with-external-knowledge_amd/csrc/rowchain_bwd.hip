@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kThreads) ICK_CHAIN_BWD_ATTR void rowchain_bwd_kern
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = blockIdx.x * kRows;
     const int d = p.d, M = p.M, dp = (d + 15) & ~15;
-    const uint32_t seed = p.drop_epoch ? p.drop_seed + *p.drop_epoch : p.drop_seed;
+    const uint32_t seed = epoch_seed(p.drop_seed, p.drop_epoch);
     const bool ffn = p.w1p != nullptr;         // uniform
     const bool ln_wave = wave < kRows;
     const int lrow = row0 + wave;
