@@ -391,6 +391,15 @@ struct KVRegs {
             v[q] = STREAM ? ld4o_stream(vbase, o) : ld4o(vbase, o);
         }
     }
+    // the same with this lane's NPC row offsets already known (off[q]: byte offset of the row of position p0 + 8 q + p8,
+    // clamped by the caller; keys and values share the addressing)
+    __device__ __forceinline__ void load_at(const float* kbase, const float* vbase, const uint32_t (&off)[NPC]) {
+        const uint32_t c16 = 16u * (uint32_t)(threadIdx.x & 7);
+#pragma unroll
+        for (int q = 0; q < NPC; ++q) k[q] = ld4o(kbase, off[q] + c16);
+#pragma unroll
+        for (int q = 0; q < NPC; ++q) v[q] = ld4o(vbase, off[q] + c16);
+    }
 };
 
 struct AttnState {      // running softmax state of one query row in one wave
@@ -679,12 +688,27 @@ __global__ __launch_bounds__(kNT) void dec_self_kernel(SelfArgs a) {
     KVRegs<NPC> kv;
     const int p8 = lane >> 3, c = lane & 7;
     const int plast = max(pos - 1, 0);                               // position `pos` itself is not in the cache yet
-    auto cache_off = [&](int p) {
-        p = min(p, plast);
-        const int64_t cr = a.anc ? (int64_t)a.anc[myrow * a.ML + p] : myrow;
-        return (uint32_t)(((cr * a.H + h) * a.ML + p) * kDhp) * 4u;
+    // Row offsets of a chunk's positions.  With beam search the cache row of position p is the ancestor's
+    // (anc[row][p]): those indices are fetched for the whole chunk in ONE basic block -- as a per-position lambda inside
+    // the load loop every index load sat in a branch of its own and was waited for on the spot (load, vmcnt(0), key load,
+    // and the same again for the value: eight memory round trips per chunk, ISA of round 5's build).
+    uint32_t coff[NPC];
+    auto cache_offs = [&](int p0) {
+        int pp[NPC];
+        int64_t cr[NPC];
+#pragma unroll
+        for (int q = 0; q < NPC; ++q) pp[q] = min(min(p0 + 8 * q + p8, pos), plast);
+        if (a.anc != nullptr) {      // uniform
+#pragma unroll
+            for (int q = 0; q < NPC; ++q) cr[q] = (int64_t)a.anc[myrow * a.ML + pp[q]];
+        } else {
+#pragma unroll
+            for (int q = 0; q < NPC; ++q) cr[q] = myrow;
+        }
+#pragma unroll
+        for (int q = 0; q < NPC; ++q) coff[q] = (uint32_t)(((cr[q] * a.H + h) * a.ML + pp[q]) * kDhp) * 4u;
     };
-    if (have_row) kv.template load<false>(a.kc, a.vc, 0, pos + 1, cache_off, cache_off);
+    if (have_row) { cache_offs(0); kv.load_at(a.kc, a.vc, coff); }
     ColDot<6> od;
     od.load(a.w.out_wt, d, h * dh, dh, d4);
     qd.template run<G>(&xs[0][0], 3 * dh, &qkv[0][0], 128, 1.f, false);
@@ -707,7 +731,7 @@ __global__ __launch_bounds__(kNT) void dec_self_kernel(SelfArgs a) {
         st[0].init();
         // positions 0 .. pos; loads cover the cached ones (< pos), the new row comes from the registers above
         for (int p0 = 0; p0 <= pos; p0 += 8 * NPC) {
-            if (p0 > 0) kv.template load<false>(a.kc, a.vc, p0, pos + 1, cache_off, cache_off);
+            if (p0 > 0) { cache_offs(p0); kv.load_at(a.kc, a.vc, coff); }
             attend_chunk<NPC, 1>(kv, q4, p0, pos + 1, dh, pos, kn, vn, st);
         }
         attend_reduce(st[0]);
