@@ -234,6 +234,12 @@ def test_presplit_copy_is_the_exact_three_way_split(ops, N, K, transposed):
     (2052, 1028, 516, False, 0, 1, (128, 128)),       # ragged edges of the square tile
     (2052, 1028, 516, True, 0, 1, (128, 128)),        # k-major A on the square tile
     (23044, 260, 516, True, 0, 1, (128, 80)),         # k-major A, K tail of 4 k lines
+    # split K on the pre-split kernel: the (K slice, tile) pairs are dealt to the XCDs slice-major for ANY slice count
+    # (a permutation of the workgroups: a wrong one shows as missing or doubled slices)
+    (600, 300, 13824, True, 0, 8, (128, 80)),         # one cross K/V weight gradient as the step launches it
+    (600, 300, 4096, True, 0, 2, (128, 80)), (600, 300, 4096, True, 0, 3, (128, 80)),
+    (600, 300, 4096, True, 0, 5, (128, 80)), (600, 300, 4096, True, 0, 7, (128, 80)),
+    (600, 300, 4096, True, 0, 16, (128, 80)), (1280, 300, 4096, False, 0, 9, (128, 80)),
 ])
 def test_presplit_gemm_error_not_above_exact_path(ops, M, N, K, akm, grp, split_k, tile):
     if grp:
